@@ -1,0 +1,167 @@
+/* myrtle_vision HIP hot path -- C ABI (libmyrtle_vision_hip.so), gfx950 / MI355X only.
+ *
+ * The reference (MyrtleSoftware/myrtle-vision) has no FFI: its hot path is stock torch.nn
+ * modules dispatching to ATen kernels.  Each entry point below replaces the ATen dispatch of
+ * one reference call site (cited per function as <reference file>:<line>, relative to the
+ * reference repo root, file src/myrtle_vision/models/vit.py unless another file is named).
+ *
+ * Conventions (all entry points):
+ *   - plain pointers + sizes; no torch types; device pointers unless stated
+ *   - return 0 on success, a negative MV_ERR_* otherwise; never throw, never synchronise,
+ *     never allocate (callers pass workspaces); work is enqueued on `stream`
+ *   - re-entrant, no global or thread-local state (autograd calls backward from a worker thread)
+ *   - "rows x dim" tensors are row-major; `ld*` are leading dimensions in ELEMENTS
+ *   - dtype codes: MV_F32 / MV_BF16
+ *   - MFMA entry points (mv_gemm_*_bf16, mv_attention_*) need 16-byte aligned pointers and
+ *     leading dimensions that are multiples of 8 elements
+ */
+#ifndef MYRTLE_VISION_HIP_H
+#define MYRTLE_VISION_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef void* mv_stream_t; /* hipStream_t */
+
+enum { MV_F32 = 0, MV_BF16 = 1 };
+
+enum {
+  MV_OK = 0,
+  MV_ERR_SHAPE = -1,       /* dimension constraint violated */
+  MV_ERR_ALIGN = -2,       /* pointer / leading-dimension alignment */
+  MV_ERR_LAUNCH = -3,      /* hipGetLastError() after launch */
+  MV_ERR_UNSUPPORTED = -4, /* dtype / epilogue combination not built */
+  MV_ERR_WORKSPACE = -5    /* workspace too small */
+};
+
+/* epilogues of the GEMM entry points */
+enum {
+  MV_EPI_NONE = 0,     /* C = acc (+ bias) */
+  MV_EPI_GELU = 1,     /* out2 = acc + bias (pre-activation, optional); C = gelu_erf(acc + bias) */
+  MV_EPI_RESIDUAL = 2, /* C = acc + bias + aux              (aux: fp32 [M, ld_aux]) */
+  MV_EPI_DGELU = 3,    /* C = acc * gelu_erf'(aux)          (aux: pre-activation, dtype of A) */
+  MV_EPI_EMBED = 4     /* patch-embedding: row m of the GEMM is patch (m % aux_i) of image (m / aux_i);
+                          C row = img*(aux_i+1) + 1 + patch;  C = acc + bias + aux[1 + patch]  (aux: fp32 [aux_i+1, N]) */
+};
+
+int mv_version(void);
+const char* mv_error_string(int code);
+/* number of bytes of workspace mv_gemm_tn_bf16 / mv_layernorm_bwd want for these sizes */
+size_t mv_gemm_tn_workspace_bytes(int M, int N, int Kc);
+size_t mv_layernorm_bwd_workspace_bytes(int rows, int dim);
+
+/* ---- LayerNorm: nn.LayerNorm(dim), eps 1e-5 -- vit.py:37,41 (PreNorm), :332,:353 (decoder norms) ----
+ * x: fp32 [rows, dim] with row stride ldx (lets the decoder read x[:,0] / x[:,1:] in place);
+ * y: y_dtype [rows, dim] dense; mean/rstd: fp32 [rows] (saved for backward). */
+int mv_layernorm_fwd(const float* x, long ldx, const float* gamma, const float* beta, void* y, int y_dtype,
+                     float* mean, float* rstd, int rows, int dim, float eps, mv_stream_t stream);
+/* dx[rows, dim] (fp32, row stride lddx) = dLN(dy) (+ dx_add if non-null, same layout as dx; may alias dx);
+ * dgamma/dbeta: fp32 [dim], overwritten (accumulate=0) or added to (accumulate=1). */
+int mv_layernorm_bwd(const void* dy, int dy_dtype, const float* x, long ldx, const float* gamma,
+                     const float* mean, const float* rstd, const float* dx_add, float* dx, long lddx,
+                     float* dgamma, float* dbeta, int accumulate, float* workspace, size_t workspace_bytes,
+                     int rows, int dim, mv_stream_t stream);
+
+/* ---- dense contractions on MFMA (bf16 in, fp32 accumulate) ----
+ * nn.Linear forward  y = x W^T + b : patch_to_embedding :278, to_qkv :86, to_out :98, net.0/net.3 :48-51,
+ * decoder.linear :333/:354.   C[M,N] = A[M,K] . B[N,K]^T  (both operands K-contiguous).
+ * The same entry point computes the input gradient dX = dY . W with B = W^T[K_in, N_out] (a transposed
+ * bf16 copy the host keeps), i.e. autograd's mm for AddmmBackward.
+ * Requirements: K % 8 == 0 is NOT required, but rows must be readable (and zero) up to round_up(K, 8). */
+int mv_gemm_nt_bf16(const void* A, int lda, const void* B, int ldb, void* C, int ldc, int c_dtype, int M, int N,
+                    int K, const float* bias, int epilogue, const void* aux, int ld_aux, int aux_i, void* out2,
+                    int ld_out2, mv_stream_t stream);
+/* weight gradient  dW[M,N] (fp32) (+)= A[Kc,M]^T . B[Kc,N]  (A = dY, B = X; contraction over tokens) --
+ * autograd's mm(dY^T, X) for every nn.Linear above.  Split over Kc into fp32 slabs in `workspace`,
+ * reduced deterministically.  colsum (optional, fp32 [M]) (+)= column sums of A = bias gradient. */
+int mv_gemm_tn_bf16(const void* A, int lda, const void* B, int ldb, float* C, int ldc, int M, int N, int Kc,
+                    int accumulate, float* colsum, float* workspace, size_t workspace_bytes, mv_stream_t stream);
+
+/* ---- generic fp32 contraction (exact-parity mode, odd shapes, materialised attention) ----
+ * C[b1,b2][m,n] = sum_k A[b1,b2][m,k] * B[b1,b2][k,n] with arbitrary element strides; same epilogues
+ * (aux/out2 are fp32).  alpha scales the accumulator before the epilogue; accumulate adds into C. */
+int mv_gemm_f32(const float* A, long sa_m, long sa_k, long sa_b1, long sa_b2, const float* B, long sb_k, long sb_n,
+                long sb_b1, long sb_b2, float* C, long sc_m, long sc_n, long sc_b1, long sc_b2, int M, int N, int K,
+                int nb1, int nb2, float alpha, int accumulate, const float* bias, int epilogue, const float* aux,
+                long ld_aux, int aux_i, float* out2, long ld_out2, mv_stream_t stream);
+
+/* ---- fused multi-head self-attention core -- Attention.forward vit.py:87-96 ----
+ * qkv: bf16 [B, N, 3, H, 64] (the to_qkv output, feature order [q|k|v][head][dh], vit.py:87-90);
+ * out: bf16 [B, N, H*64] = (softmax(q k^T * scale) v).transpose(1,2).reshape(B,N,C);  lse: fp32 [B,H,N].
+ * dim_head must be 64 (all shipped configs; ViT default dim_head=64, vit.py:178); N <= 320. */
+int mv_attention_fwd(const void* qkv, void* out, float* lse, int B, int N, int H, float scale, mv_stream_t stream);
+/* dqkv: bf16 [B, N, 3, H, 64]; dout/out: bf16 [B, N, H*64] */
+int mv_attention_bwd(const void* qkv, const void* out, const void* dout, const float* lse, void* dqkv, int B, int N,
+                     int H, float scale, mv_stream_t stream);
+
+/* ---- row softmax for the materialised attention path (fp32): attn.softmax(dim=-1) vit.py:93 ---- */
+int mv_softmax_fwd(const float* x, float* y, long rows, int cols, float scale, mv_stream_t stream);
+/* dx = scale * y * (dy - sum(dy*y)) */
+int mv_softmax_bwd(const float* y, const float* dy, float* dx, long rows, int cols, float scale, mv_stream_t stream);
+
+/* ---- patchify: vit.py:271-275  (B,C,H,W) fp32 -> (B*gh*gw, p*p*C) out_dtype, k = (py*p+px)*C + c ---- */
+int mv_patchify(const float* img, void* out, int out_dtype, int B, int C, int H, int W, int p, mv_stream_t stream);
+/* cls row of the embedding: x[b, 0, :] = cls[:] + pos[0, :]  (vit.py:283-290,305-310); x fp32 [B, T, D] */
+int mv_embed_cls(const float* cls, const float* pos, float* x, int B, int T, int D, mv_stream_t stream);
+/* backward of the embedding assembly: dpos[t, :] (+)= sum_b dx[b, t, :];  dcls[:] (+)= sum_b dx[b, 0, :] */
+int mv_embed_bwd(const float* dx, float* dpos, float* dcls, int accumulate, int B, int T, int D, mv_stream_t stream);
+/* gather rows 1..T-1 of every image: dst[b*(T-1)+t-1, :] = (dtype) src[b, t, :]  (dY for the patch GEMM) */
+int mv_gather_patch_rows(const float* src, void* dst, int dst_dtype, int B, int T, int D, mv_stream_t stream);
+
+/* ---- casts / layout ---- */
+/* dst (dst_dtype) = src (src_dtype), n elements */
+int mv_cast(const void* src, int src_dtype, void* dst, int dst_dtype, long n, mv_stream_t stream);
+/* weight prep for the MFMA path: w fp32 [R, C] -> w_bf16 [R, ldw] and wt_bf16 [C, ldt] (transposed), pads zeroed;
+ * either output may be NULL */
+int mv_weight_prep(const float* w, void* w_bf16, int ldw, void* wt_bf16, int ldt, int R, int C, mv_stream_t stream);
+/* column sums (bias gradient): out[c] (+)= sum_r x[r, c]; x dtype x_dtype [rows, ld] */
+int mv_colsum(const void* x, int x_dtype, long ld, float* out, int accumulate, long rows, int cols, float* workspace,
+              size_t workspace_bytes, mv_stream_t stream);
+/* y = gelu(x) and dx = dy * gelu'(x) (unfused forms, fp32/bf16) */
+int mv_gelu_fwd(const void* x, void* y, int dtype, long n, mv_stream_t stream);
+int mv_gelu_bwd(const void* x, const void* dy, void* dx, int dtype, long n, mv_stream_t stream);
+/* out = a + b (fp32), n elements: Residual.res_add vit.py:27 in the unfused path */
+int mv_add_f32(const float* a, const float* b, float* out, long n, mv_stream_t stream);
+
+/* ---- fake quantisation (QPyTorch path): utils/quantize.py:46-72,84 ----
+ * fp32 in/out, nearest rounding; float format (exp, man) or fixed point (wl, fl); in place allowed */
+int mv_quant_float(const float* x, float* y, long n, int exp_bits, int man_bits, mv_stream_t stream);
+int mv_quant_fixed(const float* x, float* y, long n, int wl, int fl, int clamp, int symmetric, mv_stream_t stream);
+/* per-tensor affine fake-quant (MinMaxObserver qparams, utils/quantize.py:242-249) */
+int mv_quant_affine(const float* x, float* y, long n, float scale, int zero_point, int qmin, int qmax,
+                    mv_stream_t stream);
+/* running min/max observer: minmax[0] = min(minmax[0], min x), minmax[1] = max(minmax[1], max x);
+ * minmax points at FOUR floats: [2..3] are scratch for the reduction */
+int mv_minmax(const float* x, long n, float* minmax, mv_stream_t stream);
+
+/* ---- loss: nn.CrossEntropyLoss() mean reduction -- classification/train.py:170,250; segmentation/train.py:188,261 ----
+ * logits fp32 viewed as [outer, C, inner] (classification: inner = 1; segmentation: outer = B, inner = H*W);
+ * labels int64 [outer*inner];  loss_sum: fp32 [1], zeroed by this call, receives sum of per-sample losses / count;
+ * dlogits (optional, dl_dtype, same layout, row length ld_dl >= C when inner == 1 with zeroed padding)
+ *   = (softmax - onehot) * grad_scale / count.  argmax (optional int64 [outer*inner]). */
+int mv_cross_entropy(const float* logits, const int64_t* labels, float* loss_sum, void* dlogits, int dl_dtype,
+                     int ld_dl, int64_t* argmax, long outer, int C, long inner, float grad_scale,
+                     mv_stream_t stream);
+
+/* ---- bilinear upsample (align_corners=False): nn.Upsample(size, 'bilinear') vit.py:355,371 ----
+ * small[b, c, y, x] is read at  small + b*sb + c*sc + (y*w + x)*sp  (so the [B, h*w, C] output of the decoder GEMM is
+ * consumed in place: the reference's transpose/view, vit.py:367-369, costs nothing); big: fp32 [B, C, H, W] dense.
+ * backward is the exact adjoint in gather form (deterministic). */
+int mv_upsample_bilinear_fwd(const float* small, long sb, long sc, long sp, float* big, int B, int C, int h, int w,
+                             int H, int W, mv_stream_t stream);
+int mv_upsample_bilinear_bwd(const float* dbig, float* dsmall, long sb, long sc, long sp, int B, int C, int h, int w,
+                             int H, int W, mv_stream_t stream);
+
+/* ---- optimizer: AdamW step (timm create_optimizer 'adamw' -> torch.optim.AdamW), classification/train.py:161-166,274-277 ----
+ * flat fp32 arrays of n elements; decoupled weight decay; bias corrections passed in (host computes from step) */
+int mv_adamw(float* p, const float* g, float* m, float* v, long n, float lr, float beta1, float beta2, float eps,
+             float weight_decay, float bias_corr1, float bias_corr2, float grad_scale, mv_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MYRTLE_VISION_HIP_H */

@@ -1,0 +1,363 @@
+// Fused multi-head self-attention core, forward and backward (reference: Attention.forward vit.py:87-96:
+//   qkv.reshape(b,n,3,H,dh).permute(2,0,3,1,4); softmax(q k^T * dh^-0.5) v; .transpose(1,2).reshape(b,n,c)).
+//
+// ViT sequences are short (N = 197 at 224^2, 257 at 256^2) and dim_head = 64, so one workgroup owns one
+// (image, head): its whole K and V (N x 64 bf16 = 25 KB each) sit in LDS, nothing is tiled over the sequence
+// and no online-softmax rescaling is needed.  All five/two products run on v_mfma_f32_16x16x32_bf16.
+//
+// Orientation is chosen so computed tiles never need a transpose through LDS (cdna guide section 3,
+// "an accumulator tile as the next MFMA's operand"):
+//   forward : S^T[key][query] = K Q^T (keys on accumulator rows).  The softmax reduction over keys is then
+//             in-lane (4 regs x tiles) + two wave shuffles (xor 16, 32), and P^T is already the B operand of
+//             O^T[d][query] = V^T P^T; V^T fragments come from the row-major V tile by ds_read_b64_tr_b16.
+//   backward: S[query][key] and dP[query][key] (keys on lanes).  P and dS are then already the B operands of
+//             dV^T += dO^T P and dK^T += Q^T dS (contraction over accumulator rows = queries); only dS crosses
+//             LDS once (stored transposed, [key][32 queries]) for dQ^T = K^T dS^T.
+// The k order inside such an accumulator-fed MFMA is permuted (slot 8g+j <-> row 4g+j of tile 0 | tile 1);
+// the LDS-side fragments are gathered in the same order (rows 4g+q of each 16-row tile), which is also the
+// conflict-free order for transposed reads of 128-byte rows in the sw128 image (tools/lds_bank_sim.py).
+#include "mv_common.h"
+
+namespace {
+
+constexpr float LOG2E = 1.4426950408889634f;
+constexpr float LN2 = 0.6931471805599453f;
+
+__device__ __forceinline__ int sw128(int row, int ch) { return row * 128 + ((ch ^ (((row >> 1) & 3) << 1)) << 4); }
+// dS^T image: [key][32 queries] bf16 = 64-byte rows; the two 32-byte halves swap on rows 4..7 (mod 8)
+__device__ __forceinline__ int swds(int key, int half) { return key * 64 + ((half ^ ((key >> 2) & 1)) << 5); }
+
+__device__ __forceinline__ bf16x8 cat8(bf16x4 a, bf16x4 b) { return __builtin_shufflevector(a, b, 0, 1, 2, 3, 4, 5, 6, 7); }
+__device__ __forceinline__ bf16x4 tr_read(const char* p) {
+  return __builtin_amdgcn_ds_read_tr16_b64_v4bf16(LDS_PTR(bf16x4, p));
+}
+__device__ __forceinline__ bf16x8 pack8(f32x4 a, f32x4 b) {
+  bf16x8 r = {(bf16_t)a[0], (bf16_t)a[1], (bf16_t)a[2], (bf16_t)a[3], (bf16_t)b[0], (bf16_t)b[1], (bf16_t)b[2], (bf16_t)b[3]};
+  return r;
+}
+__device__ __forceinline__ bf16x4 pack4(f32x4 a) {
+  bf16x4 r = {(bf16_t)a[0], (bf16_t)a[1], (bf16_t)a[2], (bf16_t)a[3]};
+  return r;
+}
+// transposed fragment: column (lane&15) of the 16 columns starting at col0 (elements), k slots 8g+e <-> rows
+// row_base + 4g + e (e<4) and row_base + 16 + 4g + (e-4); tile has 128-byte rows in the sw128 image
+__device__ __forceinline__ bf16x8 tr_frag128(const char* tile, int row_base, int col0, int lane) {
+  const int g = lane >> 4, q = (lane >> 2) & 3, p = lane & 3;
+  const int r = row_base + 4 * g + q, ch = (col0 >> 3) + (p >> 1), b = 8 * (p & 1);
+  return cat8(tr_read(tile + sw128(r, ch) + b), tr_read(tile + sw128(r + 16, ch) + b));
+}
+// row fragment: 8 consecutive k (k-step ks of 32) of row (row_base + lane&15)
+__device__ __forceinline__ bf16x8 row_frag128(const char* tile, int row_base, int ks, int lane) {
+  return *reinterpret_cast<const bf16x8*>(tile + sw128(row_base + (lane & 15), 4 * ks + (lane >> 4)));
+}
+
+// ------------------------------------------------------------------------------------------------
+// forward: one 256-thread workgroup per (image, head); waves take 16-query tiles round-robin
+// ------------------------------------------------------------------------------------------------
+template <int NKT>
+__global__ __launch_bounds__(256, (NKT <= 14 ? 2 : 1)) void attn_fwd_kernel(const bf16_t* __restrict__ qkv, bf16_t* __restrict__ out,
+                                                          float* __restrict__ lse, int N, int H, float scale_log2e) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  constexpr int NP = NKT * 16;
+  char* sK = smem;
+  char* sV = smem + NP * 128;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 4;
+  const int b = blockIdx.x / H, h = blockIdx.x % H;
+  const long D = (long)H * 64;
+  const bf16_t* base = qkv + (long)b * N * 3 * D + h * 64;
+  const u32x4 zero4 = {0u, 0u, 0u, 0u};
+  for (int idx = tid; idx < NP * 8; idx += 256) {
+    const int row = idx >> 3, ch = idx & 7;
+    const long rr = row < N ? row : N - 1;  // unconditional load from a clamped row, zeroed by select
+    u32x4 kv = *reinterpret_cast<const u32x4*>(base + rr * 3 * D + D + ch * 8);
+    u32x4 vv = *reinterpret_cast<const u32x4*>(base + rr * 3 * D + 2 * D + ch * 8);
+    kv = row < N ? kv : zero4;
+    vv = row < N ? vv : zero4;
+    *reinterpret_cast<u32x4*>(sK + sw128(row, ch)) = kv;
+    *reinterpret_cast<u32x4*>(sV + sw128(row, ch)) = vv;
+  }
+  __syncthreads();
+
+  const int nqt = (N + 15) >> 4;
+  for (int qt = wave; qt < nqt; qt += 4) {
+    const int qrow = qt * 16 + (lane & 15);
+    bf16x8 qf[2];
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      u32x4 t = *reinterpret_cast<const u32x4*>(base + (long)(qrow < N ? qrow : N - 1) * 3 * D + 32 * ks + 8 * g);
+      t = qrow < N ? t : zero4;
+      qf[ks] = __builtin_bit_cast(bf16x8, t);
+    }
+    f32x4 st[NKT];
+    float mx = -INFINITY;
+#pragma unroll
+    for (int kt = 0; kt < NKT; ++kt) {
+      f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks)
+        acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(row_frag128(sK, kt * 16, ks, lane), qf[ks], acc, 0, 0, 0);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int key = kt * 16 + 4 * g + r;
+        const float v = key < N ? acc[r] * scale_log2e : -INFINITY;
+        acc[r] = v;
+        mx = fmaxf(mx, v);
+      }
+      st[kt] = acc;
+    }
+    mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+    float sum = 0.f;
+#pragma unroll
+    for (int kt = 0; kt < NKT; ++kt)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const float p = __builtin_amdgcn_exp2f(st[kt][r] - mx);
+        st[kt][r] = p;
+        sum += p;
+      }
+    sum += __shfl_xor(sum, 16, 64);
+    sum += __shfl_xor(sum, 32, 64);
+
+    f32x4 o[4];
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt) o[dt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int u = 0; u < NKT / 2; ++u) {
+      const bf16x8 pf = pack8(st[2 * u], st[2 * u + 1]);
+#pragma unroll
+      for (int dt = 0; dt < 4; ++dt)
+        o[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(tr_frag128(sV, 32 * u, dt * 16, lane), pf, o[dt], 0, 0, 0);
+    }
+    if (qrow < N) {
+      const float inv = 1.0f / sum;
+      bf16_t* orow = out + ((long)b * N + qrow) * D + h * 64 + 4 * g;
+#pragma unroll
+      for (int dt = 0; dt < 4; ++dt) {
+        const f32x4 v = {o[dt][0] * inv, o[dt][1] * inv, o[dt][2] * inv, o[dt][3] * inv};
+        *reinterpret_cast<bf16x4*>(orow + dt * 16) = pack4(v);
+      }
+      if (g == 0) lse[((long)b * H + h) * N + qrow] = (mx + __builtin_amdgcn_logf(sum)) * LN2;
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// backward: one 512-thread workgroup per (image, head); wave w owns key tiles w, w+8, (w+16)
+// ------------------------------------------------------------------------------------------------
+template <int NKT, int KPW>  // NKT 16-key tiles (even), KPW key tiles per wave
+__global__ __launch_bounds__(512, 1) void attn_bwd_kernel(const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ out,
+                                                          const bf16_t* __restrict__ dout, const float* __restrict__ lse,
+                                                          bf16_t* __restrict__ dqkv, int N, int H, float scale) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  constexpr int NP = NKT * 16;
+  char* sK = smem;                         // [NP][64] bf16, sw128
+  char* sV = sK + NP * 128;
+  char* sPair = sV + NP * 128;             // 2 buffers x { Q[32][64], dO[32][64] }, sw128 : 2 x 8 KiB
+  char* sDS = sPair + 2 * 8192;            // 2 buffers x [NP][32] bf16 (dS^T), swds
+  float* sLse = reinterpret_cast<float*>(sDS + 2 * NP * 64);  // [NP] lse * log2(e), +inf on padding rows
+  float* sDelta = sLse + NP;                                  // [NP] rowsum(dO * O)
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 4;
+  const int b = blockIdx.x / H, h = blockIdx.x % H;
+  const long D = (long)H * 64;
+  const bf16_t* base = qkv + (long)b * N * 3 * D + h * 64;
+  const bf16_t* dobase = dout + (long)b * N * D + h * 64;
+  const bf16_t* obase = out + (long)b * N * D + h * 64;
+  bf16_t* dbase = dqkv + (long)b * N * 3 * D + h * 64;
+  const u32x4 zero4 = {0u, 0u, 0u, 0u};
+  const float c2 = scale * LOG2E;
+
+  for (int idx = tid; idx < NP * 8; idx += 512) {
+    const int row = idx >> 3, ch = idx & 7;
+    const long rr = row < N ? row : N - 1;  // unconditional load from a clamped row, zeroed by select
+    u32x4 kv = *reinterpret_cast<const u32x4*>(base + rr * 3 * D + D + ch * 8);
+    u32x4 vv = *reinterpret_cast<const u32x4*>(base + rr * 3 * D + 2 * D + ch * 8);
+    kv = row < N ? kv : zero4;
+    vv = row < N ? vv : zero4;
+    *reinterpret_cast<u32x4*>(sK + sw128(row, ch)) = kv;
+    *reinterpret_cast<u32x4*>(sV + sw128(row, ch)) = vv;
+  }
+  // dS^T rows of key tiles that are entirely padding are never written: keep them finite (0 * K-pad-row = 0)
+  for (int idx = tid; idx < 2 * NP * 4; idx += 512) reinterpret_cast<u32x4*>(sDS)[idx] = zero4;
+  for (int row = tid; row < NP; row += 512) {
+    float dl = 0.f, l2 = INFINITY;
+    if (row < N) {
+      l2 = lse[((long)b * H + h) * N + row] * LOG2E;
+#pragma unroll
+      for (int c = 0; c < 8; ++c) {
+        const u32x4 a = *reinterpret_cast<const u32x4*>(dobase + (long)row * D + c * 8);
+        const u32x4 o = *reinterpret_cast<const u32x4*>(obase + (long)row * D + c * 8);
+        const bf16x8 av = __builtin_bit_cast(bf16x8, a), ov = __builtin_bit_cast(bf16x8, o);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) dl += (float)av[e] * (float)ov[e];
+      }
+    }
+    sLse[row] = l2;
+    sDelta[row] = dl;
+  }
+
+  // pair staging: 512 threads = 2 tiles x 32 rows x 8 chunks: thread -> (which = tid>>8, row = (tid>>3)&31, ch = tid&7)
+  const int p_which = tid >> 8, p_row = (tid >> 3) & 31, p_ch = tid & 7;
+  const bf16_t* pair_src = p_which == 0 ? base + p_ch * 8 : dobase + p_ch * 8;
+  const long pair_ld = p_which == 0 ? 3 * D : D;
+  auto load_pair = [&](int u) -> u32x4 {
+    const int q = 32 * u + p_row;
+    const u32x4 v = *reinterpret_cast<const u32x4*>(pair_src + (long)(q < N ? q : N - 1) * pair_ld);
+    return q < N ? v : zero4;
+  };
+  auto store_pair = [&](int buf, u32x4 v) {
+    *reinterpret_cast<u32x4*>(sPair + buf * 8192 + p_which * 4096 + sw128(p_row, p_ch)) = v;
+  };
+
+  f32x4 adk[KPW][4], adv[KPW][4];
+#pragma unroll
+  for (int i = 0; i < KPW; ++i)
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt) {
+      adk[i][dt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+      adv[i][dt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    }
+
+  constexpr int NQP = NKT / 2;
+  store_pair(0, load_pair(0));
+  __syncthreads();
+
+  const int nkt_valid = (N + 15) >> 4;
+  for (int u = 0; u < NQP; ++u) {
+    const int cur = u & 1;
+    u32x4 nxt = zero4;
+    if (u + 1 < NQP) nxt = load_pair(u + 1);
+    const char* sQ = sPair + cur * 8192;
+    const char* sDO = sQ + 4096;
+    char* sds = sDS + cur * (NP * 64);
+
+    if (32 * u < N) {
+#pragma unroll
+      for (int i = 0; i < KPW; ++i) {
+        const int kt = wave + 8 * i;
+        if (kt >= nkt_valid) continue;
+        const int key = kt * 16 + (lane & 15);
+        f32x4 s[2], dp[2];
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+          s[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+          dp[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+          for (int ks = 0; ks < 2; ++ks) {
+            s[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(row_frag128(sQ, t * 16, ks, lane),
+                                                           row_frag128(sK, kt * 16, ks, lane), s[t], 0, 0, 0);
+            dp[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(row_frag128(sDO, t * 16, ks, lane),
+                                                            row_frag128(sV, kt * 16, ks, lane), dp[t], 0, 0, 0);
+          }
+        }
+        // P = exp2(S*c2 - lse2[q]),  dS = P * (dP - delta[q]) * scale ; q = 32u + 16t + 4g + r, key on the lane
+        f32x4 pp[2], ds[2];
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const int ql = 32 * u + 16 * t + 4 * g + r;
+            float p = __builtin_amdgcn_exp2f(s[t][r] * c2 - sLse[ql]);
+            p = key < N ? p : 0.f;
+            pp[t][r] = p;
+            ds[t][r] = p * (dp[t][r] - sDelta[ql]) * scale;
+          }
+        const bf16x8 pf = pack8(pp[0], pp[1]);
+        const bf16x8 dsf = pack8(ds[0], ds[1]);
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt) {
+          adv[i][dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(tr_frag128(sDO, 0, dt * 16, lane), pf, adv[i][dt], 0, 0, 0);
+          adk[i][dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(tr_frag128(sQ, 0, dt * 16, lane), dsf, adk[i][dt], 0, 0, 0);
+        }
+        // dS^T -> LDS: row = key, 4 consecutive queries per lane per q-tile
+#pragma unroll
+        for (int t = 0; t < 2; ++t) *reinterpret_cast<bf16x4*>(sds + swds(key, t) + 8 * g) = pack4(ds[t]);
+      }
+    }
+    if (u + 1 < NQP) store_pair(cur ^ 1, nxt);
+    __syncthreads();
+
+    // dQ^T[d][q] = sum_key K^T[d][key] dS^T[key][q] : 2 q-tiles x 4 d-tiles = 8 output tiles, one per wave
+    if (32 * u < N) {
+      const int t = wave >> 2, dt = wave & 3;
+      f32x4 dq = {0.f, 0.f, 0.f, 0.f};
+      const int q4 = (lane >> 2) & 3, p = lane & 3;
+      for (int v = 0; v < NQP; ++v) {
+        if (32 * v >= N) break;
+        const int r = 32 * v + 4 * g + q4;
+        const bf16x8 dsf = cat8(tr_read(sds + swds(r, t) + 8 * p), tr_read(sds + swds(r + 16, t) + 8 * p));
+        dq = __builtin_amdgcn_mfma_f32_16x16x32_bf16(tr_frag128(sK, 32 * v, dt * 16, lane), dsf, dq, 0, 0, 0);
+      }
+      const int q = 32 * u + 16 * t + (lane & 15);
+      if (q < N) *reinterpret_cast<bf16x4*>(dbase + (long)q * 3 * D + dt * 16 + 4 * g) = pack4(dq);
+    }
+  }
+
+#pragma unroll
+  for (int i = 0; i < KPW; ++i) {
+    const int kt = wave + 8 * i;
+    const int key = kt * 16 + (lane & 15);
+    if (kt < nkt_valid && key < N) {
+#pragma unroll
+      for (int dt = 0; dt < 4; ++dt) {
+        *reinterpret_cast<bf16x4*>(dbase + (long)key * 3 * D + D + dt * 16 + 4 * g) = pack4(adk[i][dt]);
+        *reinterpret_cast<bf16x4*>(dbase + (long)key * 3 * D + 2 * D + dt * 16 + 4 * g) = pack4(adv[i][dt]);
+      }
+    }
+  }
+}
+
+template <typename K>
+int set_smem(K kernel, int bytes) {
+  return hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, bytes) ==
+                 hipSuccess
+             ? 0
+             : -1;
+}
+
+constexpr int fwd_smem(int nkt) { return nkt * 16 * 128 * 2; }
+constexpr int bwd_smem(int nkt) { return nkt * 16 * 128 * 2 + 2 * 8192 + 2 * nkt * 16 * 64 + 2 * nkt * 16 * 4; }
+
+}  // namespace
+
+extern "C" int mv_attention_fwd(const void* qkv, void* out, float* lse, int B, int N, int H, float scale,
+                                mv_stream_t stream) {
+  MV_REQUIRE(B >= 0 && N > 0 && H > 0 && N <= 320, MV_ERR_SHAPE);
+  MV_REQUIRE(mv_aligned16(qkv) && mv_aligned16(out), MV_ERR_ALIGN);
+  if (B == 0) return MV_OK;
+  hipStream_t s = (hipStream_t)stream;
+  const float sl = scale * LOG2E;
+  if (N <= 224) {
+    static const int a = set_smem(attn_fwd_kernel<14>, fwd_smem(14));
+    if (a) return MV_ERR_LAUNCH;
+    attn_fwd_kernel<14><<<B * H, 256, fwd_smem(14), s>>>((const bf16_t*)qkv, (bf16_t*)out, lse, N, H, sl);
+  } else {
+    static const int a = set_smem(attn_fwd_kernel<20>, fwd_smem(20));
+    if (a) return MV_ERR_LAUNCH;
+    attn_fwd_kernel<20><<<B * H, 256, fwd_smem(20), s>>>((const bf16_t*)qkv, (bf16_t*)out, lse, N, H, sl);
+  }
+  MV_CHECK_LAUNCH();
+  return MV_OK;
+}
+
+extern "C" int mv_attention_bwd(const void* qkv, const void* out, const void* dout, const float* lse, void* dqkv, int B,
+                                int N, int H, float scale, mv_stream_t stream) {
+  MV_REQUIRE(B >= 0 && N > 0 && H > 0 && N <= 320, MV_ERR_SHAPE);
+  MV_REQUIRE(mv_aligned16(qkv) && mv_aligned16(out) && mv_aligned16(dout) && mv_aligned16(dqkv), MV_ERR_ALIGN);
+  if (B == 0) return MV_OK;
+  hipStream_t s = (hipStream_t)stream;
+  if (N <= 224) {
+    static const int a = set_smem(attn_bwd_kernel<14, 2>, bwd_smem(14));
+    if (a) return MV_ERR_LAUNCH;
+    attn_bwd_kernel<14, 2><<<B * H, 512, bwd_smem(14), s>>>((const bf16_t*)qkv, (const bf16_t*)out, (const bf16_t*)dout,
+                                                          lse, (bf16_t*)dqkv, N, H, scale);
+  } else {
+    static const int a = set_smem(attn_bwd_kernel<20, 3>, bwd_smem(20));
+    if (a) return MV_ERR_LAUNCH;
+    attn_bwd_kernel<20, 3><<<B * H, 512, bwd_smem(20), s>>>((const bf16_t*)qkv, (const bf16_t*)out, (const bf16_t*)dout,
+                                                          lse, (bf16_t*)dqkv, N, H, scale);
+  }
+  MV_CHECK_LAUNCH();
+  return MV_OK;
+}

@@ -1,0 +1,696 @@
+// HBM-bound elementwise / layout kernels of the ViT hot path (gfx950).  All are grid-stride, 16 bytes per
+// lane where the layout allows it.
+#include "mv_common.h"
+
+namespace {
+
+inline int ew_grid(long n_items, int per_block = 256) {
+  long g = (n_items + per_block - 1) / per_block;
+  if (g < 1) g = 1;
+  if (g > 4096) g = 4096;  // 16 blocks per CU, grid-stride beyond
+  return (int)g;
+}
+
+// ---- patchify (vit.py:271-275): out[(b*gh+gy)*gw+gx][(py*p+px)*C + c] = img[b][c][gy*p+py][gx*p+px] ----
+// One thread produces the C values of 4 consecutive px (4*C consecutive outputs): its C reads are float4 loads
+// from C planes (coalesced along x), its writes are 4*C consecutive elements.
+template <typename T, int C>
+__global__ __launch_bounds__(256) void patchify_kernel(const float* __restrict__ img, T* __restrict__ out, int B, int H,
+                                                       int W, int p) {
+  const int gw = W / p, gh = H / p;
+  const int p4 = p >> 2;
+  const long total = (long)B * H * (W >> 2);  // one item = 4 pixels of one row
+  for (long it = (long)blockIdx.x * 256 + threadIdx.x; it < total; it += (long)gridDim.x * 256) {
+    const int x4 = (int)(it % (W >> 2));
+    const long t = it / (W >> 2);
+    const int y = (int)(t % H);
+    const int b = (int)(t / H);
+    const int gx = x4 / p4, px = (x4 - gx * p4) * 4;
+    const int gy = y / p, py = y - gy * p;
+    float v[C][4];
+#pragma unroll
+    for (int c = 0; c < C; ++c) {
+      const float4 f = *reinterpret_cast<const float4*>(img + (((long)b * C + c) * H + y) * W + x4 * 4);
+      v[c][0] = f.x; v[c][1] = f.y; v[c][2] = f.z; v[c][3] = f.w;
+    }
+    T* o = out + (((long)b * gh + gy) * gw + gx) * ((long)p * p * C) + ((long)py * p + px) * C;
+#pragma unroll
+    for (int e = 0; e < 4; ++e)
+#pragma unroll
+      for (int c = 0; c < C; ++c) o[e * C + c] = (T)v[c][e];
+  }
+}
+
+template <typename T>
+__global__ void patchify_generic_kernel(const float* __restrict__ img, T* __restrict__ out, int B, int C, int H, int W,
+                                        int p) {
+  const int gw = W / p, gh = H / p;
+  const long total = (long)B * C * H * W;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    // iterate in OUTPUT order so writes coalesce
+    const long pd = (long)p * p * C;
+    const long row = i / pd;
+    const int k = (int)(i - row * pd);
+    const int c = k % C, pp = k / C, px = pp % p, py = pp / p;
+    const int gx = (int)(row % gw);
+    const long t = row / gw;
+    const int gy = (int)(t % gh), b = (int)(t / gh);
+    out[i] = (T)img[(((long)b * C + c) * H + gy * p + py) * W + gx * p + px];
+  }
+}
+
+__global__ void embed_cls_kernel(const float* __restrict__ cls, const float* __restrict__ pos, float* __restrict__ x,
+                                 int B, int T, int D) {
+  const long total = (long)B * D;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const int d = (int)(i % D);
+    const long b = i / D;
+    x[b * T * D + d] = cls[d] + pos[d];
+  }
+}
+
+// dpos[t][d] = sum_b dx[b][t][d]; dcls[d] = dpos[0][d]
+__global__ void embed_bwd_kernel(const float* __restrict__ dx, float* dpos, float* dcls, int accumulate, int B, int T,
+                                 int D) {
+  const long total = (long)T * D;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    float s = 0.f;
+    for (int b = 0; b < B; ++b) s += dx[(long)b * total + i];
+    if (dpos) dpos[i] = accumulate ? dpos[i] + s : s;
+    if (dcls && i < D) dcls[i] = accumulate ? dcls[i] + s : s;
+  }
+}
+
+template <typename T>
+__global__ void gather_patch_rows_kernel(const float* __restrict__ src, T* __restrict__ dst, int B, int Tk, int D) {
+  const int D4 = D >> 2;
+  const long total = (long)B * (Tk - 1) * D4;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const int d4 = (int)(i % D4);
+    const long r = i / D4;
+    const long b = r / (Tk - 1), t = r - b * (Tk - 1);
+    const float4 v = *reinterpret_cast<const float4*>(src + ((b * Tk + t + 1) * (long)D) + d4 * 4);
+    T* o = dst + r * D + d4 * 4;
+    if constexpr (sizeof(T) == 4) {
+      *reinterpret_cast<float4*>(o) = v;
+    } else {
+      bf16x4 w = {(bf16_t)v.x, (bf16_t)v.y, (bf16_t)v.z, (bf16_t)v.w};
+      *reinterpret_cast<bf16x4*>(o) = w;
+    }
+  }
+}
+
+template <typename S, typename T>
+__global__ void cast_kernel(const S* __restrict__ src, T* __restrict__ dst, long n) {
+  const long n4 = n >> 2;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long)gridDim.x * blockDim.x) {
+    float v[4];
+    if constexpr (sizeof(S) == 4) {
+      const float4 f = reinterpret_cast<const float4*>(src)[i];
+      v[0] = f.x; v[1] = f.y; v[2] = f.z; v[3] = f.w;
+    } else {
+      const bf16x4 f = reinterpret_cast<const bf16x4*>(src)[i];
+      v[0] = (float)f[0]; v[1] = (float)f[1]; v[2] = (float)f[2]; v[3] = (float)f[3];
+    }
+    if constexpr (sizeof(T) == 4) {
+      reinterpret_cast<float4*>(dst)[i] = make_float4(v[0], v[1], v[2], v[3]);
+    } else {
+      bf16x4 w = {(bf16_t)v[0], (bf16_t)v[1], (bf16_t)v[2], (bf16_t)v[3]};
+      reinterpret_cast<bf16x4*>(dst)[i] = w;
+    }
+  }
+  for (long i = (n4 << 2) + (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x)
+    dst[i] = (T)(float)src[i];
+}
+
+// w fp32 [R][C] -> wb bf16 [R][ldw] (pad columns zero) and wt bf16 [C][ldt] (pad zero).  32x32 tile through LDS.
+__global__ __launch_bounds__(256) void weight_prep_kernel(const float* __restrict__ w, bf16_t* wb, int ldw, bf16_t* wt,
+                                                          int ldt, int R, int C) {
+  __shared__ float tile[32][33];
+  const int r0 = blockIdx.y * 32, c0 = blockIdx.x * 32;
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;  // 32 x 8
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int r = r0 + ty + 8 * i, c = c0 + tx;
+    const float v = (r < R && c < C) ? w[(long)r * C + c] : 0.f;
+    tile[ty + 8 * i][tx] = v;
+    if (wb && r < R && c < ldw) wb[(long)r * ldw + c] = (bf16_t)v;
+  }
+  __syncthreads();
+  if (wt) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int c = c0 + ty + 8 * i, r = r0 + tx;  // wt[c][r]
+      if (c < C && r < ldt) wt[(long)c * ldt + r] = (bf16_t)tile[tx][ty + 8 * i];
+    }
+  }
+}
+
+template <typename T>
+__global__ void gelu_fwd_kernel(const T* __restrict__ x, T* __restrict__ y, long n) {
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x)
+    y[i] = (T)gelu_f((float)x[i]);
+}
+template <typename T>
+__global__ void gelu_bwd_kernel(const T* __restrict__ x, const T* __restrict__ dy, T* __restrict__ dx, long n) {
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x)
+    dx[i] = (T)((float)dy[i] * dgelu_f((float)x[i]));
+}
+__global__ void add_kernel(const float* __restrict__ a, const float* __restrict__ b, float* __restrict__ o, long n) {
+  const long n4 = n >> 2;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long)gridDim.x * blockDim.x) {
+    const float4 x = reinterpret_cast<const float4*>(a)[i], y = reinterpret_cast<const float4*>(b)[i];
+    reinterpret_cast<float4*>(o)[i] = make_float4(x.x + y.x, x.y + y.y, x.z + y.z, x.w + y.w);
+  }
+  for (long i = (n4 << 2) + (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x)
+    o[i] = a[i] + b[i];
+}
+
+// ---- fake quantisation: fused quant+dequant, fp32 in/out (utils/quantize.py:46-72,84; algorithm: qtorch 0.3.0
+// float_quantize_nearest / fixed_point_quantize_nearest, restated in oracle/quant_oracle.py) ----
+__device__ __forceinline__ float quant_float_one(float a, int exp_bits, int man_bits) {
+  const unsigned bits = __float_as_uint(a);
+  const unsigned sign = bits & 0x80000000u;
+  const unsigned mask = (1u << (23 - man_bits)) - 1u;
+  const unsigned half = 1u << (23 - man_bits - 1);
+  const int texp = (int)((bits & 0x7FFFFFFFu) >> 23) - 127;
+  const int min_exp = -((1 << (exp_bits - 1)) - 2);
+  if (texp < min_exp) {  // target-subnormal range: round on the grid of spacing 2^(min_exp - man)
+    const float shift = __uint_as_float(((unsigned)(127 + min_exp) << 23) | sign);
+    const float val = a + shift;
+    const unsigned qb = (__float_as_uint(val) + half) & ~mask;
+    return __uint_as_float(qb) - shift;
+  }
+  unsigned q = (bits + half) & ~mask;
+  const int qexp = (int)((q & 0x7FFFFFFFu) >> 23);
+  const int max_store = (1 << (exp_bits - 1)) - 1 + 127;
+  const int min_store = min_exp + 127;
+  if (qexp > max_store) {
+    const unsigned max_man = (0x7FFFFFu >> (23 - man_bits)) << (23 - man_bits);
+    q = sign | ((unsigned)max_store << 23) | max_man;
+  } else if (qexp < min_store && q != 0u) {
+    const unsigned mag = q & 0x7FFFFFFFu;
+    q = mag > ((unsigned)(min_store - 1) << 23) ? (sign | ((unsigned)min_store << 23)) : 0u;
+  }
+  return __uint_as_float(q);
+}
+
+__global__ void quant_float_kernel(const float* __restrict__ x, float* __restrict__ y, long n, int e, int m) {
+  const long n4 = n >> 2;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long)gridDim.x * blockDim.x) {
+    const float4 v = reinterpret_cast<const float4*>(x)[i];
+    reinterpret_cast<float4*>(y)[i] = make_float4(quant_float_one(v.x, e, m), quant_float_one(v.y, e, m),
+                                                  quant_float_one(v.z, e, m), quant_float_one(v.w, e, m));
+  }
+  for (long i = (n4 << 2) + (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x)
+    y[i] = quant_float_one(x[i], e, m);
+}
+
+__global__ void quant_fixed_kernel(const float* __restrict__ x, float* __restrict__ y, long n, float scale, float inv,
+                                   float tmin, float tmax, int clamp) {
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+    float r = floorf(x[i] * scale + 0.5f) * inv;
+    if (clamp) r = fminf(fmaxf(r, tmin), tmax);
+    y[i] = r;
+  }
+}
+
+__global__ void quant_affine_kernel(const float* __restrict__ x, float* __restrict__ y, long n, float scale, float inv,
+                                    int zp, int qmin, int qmax) {
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+    float q = rintf(x[i] * inv) + (float)zp;  // rintf = round-half-even = std::nearbyint default mode
+    q = fminf(fmaxf(q, (float)qmin), (float)qmax);
+    y[i] = (q - (float)zp) * scale;
+  }
+}
+
+// order-preserving float <-> uint map so min/max can use integer atomics
+__device__ __forceinline__ unsigned f2ord(float f) {
+  const unsigned u = __float_as_uint(f);
+  return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+__device__ __forceinline__ float ord2f(unsigned o) {
+  return __uint_as_float((o & 0x80000000u) ? (o & 0x7FFFFFFFu) : ~o);
+}
+__global__ __launch_bounds__(256) void minmax_kernel(const float* __restrict__ x, long n, unsigned* ord) {
+  float mn = INFINITY, mxv = -INFINITY;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
+    const float v = x[i];
+    mn = fminf(mn, v);
+    mxv = fmaxf(mxv, v);
+  }
+  mn = -wave_max(-mn);
+  mxv = wave_max(mxv);
+  if ((threadIdx.x & 63) == 0) {
+    atomicMin(&ord[0], f2ord(mn));
+    atomicMax(&ord[1], f2ord(mxv));
+  }
+}
+__global__ void minmax_begin_kernel(const float* minmax, unsigned* ord) {
+  ord[0] = f2ord(minmax[0]);
+  ord[1] = f2ord(minmax[1]);
+}
+__global__ void minmax_end_kernel(float* minmax, const unsigned* ord) {
+  minmax[0] = ord2f(ord[0]);
+  minmax[1] = ord2f(ord[1]);
+}
+
+// ---- cross entropy, mean reduction.  One wave per sample; classes strided by `inner` -------------------
+template <typename DT>
+__global__ __launch_bounds__(256) void cross_entropy_kernel(const float* __restrict__ logits,
+                                                            const int64_t* __restrict__ labels, float* loss_sum,
+                                                            DT* dlogits, int ld_dl, int64_t* argmax, long outer, int C,
+                                                            long inner, float inv_count, float gscale) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const long total = outer * inner;
+  float block_loss = 0.f;
+  for (long smp = (long)blockIdx.x * 4 + wave; smp < total; smp += (long)gridDim.x * 4) {
+    const long o = smp / inner, in = smp - o * inner;
+    const float* lp = logits + o * C * inner + in;
+    float mx = -INFINITY;
+    int am = 0;
+    for (int c = lane; c < C; c += 64) {
+      const float v = lp[(long)c * inner];
+      if (v > mx) { mx = v; am = c; }
+    }
+    // wave arg-max, first index wins on ties (torch.argmax semantics)
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+      const float om = __shfl_xor(mx, off, 64);
+      const int oa = __shfl_xor(am, off, 64);
+      if (om > mx || (om == mx && oa < am)) { mx = om; am = oa; }
+    }
+    float s = 0.f;
+    for (int c = lane; c < C; c += 64) s += expf(lp[(long)c * inner] - mx);
+    s = wave_sum(s);
+    const int64_t y = labels[smp];
+    const float lse = mx + logf(s);
+    if (lane == 0) {
+      block_loss += lse - lp[(long)y * inner];
+      if (argmax) argmax[smp] = am;
+    }
+    if (dlogits) {
+      const float inv = 1.0f / s;
+      if (inner == 1) {
+        DT* dp = dlogits + o * ld_dl;
+        for (int c = lane; c < ld_dl; c += 64) {
+          float gq = 0.f;
+          if (c < C) gq = (expf(lp[c] - mx) * inv - (c == (int)y ? 1.f : 0.f)) * inv_count * gscale;
+          dp[c] = (DT)gq;
+        }
+      } else {
+        DT* dp = dlogits + o * C * inner + in;
+        for (int c = lane; c < C; c += 64)
+          dp[(long)c * inner] = (DT)((expf(lp[(long)c * inner] - mx) * inv - (c == (int)y ? 1.f : 0.f)) * inv_count * gscale);
+      }
+    }
+  }
+  __shared__ float red[4];
+  if (lane == 0) red[wave] = block_loss;
+  __syncthreads();
+  if (threadIdx.x == 0) atomicAdd(loss_sum, ((red[0] + red[1]) + (red[2] + red[3])) * inv_count);
+}
+
+// segmentation layout (inner > 1): one THREAD per pixel, classes in a register loop, so that consecutive lanes
+// read consecutive pixels of one class plane (coalesced); C is small (17)
+template <typename DT>
+__global__ __launch_bounds__(256) void cross_entropy_pixel_kernel(const float* __restrict__ logits,
+                                                                  const int64_t* __restrict__ labels, float* loss_sum,
+                                                                  DT* dlogits, int64_t* argmax, long outer, int C,
+                                                                  long inner, float inv_count, float gscale) {
+  const long total = outer * inner;
+  float my_loss = 0.f;
+  for (long smp = (long)blockIdx.x * 256 + threadIdx.x; smp < total; smp += (long)gridDim.x * 256) {
+    const long o = smp / inner, in = smp - o * inner;
+    const float* lp = logits + o * C * inner + in;
+    float mx = -INFINITY;
+    int am = 0;
+    for (int c = 0; c < C; ++c) {
+      const float v = lp[(long)c * inner];
+      if (v > mx) { mx = v; am = c; }
+    }
+    float s = 0.f;
+    for (int c = 0; c < C; ++c) s += expf(lp[(long)c * inner] - mx);
+    const int y = (int)labels[smp];
+    my_loss += mx + logf(s) - lp[(long)y * inner];
+    if (argmax) argmax[smp] = am;
+    if (dlogits) {
+      const float inv = 1.0f / s;
+      DT* dp = dlogits + o * C * inner + in;
+      for (int c = 0; c < C; ++c)
+        dp[(long)c * inner] = (DT)((expf(lp[(long)c * inner] - mx) * inv - (c == y ? 1.f : 0.f)) * inv_count * gscale);
+    }
+  }
+  my_loss = wave_sum(my_loss);
+  __shared__ float red[4];
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = my_loss;
+  __syncthreads();
+  if (threadIdx.x == 0) atomicAdd(loss_sum, ((red[0] + red[1]) + (red[2] + red[3])) * inv_count);
+}
+
+// ---- bilinear upsample, align_corners=False (ATen upsample_bilinear2d): src = (dst + 0.5) * scale - 0.5, clamped at 0
+__device__ __forceinline__ void bilin_src(int d, float scale, int in_size, int& i0, int& i1, float& l1) {
+  float s = ((float)d + 0.5f) * scale - 0.5f;
+  if (s < 0.f) s = 0.f;
+  i0 = (int)s;
+  if (i0 > in_size - 1) i0 = in_size - 1;
+  i1 = i0 + (i0 < in_size - 1 ? 1 : 0);
+  l1 = s - (float)i0;
+}
+__global__ void upsample_fwd_kernel(const float* __restrict__ in, long sb, long sc, long sp, float* __restrict__ out,
+                                    int B, int C, int h, int w, int H, int W, float sh, float sw) {
+  const long total = (long)B * C * H * W;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const int X = (int)(i % W);
+    const long t = i / W;
+    const int Y = (int)(t % H);
+    const long bc = t / H;
+    const int c = (int)(bc % C);
+    const long b = bc / C;
+    int y0, y1, x0, x1;
+    float ly, lx;
+    bilin_src(Y, sh, h, y0, y1, ly);
+    bilin_src(X, sw, w, x0, x1, lx);
+    const float* p = in + b * sb + c * sc;
+    const float top = p[(long)(y0 * w + x0) * sp] * (1.f - lx) + p[(long)(y0 * w + x1) * sp] * lx;
+    const float bot = p[(long)(y1 * w + x0) * sp] * (1.f - lx) + p[(long)(y1 * w + x1) * sp] * lx;
+    out[i] = top * (1.f - ly) + bot * ly;
+  }
+}
+// backward in gather form: each input pixel sums the (few) output pixels that reference it -> deterministic.
+__global__ void upsample_bwd_kernel(const float* __restrict__ dout, float* __restrict__ din, long sb, long sc, long sp,
+                                    int B, int C, int h, int w, int H, int W, float sh, float sw) {
+  const long total = (long)B * C * h * w;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    // iterate with c fastest when the small tensor is channels-last (sc == 1) so writes coalesce
+    int x, y, c;
+    long b;
+    if (sc == 1) {
+      c = (int)(i % C);
+      const long t = i / C;
+      x = (int)(t % w);
+      const long t2 = t / w;
+      y = (int)(t2 % h);
+      b = t2 / h;
+    } else {
+      x = (int)(i % w);
+      const long t = i / w;
+      y = (int)(t % h);
+      const long bc = t / h;
+      c = (int)(bc % C);
+      b = bc / C;
+    }
+    // candidate output rows/cols: a superset of those whose (y0|y1) / (x0|x1) can equal y / x
+    int Ylo = (int)floorf(((float)y - 1.f + 0.5f) / sh - 0.5f) - 1, Yhi = (int)ceilf(((float)y + 1.f + 0.5f) / sh - 0.5f) + 1;
+    int Xlo = (int)floorf(((float)x - 1.f + 0.5f) / sw - 0.5f) - 1, Xhi = (int)ceilf(((float)x + 1.f + 0.5f) / sw - 0.5f) + 1;
+    if (Ylo < 0) Ylo = 0;
+    if (Xlo < 0) Xlo = 0;
+    if (Yhi > H - 1) Yhi = H - 1;
+    if (Xhi > W - 1) Xhi = W - 1;
+    float s = 0.f;
+    const float* dp = dout + (b * C + c) * (long)H * W;
+    for (int Y = Ylo; Y <= Yhi; ++Y) {
+      int y0, y1; float ly;
+      bilin_src(Y, sh, h, y0, y1, ly);
+      float wy = 0.f;
+      if (y0 == y) wy += 1.f - ly;
+      if (y1 == y) wy += ly;
+      if (wy == 0.f) continue;
+      for (int X = Xlo; X <= Xhi; ++X) {
+        int x0, x1; float lx;
+        bilin_src(X, sw, w, x0, x1, lx);
+        float wx = 0.f;
+        if (x0 == x) wx += 1.f - lx;
+        if (x1 == x) wx += lx;
+        if (wx != 0.f) s += wy * wx * dp[(long)Y * W + X];
+      }
+    }
+    din[b * sb + c * sc + (long)(y * w + x) * sp] = s;
+  }
+}
+
+// ---- AdamW (torch.optim.AdamW semantics): p *= 1 - lr*wd; m,v update; p -= lr/bc1 * m / (sqrt(v)/sqrt(bc2) + eps)
+__global__ void adamw_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
+                             float* __restrict__ v, long n, float lr, float b1, float b2, float eps, float wd, float bc1,
+                             float bc2, float gscale) {
+  const float step = lr / bc1, inv_sqrt_bc2 = rsqrtf(bc2);
+  const long n4 = n >> 2;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long)gridDim.x * blockDim.x) {
+    float4 P = reinterpret_cast<float4*>(p)[i], M = reinterpret_cast<float4*>(m)[i], V = reinterpret_cast<float4*>(v)[i];
+    const float4 G = reinterpret_cast<const float4*>(g)[i];
+    float* pp = &P.x; float* mm = &M.x; float* vv = &V.x; const float* gg = &G.x;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const float gr = gg[e] * gscale;
+      pp[e] *= 1.f - lr * wd;
+      mm[e] = b1 * mm[e] + (1.f - b1) * gr;
+      vv[e] = b2 * vv[e] + (1.f - b2) * gr * gr;
+      pp[e] -= step * mm[e] / (sqrtf(vv[e]) * inv_sqrt_bc2 + eps);
+    }
+    reinterpret_cast<float4*>(p)[i] = P;
+    reinterpret_cast<float4*>(m)[i] = M;
+    reinterpret_cast<float4*>(v)[i] = V;
+  }
+  for (long i = (n4 << 2) + (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+    const float gr = g[i] * gscale;
+    float P = p[i] * (1.f - lr * wd);
+    const float M = b1 * m[i] + (1.f - b1) * gr, V = b2 * v[i] + (1.f - b2) * gr * gr;
+    P -= step * M / (sqrtf(V) * inv_sqrt_bc2 + eps);
+    p[i] = P; m[i] = M; v[i] = V;
+  }
+}
+
+}  // namespace
+
+#define S_ ((hipStream_t)stream)
+
+extern "C" int mv_version(void) { return 100; }
+extern "C" const char* mv_error_string(int code) {
+  switch (code) {
+    case MV_OK: return "ok";
+    case MV_ERR_SHAPE: return "shape constraint violated";
+    case MV_ERR_ALIGN: return "pointer or leading dimension not aligned (16 B / multiple of 8 elements)";
+    case MV_ERR_LAUNCH: return "kernel launch failed";
+    case MV_ERR_UNSUPPORTED: return "dtype/epilogue combination not supported";
+    case MV_ERR_WORKSPACE: return "workspace too small";
+    default: return "unknown error";
+  }
+}
+
+extern "C" int mv_patchify(const float* img, void* out, int out_dtype, int B, int C, int H, int W, int p,
+                           mv_stream_t stream) {
+  MV_REQUIRE(B >= 0 && C > 0 && p > 0 && H % p == 0 && W % p == 0, MV_ERR_SHAPE);
+  MV_REQUIRE(out_dtype == MV_F32 || out_dtype == MV_BF16, MV_ERR_UNSUPPORTED);
+  if (B == 0) return MV_OK;
+  if (C == 3 && p % 4 == 0 && W % 4 == 0 && mv_aligned16(img)) {
+    const long items = (long)B * H * (W / 4);
+    if (out_dtype == MV_F32)
+      patchify_kernel<float, 3><<<ew_grid(items), 256, 0, S_>>>(img, (float*)out, B, H, W, p);
+    else
+      patchify_kernel<bf16_t, 3><<<ew_grid(items), 256, 0, S_>>>(img, (bf16_t*)out, B, H, W, p);
+  } else {
+    const long n = (long)B * C * H * W;
+    if (out_dtype == MV_F32)
+      patchify_generic_kernel<float><<<ew_grid(n), 256, 0, S_>>>(img, (float*)out, B, C, H, W, p);
+    else
+      patchify_generic_kernel<bf16_t><<<ew_grid(n), 256, 0, S_>>>(img, (bf16_t*)out, B, C, H, W, p);
+  }
+  MV_CHECK_LAUNCH();
+  return MV_OK;
+}
+
+extern "C" int mv_embed_cls(const float* cls, const float* pos, float* x, int B, int T, int D, mv_stream_t stream) {
+  MV_REQUIRE(B >= 0 && T > 0 && D > 0, MV_ERR_SHAPE);
+  if (B == 0) return MV_OK;
+  embed_cls_kernel<<<ew_grid((long)B * D), 256, 0, S_>>>(cls, pos, x, B, T, D);
+  MV_CHECK_LAUNCH();
+  return MV_OK;
+}
+
+extern "C" int mv_embed_bwd(const float* dx, float* dpos, float* dcls, int accumulate, int B, int T, int D,
+                            mv_stream_t stream) {
+  MV_REQUIRE(B >= 0 && T > 0 && D > 0, MV_ERR_SHAPE);
+  embed_bwd_kernel<<<ew_grid((long)T * D), 256, 0, S_>>>(dx, dpos, dcls, accumulate, B, T, D);
+  MV_CHECK_LAUNCH();
+  return MV_OK;
+}
+
+extern "C" int mv_gather_patch_rows(const float* src, void* dst, int dst_dtype, int B, int T, int D,
+                                    mv_stream_t stream) {
+  MV_REQUIRE(B >= 0 && T > 1 && D > 0 && D % 4 == 0, MV_ERR_SHAPE);
+  MV_REQUIRE(mv_aligned16(src) && mv_aligned16(dst), MV_ERR_ALIGN);
+  if (B == 0) return MV_OK;
+  const long n = (long)B * (T - 1) * (D / 4);
+  if (dst_dtype == MV_F32)
+    gather_patch_rows_kernel<float><<<ew_grid(n), 256, 0, S_>>>(src, (float*)dst, B, T, D);
+  else if (dst_dtype == MV_BF16)
+    gather_patch_rows_kernel<bf16_t><<<ew_grid(n), 256, 0, S_>>>(src, (bf16_t*)dst, B, T, D);
+  else
+    return MV_ERR_UNSUPPORTED;
+  MV_CHECK_LAUNCH();
+  return MV_OK;
+}
+
+extern "C" int mv_cast(const void* src, int src_dtype, void* dst, int dst_dtype, long n, mv_stream_t stream) {
+  MV_REQUIRE(n >= 0, MV_ERR_SHAPE);
+  if (n == 0) return MV_OK;
+  MV_REQUIRE(mv_aligned16(src) && mv_aligned16(dst), MV_ERR_ALIGN);
+  const int grid = ew_grid((n + 3) / 4);
+  if (src_dtype == MV_F32 && dst_dtype == MV_BF16)
+    cast_kernel<float, bf16_t><<<grid, 256, 0, S_>>>((const float*)src, (bf16_t*)dst, n);
+  else if (src_dtype == MV_BF16 && dst_dtype == MV_F32)
+    cast_kernel<bf16_t, float><<<grid, 256, 0, S_>>>((const bf16_t*)src, (float*)dst, n);
+  else if (src_dtype == MV_F32 && dst_dtype == MV_F32)
+    cast_kernel<float, float><<<grid, 256, 0, S_>>>((const float*)src, (float*)dst, n);
+  else
+    return MV_ERR_UNSUPPORTED;
+  MV_CHECK_LAUNCH();
+  return MV_OK;
+}
+
+extern "C" int mv_weight_prep(const float* w, void* w_bf16, int ldw, void* wt_bf16, int ldt, int R, int C,
+                              mv_stream_t stream) {
+  MV_REQUIRE(R > 0 && C > 0 && (!w_bf16 || ldw >= C) && (!wt_bf16 || ldt >= R), MV_ERR_SHAPE);
+  const int cols = (w_bf16 && ldw > C) ? ldw : C, rows = (wt_bf16 && ldt > R) ? ldt : R;
+  dim3 grid(mv_cdiv(cols, 32), mv_cdiv(rows, 32));
+  weight_prep_kernel<<<grid, 256, 0, S_>>>(w, (bf16_t*)w_bf16, ldw, (bf16_t*)wt_bf16, ldt, R, C);
+  MV_CHECK_LAUNCH();
+  return MV_OK;
+}
+
+extern "C" int mv_gelu_fwd(const void* x, void* y, int dtype, long n, mv_stream_t stream) {
+  if (n <= 0) return n == 0 ? MV_OK : MV_ERR_SHAPE;
+  if (dtype == MV_F32)
+    gelu_fwd_kernel<float><<<ew_grid(n), 256, 0, S_>>>((const float*)x, (float*)y, n);
+  else if (dtype == MV_BF16)
+    gelu_fwd_kernel<bf16_t><<<ew_grid(n), 256, 0, S_>>>((const bf16_t*)x, (bf16_t*)y, n);
+  else
+    return MV_ERR_UNSUPPORTED;
+  MV_CHECK_LAUNCH();
+  return MV_OK;
+}
+
+extern "C" int mv_gelu_bwd(const void* x, const void* dy, void* dx, int dtype, long n, mv_stream_t stream) {
+  if (n <= 0) return n == 0 ? MV_OK : MV_ERR_SHAPE;
+  if (dtype == MV_F32)
+    gelu_bwd_kernel<float><<<ew_grid(n), 256, 0, S_>>>((const float*)x, (const float*)dy, (float*)dx, n);
+  else if (dtype == MV_BF16)
+    gelu_bwd_kernel<bf16_t><<<ew_grid(n), 256, 0, S_>>>((const bf16_t*)x, (const bf16_t*)dy, (bf16_t*)dx, n);
+  else
+    return MV_ERR_UNSUPPORTED;
+  MV_CHECK_LAUNCH();
+  return MV_OK;
+}
+
+extern "C" int mv_add_f32(const float* a, const float* b, float* out, long n, mv_stream_t stream) {
+  if (n <= 0) return n == 0 ? MV_OK : MV_ERR_SHAPE;
+  MV_REQUIRE(mv_aligned16(a) && mv_aligned16(b) && mv_aligned16(out), MV_ERR_ALIGN);
+  add_kernel<<<ew_grid((n + 3) / 4), 256, 0, S_>>>(a, b, out, n);
+  MV_CHECK_LAUNCH();
+  return MV_OK;
+}
+
+extern "C" int mv_quant_float(const float* x, float* y, long n, int exp_bits, int man_bits, mv_stream_t stream) {
+  MV_REQUIRE(n >= 0 && exp_bits >= 2 && exp_bits <= 8 && man_bits >= 0 && man_bits <= 22, MV_ERR_SHAPE);
+  if (n == 0) return MV_OK;
+  MV_REQUIRE(mv_aligned16(x) && mv_aligned16(y), MV_ERR_ALIGN);
+  quant_float_kernel<<<ew_grid((n + 3) / 4), 256, 0, S_>>>(x, y, n, exp_bits, man_bits);
+  MV_CHECK_LAUNCH();
+  return MV_OK;
+}
+
+extern "C" int mv_quant_fixed(const float* x, float* y, long n, int wl, int fl, int clamp, int symmetric,
+                              mv_stream_t stream) {
+  MV_REQUIRE(n >= 0 && wl > 0 && wl <= 32, MV_ERR_SHAPE);
+  if (n == 0) return MV_OK;
+  const float scale = ldexpf(1.f, fl), inv = ldexpf(1.f, -fl);
+  float tmax = ldexpf(1.f, wl - fl - 1) - inv, tmin = -ldexpf(1.f, wl - fl - 1);
+  if (symmetric) tmin += inv;
+  quant_fixed_kernel<<<ew_grid(n), 256, 0, S_>>>(x, y, n, scale, inv, tmin, tmax, clamp);
+  MV_CHECK_LAUNCH();
+  return MV_OK;
+}
+
+extern "C" int mv_quant_affine(const float* x, float* y, long n, float scale, int zero_point, int qmin, int qmax,
+                               mv_stream_t stream) {
+  MV_REQUIRE(n >= 0 && scale > 0.f && qmin < qmax, MV_ERR_SHAPE);
+  if (n == 0) return MV_OK;
+  quant_affine_kernel<<<ew_grid(n), 256, 0, S_>>>(x, y, n, scale, 1.0f / scale, zero_point, qmin, qmax);
+  MV_CHECK_LAUNCH();
+  return MV_OK;
+}
+
+extern "C" int mv_minmax(const float* x, long n, float* minmax, mv_stream_t stream) {
+  MV_REQUIRE(n >= 0, MV_ERR_SHAPE);
+  if (n == 0) return MV_OK;
+  // minmax[2..3] (caller allocates 4 floats) hold the order-preserving integer image during the reduction
+  unsigned* ord = reinterpret_cast<unsigned*>(minmax + 2);
+  minmax_begin_kernel<<<1, 1, 0, S_>>>(minmax, ord);
+  minmax_kernel<<<ew_grid(n), 256, 0, S_>>>(x, n, ord);
+  minmax_end_kernel<<<1, 1, 0, S_>>>(minmax, ord);
+  MV_CHECK_LAUNCH();
+  return MV_OK;
+}
+
+extern "C" int mv_cross_entropy(const float* logits, const int64_t* labels, float* loss_sum, void* dlogits, int dl_dtype,
+                                int ld_dl, int64_t* argmax, long outer, int C, long inner, float grad_scale,
+                                mv_stream_t stream) {
+  MV_REQUIRE(outer >= 0 && C > 0 && inner >= 1, MV_ERR_SHAPE);
+  MV_REQUIRE(!dlogits || dl_dtype == MV_F32 || dl_dtype == MV_BF16, MV_ERR_UNSUPPORTED);
+  MV_REQUIRE(!dlogits || inner > 1 || ld_dl >= C, MV_ERR_SHAPE);
+  if (hipMemsetAsync(loss_sum, 0, sizeof(float), S_) != hipSuccess) return MV_ERR_LAUNCH;
+  const long total = outer * inner;
+  if (total == 0) return MV_OK;
+  const float inv_count = 1.0f / (float)total;
+  if (inner == 1) {
+    const int grid = ew_grid(total, 4);
+    if (dl_dtype == MV_BF16 && dlogits)
+      cross_entropy_kernel<bf16_t><<<grid, 256, 0, S_>>>(logits, labels, loss_sum, (bf16_t*)dlogits, ld_dl, argmax, outer,
+                                                         C, inner, inv_count, grad_scale);
+    else
+      cross_entropy_kernel<float><<<grid, 256, 0, S_>>>(logits, labels, loss_sum, (float*)dlogits, ld_dl, argmax, outer, C,
+                                                        inner, inv_count, grad_scale);
+  } else {
+    const int grid = ew_grid(total);
+    if (dl_dtype == MV_BF16 && dlogits)
+      cross_entropy_pixel_kernel<bf16_t><<<grid, 256, 0, S_>>>(logits, labels, loss_sum, (bf16_t*)dlogits, argmax, outer,
+                                                               C, inner, inv_count, grad_scale);
+    else
+      cross_entropy_pixel_kernel<float><<<grid, 256, 0, S_>>>(logits, labels, loss_sum, (float*)dlogits, argmax, outer, C,
+                                                              inner, inv_count, grad_scale);
+  }
+  MV_CHECK_LAUNCH();
+  return MV_OK;
+}
+
+extern "C" int mv_upsample_bilinear_fwd(const float* small, long sb, long sc, long sp, float* big, int B, int C, int h,
+                                        int w, int H, int W, mv_stream_t stream) {
+  MV_REQUIRE(B >= 0 && C > 0 && h > 0 && w > 0 && H > 0 && W > 0, MV_ERR_SHAPE);
+  if (B == 0) return MV_OK;
+  upsample_fwd_kernel<<<ew_grid((long)B * C * H * W), 256, 0, S_>>>(small, sb, sc, sp, big, B, C, h, w, H, W,
+                                                                     (float)h / (float)H, (float)w / (float)W);
+  MV_CHECK_LAUNCH();
+  return MV_OK;
+}
+
+extern "C" int mv_upsample_bilinear_bwd(const float* dbig, float* dsmall, long sb, long sc, long sp, int B, int C, int h,
+                                        int w, int H, int W, mv_stream_t stream) {
+  MV_REQUIRE(B >= 0 && C > 0 && h > 0 && w > 0 && H > 0 && W > 0, MV_ERR_SHAPE);
+  if (B == 0) return MV_OK;
+  upsample_bwd_kernel<<<ew_grid((long)B * C * h * w), 256, 0, S_>>>(dbig, dsmall, sb, sc, sp, B, C, h, w, H, W,
+                                                                     (float)h / (float)H, (float)w / (float)W);
+  MV_CHECK_LAUNCH();
+  return MV_OK;
+}
+
+extern "C" int mv_adamw(float* p, const float* g, float* m, float* v, long n, float lr, float beta1, float beta2,
+                        float eps, float weight_decay, float bias_corr1, float bias_corr2, float grad_scale,
+                        mv_stream_t stream) {
+  MV_REQUIRE(n >= 0, MV_ERR_SHAPE);
+  if (n == 0) return MV_OK;
+  MV_REQUIRE(mv_aligned16(p) && mv_aligned16(g) && mv_aligned16(m) && mv_aligned16(v), MV_ERR_ALIGN);
+  adamw_kernel<<<ew_grid((n + 3) / 4), 256, 0, S_>>>(p, g, m, v, n, lr, beta1, beta2, eps, weight_decay, bias_corr1,
+                                                     bias_corr2, grad_scale);
+  MV_CHECK_LAUNCH();
+  return MV_OK;
+}

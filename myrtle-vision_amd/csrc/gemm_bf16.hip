@@ -1,0 +1,538 @@
+// bf16 MFMA contractions for the ViT Linear layers (gfx950, v_mfma_f32_16x16x32_bf16).
+//
+//   mv_gemm_nt_bf16 : C[M,N] = A[M,K] . B[N,K]^T (+ fused epilogue)   -- nn.Linear forward (vit.py:278,86,98,
+//                     48-51,333,354) and, with B = W^T, the input gradient dX = dY . W.
+//   mv_gemm_tn_bf16 : C[M,N] (+)= A[Kc,M]^T . B[Kc,N]                  -- weight gradient dW = dY^T . X.
+//
+// Structure (both): 128x128 output tile per 256-thread workgroup (4 waves as 2x2, 64x64 per wave =
+// 4x4 MFMA tiles, 64 fp32 accumulator VGPRs), K-step 64, LDS double buffer (2 x 32 KiB, two workgroups
+// per CU), register-staged global->LDS copies issued one K-step ahead (loads of step t+2 are in flight
+// while step t+1 computes; the LDS write of t+1 happens after step t's barrier), one barrier per K-step.
+//
+// LDS images (checked with tools/lds_bank_sim.py against the gfx950 banking rules):
+//   NT: tiles are [128 rows][64 k] bf16 = 128-byte rows, 16-byte chunk index XORed with ((row>>1)&3)<<1.
+//       Fragment reads are ds_read_b128 (8 consecutive k of one row): conflict-free.
+//   TN: tiles are [64 kc][128 cols] bf16 = 256-byte rows, chunk ^= ((row&3)<<2)|((row>>2)&3).  Both MFMA
+//       operands need 8 consecutive kc of one column = a column read: two ds_read_b64_tr_b16 (hardware
+//       transpose) per fragment, conflict-free in this image.  No transposed copies of activations exist.
+//
+// The MFMA is issued as D' = B_frag x A_frag, i.e. it produces the TRANSPOSE of the output tile, so a lane
+// holds 4 consecutive output columns of one row: epilogue loads/stores are 8-/16-byte vectors.
+//
+// Workgroup ids are remapped so the 8 XCDs each walk a contiguous run of tiles (n fastest): the blocks
+// sharing one A row-panel run on one XCD and hit its L2.
+#include "mv_common.h"
+
+namespace {
+
+constexpr int BM = 128, BN = 128, BK = 64;
+constexpr int STAGE_BYTES = (BM + BN) * BK * 2;  // 32 KiB
+constexpr int SMEM_BYTES = 2 * STAGE_BYTES;      // 64 KiB
+
+__device__ __forceinline__ int sw128(int row, int ch) { return row * 128 + ((ch ^ (((row >> 1) & 3) << 1)) << 4); }
+__device__ __forceinline__ int sw256(int row, int ch) {
+  return row * 256 + ((ch ^ (((row & 3) << 2) | ((row >> 2) & 3))) << 4);
+}
+
+// bijective XCD-aware remap of a 1-D grid (cdna guide T1): XCD x (= bid % 8) owns a contiguous run of tiles
+__device__ __forceinline__ int xcd_remap(int bid, int nwg) {
+  const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7, idx = bid >> 3;
+  return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+}
+
+struct EpiArgs {
+  const float* bias;
+  const void* aux;
+  int ld_aux;
+  int aux_i;
+  void* out2;
+  int ld_out2;
+};
+
+template <typename CT>
+__device__ __forceinline__ void store4(CT* p, const float v[4], bool vec, int nvalid) {
+  if (vec) {
+    if constexpr (sizeof(CT) == 4) {
+      *reinterpret_cast<float4*>(p) = make_float4(v[0], v[1], v[2], v[3]);
+    } else {
+      bf16x4 o = {(bf16_t)v[0], (bf16_t)v[1], (bf16_t)v[2], (bf16_t)v[3]};
+      *reinterpret_cast<bf16x4*>(p) = o;
+    }
+  } else {
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+      if (r < nvalid) p[r] = (CT)v[r];
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// NT kernel
+// ------------------------------------------------------------------------------------------------
+template <int EPI, typename CT>
+__global__ __launch_bounds__(256, 2) void gemm_nt_kernel(const bf16_t* __restrict__ A, int lda,
+                                                         const bf16_t* __restrict__ B, int ldb, CT* __restrict__ C,
+                                                         int ldc, int M, int N, int K, int tiles_n, EpiArgs ep) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int t = xcd_remap(blockIdx.x, gridDim.x);
+  const int m0 = (t / tiles_n) * BM, n0 = (t % tiles_n) * BN;
+
+  // staging map: 8 lanes cover one 128-byte row (8 chunks of 16 B), 32 rows per pass, 4 passes per tile.
+  // Loads are UNCONDITIONAL from clamped (always valid) addresses and zeroed by a select afterwards: a
+  // conditional load makes hipcc branch around it and drain vmcnt per element (cdna guide, trap (c)).
+  const int sc = tid & 7, sr = tid >> 3;
+  u32x4 ra0, ra1, ra2, ra3, rb0, rb1, rb2, rb3;
+  const u32x4 zero4 = {0u, 0u, 0u, 0u};
+  const bf16_t* pa[4];
+  const bf16_t* pb[4];
+  bool va[4], vb[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int ar = m0 + sr + 32 * i, br = n0 + sr + 32 * i;
+    va[i] = ar < M;
+    vb[i] = br < N;
+    pa[i] = A + (long)(va[i] ? ar : M - 1) * lda + sc * 8;
+    pb[i] = B + (long)(vb[i] ? br : N - 1) * ldb + sc * 8;
+  }
+#define NT_LOAD_TILE(kt_)                                                                 \
+  {                                                                                       \
+    const int k_ = (kt_) * BK;                                                            \
+    const bool kin_ = (k_ + sc * 8) < K;                                                  \
+    const int ko_ = kin_ ? k_ : -(sc * 8);                                                \
+    ra0 = *reinterpret_cast<const u32x4*>(pa[0] + ko_);                                   \
+    ra1 = *reinterpret_cast<const u32x4*>(pa[1] + ko_);                                   \
+    ra2 = *reinterpret_cast<const u32x4*>(pa[2] + ko_);                                   \
+    ra3 = *reinterpret_cast<const u32x4*>(pa[3] + ko_);                                   \
+    rb0 = *reinterpret_cast<const u32x4*>(pb[0] + ko_);                                   \
+    rb1 = *reinterpret_cast<const u32x4*>(pb[1] + ko_);                                   \
+    rb2 = *reinterpret_cast<const u32x4*>(pb[2] + ko_);                                   \
+    rb3 = *reinterpret_cast<const u32x4*>(pb[3] + ko_);                                   \
+    ra0 = (kin_ && va[0]) ? ra0 : zero4; ra1 = (kin_ && va[1]) ? ra1 : zero4;             \
+    ra2 = (kin_ && va[2]) ? ra2 : zero4; ra3 = (kin_ && va[3]) ? ra3 : zero4;             \
+    rb0 = (kin_ && vb[0]) ? rb0 : zero4; rb1 = (kin_ && vb[1]) ? rb1 : zero4;             \
+    rb2 = (kin_ && vb[2]) ? rb2 : zero4; rb3 = (kin_ && vb[3]) ? rb3 : zero4;             \
+  }
+#define NT_STORE_TILE(stage_)                                                             \
+  {                                                                                       \
+    char* sa_ = smem + (stage_) * STAGE_BYTES;                                            \
+    char* sb_ = sa_ + BM * BK * 2;                                                        \
+    *reinterpret_cast<u32x4*>(sa_ + sw128(sr, sc)) = ra0;                                 \
+    *reinterpret_cast<u32x4*>(sa_ + sw128(sr + 32, sc)) = ra1;                            \
+    *reinterpret_cast<u32x4*>(sa_ + sw128(sr + 64, sc)) = ra2;                            \
+    *reinterpret_cast<u32x4*>(sa_ + sw128(sr + 96, sc)) = ra3;                            \
+    *reinterpret_cast<u32x4*>(sb_ + sw128(sr, sc)) = rb0;                                 \
+    *reinterpret_cast<u32x4*>(sb_ + sw128(sr + 32, sc)) = rb1;                            \
+    *reinterpret_cast<u32x4*>(sb_ + sw128(sr + 64, sc)) = rb2;                            \
+    *reinterpret_cast<u32x4*>(sb_ + sw128(sr + 96, sc)) = rb3;                            \
+  }
+
+  f32x4 acc[4][4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  const int nk = (K + BK - 1) / BK;
+  NT_LOAD_TILE(0)
+  NT_STORE_TILE(0)
+  if (nk > 1) NT_LOAD_TILE(1)
+  __syncthreads();
+
+  const int frow = lane & 15, fch = lane >> 4;
+  for (int kt = 0; kt < nk; ++kt) {
+    const int cur = kt & 1;
+    const char* sa = smem + cur * STAGE_BYTES;
+    const char* sb = sa + BM * BK * 2;
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      bf16x8 af[4], bfr[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        af[i] = *reinterpret_cast<const bf16x8*>(sa + sw128(wm * 64 + i * 16 + frow, 4 * ks + fch));
+        bfr[i] = *reinterpret_cast<const bf16x8*>(sb + sw128(wn * 64 + i * 16 + frow, 4 * ks + fch));
+      }
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[j], af[i], acc[i][j], 0, 0, 0);
+    }
+    if (kt + 1 < nk) NT_STORE_TILE(cur ^ 1)
+    if (kt + 2 < nk) NT_LOAD_TILE(kt + 2)
+    __syncthreads();
+  }
+#undef NT_LOAD_TILE
+#undef NT_STORE_TILE
+
+  // ---- epilogue: lane holds, for tile (i,j): row m = .. + (lane&15), cols n = .. + 4*(lane>>4) + 0..3
+  const bool ldc_vec = (ldc & 3) == 0;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int m = m0 + wm * 64 + i * 16 + (lane & 15);
+    if (m >= M) continue;
+    long crow = m;
+    int patch = 0;
+    if constexpr (EPI == MV_EPI_EMBED) {
+      const int img = m / ep.aux_i;
+      patch = m - img * ep.aux_i;
+      crow = (long)img * (ep.aux_i + 1) + 1 + patch;
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int n = n0 + wn * 64 + j * 16 + 4 * (lane >> 4);
+      if (n >= N) continue;
+      const int nvalid = (N - n) >= 4 ? 4 : (N - n);
+      const bool vec = ldc_vec && nvalid == 4;
+      float v[4] = {acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]};
+      if (ep.bias) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+          if (r < nvalid) v[r] += ep.bias[n + r];
+      }
+      if constexpr (EPI == MV_EPI_GELU) {
+        if (ep.out2) store4(reinterpret_cast<bf16_t*>(ep.out2) + (long)m * ep.ld_out2 + n, v, vec && (ep.ld_out2 & 3) == 0, nvalid);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[r] = gelu_f(v[r]);
+      } else if constexpr (EPI == MV_EPI_RESIDUAL) {
+        const float* ax = reinterpret_cast<const float*>(ep.aux) + (long)m * ep.ld_aux + n;
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+          if (r < nvalid) v[r] += ax[r];
+      } else if constexpr (EPI == MV_EPI_DGELU) {
+        const bf16_t* ax = reinterpret_cast<const bf16_t*>(ep.aux) + (long)m * ep.ld_aux + n;
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+          if (r < nvalid) v[r] *= dgelu_f((float)ax[r]);
+      } else if constexpr (EPI == MV_EPI_EMBED) {
+        const float* ax = reinterpret_cast<const float*>(ep.aux) + (long)(1 + patch) * ep.ld_aux + n;
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+          if (r < nvalid) v[r] += ax[r];
+      }
+      store4(C + crow * ldc + n, v, vec, nvalid);
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// TN kernel: slab[s][M][N] = sum over this split's kc of A[kc][m] * B[kc][n]
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256, 2) void gemm_tn_kernel(const bf16_t* __restrict__ A, int lda,
+                                                         const bf16_t* __restrict__ B, int ldb, float* __restrict__ C,
+                                                         long ldc, long slab_stride, int M, int N, int Kc, int tiles_n,
+                                                         int tiles_mn, int steps_per_split) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int t_all = xcd_remap(blockIdx.x, gridDim.x);
+  const int split = t_all / tiles_mn;
+  const int t = t_all - split * tiles_mn;
+  const int m0 = (t / tiles_n) * BM, n0 = (t % tiles_n) * BN;
+  const int nk_total = (Kc + BK - 1) / BK;
+  const int kt0 = split * steps_per_split;
+  int nk = nk_total - kt0;
+  if (nk > steps_per_split) nk = steps_per_split;
+  float* Cs = C + (long)split * slab_stride;
+
+  // staging map: 16 lanes cover one 256-byte row (16 chunks), 16 rows per pass, 4 passes per tile; loads are
+  // unconditional from clamped addresses, zeroed by select (see the NT kernel)
+  const int sc = tid & 15, sr = tid >> 4;
+  u32x4 ra0, ra1, ra2, ra3, rb0, rb1, rb2, rb3;
+  const u32x4 zero4 = {0u, 0u, 0u, 0u};
+  const bool a_in = (m0 + sc * 8) < M, b_in = (n0 + sc * 8) < N;
+  const bf16_t* pa = A + (a_in ? m0 + sc * 8 : 0);
+  const bf16_t* pb = B + (b_in ? n0 + sc * 8 : 0);
+  const int kc_last = Kc - 1;
+#define TN_LOAD_TILE(kt_)                                                                 \
+  {                                                                                       \
+    const int kc_ = (kt0 + (kt_)) * BK + sr;                                              \
+    const bool k0_ = kc_ < Kc, k1_ = kc_ + 16 < Kc, k2_ = kc_ + 32 < Kc, k3_ = kc_ + 48 < Kc; \
+    const long r0_ = k0_ ? kc_ : kc_last, r1_ = k1_ ? kc_ + 16 : kc_last;                 \
+    const long r2_ = k2_ ? kc_ + 32 : kc_last, r3_ = k3_ ? kc_ + 48 : kc_last;            \
+    ra0 = *reinterpret_cast<const u32x4*>(pa + r0_ * lda);                                \
+    ra1 = *reinterpret_cast<const u32x4*>(pa + r1_ * lda);                                \
+    ra2 = *reinterpret_cast<const u32x4*>(pa + r2_ * lda);                                \
+    ra3 = *reinterpret_cast<const u32x4*>(pa + r3_ * lda);                                \
+    rb0 = *reinterpret_cast<const u32x4*>(pb + r0_ * ldb);                                \
+    rb1 = *reinterpret_cast<const u32x4*>(pb + r1_ * ldb);                                \
+    rb2 = *reinterpret_cast<const u32x4*>(pb + r2_ * ldb);                                \
+    rb3 = *reinterpret_cast<const u32x4*>(pb + r3_ * ldb);                                \
+    ra0 = (k0_ && a_in) ? ra0 : zero4; ra1 = (k1_ && a_in) ? ra1 : zero4;                 \
+    ra2 = (k2_ && a_in) ? ra2 : zero4; ra3 = (k3_ && a_in) ? ra3 : zero4;                 \
+    rb0 = (k0_ && b_in) ? rb0 : zero4; rb1 = (k1_ && b_in) ? rb1 : zero4;                 \
+    rb2 = (k2_ && b_in) ? rb2 : zero4; rb3 = (k3_ && b_in) ? rb3 : zero4;                 \
+  }
+#define TN_STORE_TILE(stage_)                                                             \
+  {                                                                                       \
+    char* sa_ = smem + (stage_) * STAGE_BYTES;                                            \
+    char* sb_ = sa_ + BK * BM * 2;                                                        \
+    *reinterpret_cast<u32x4*>(sa_ + sw256(sr, sc)) = ra0;                                 \
+    *reinterpret_cast<u32x4*>(sa_ + sw256(sr + 16, sc)) = ra1;                            \
+    *reinterpret_cast<u32x4*>(sa_ + sw256(sr + 32, sc)) = ra2;                            \
+    *reinterpret_cast<u32x4*>(sa_ + sw256(sr + 48, sc)) = ra3;                            \
+    *reinterpret_cast<u32x4*>(sb_ + sw256(sr, sc)) = rb0;                                 \
+    *reinterpret_cast<u32x4*>(sb_ + sw256(sr + 16, sc)) = rb1;                            \
+    *reinterpret_cast<u32x4*>(sb_ + sw256(sr + 32, sc)) = rb2;                            \
+    *reinterpret_cast<u32x4*>(sb_ + sw256(sr + 48, sc)) = rb3;                            \
+  }
+
+  f32x4 acc[4][4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  if (nk > 0) {
+    TN_LOAD_TILE(0)
+    TN_STORE_TILE(0)
+    if (nk > 1) TN_LOAD_TILE(1)
+  }
+  __syncthreads();
+
+  // transposed-read lane map (ds_read_b64_tr_b16): within a 16-lane group, lane 4q+p addresses row q, columns
+  // 4p..4p+3 of a 4x16 block and receives column (lane&15) of its 4 rows.
+  const int g = lane >> 4, q = (lane >> 2) & 3, p = lane & 3;
+  for (int kt = 0; kt < nk; ++kt) {
+    const int cur = kt & 1;
+    const char* sa = smem + cur * STAGE_BYTES;
+    const char* sb = sa + BK * BM * 2;
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      bf16x8 af[4], bfr[4];
+      const int r0 = 32 * ks + 8 * g + q;  // fragment element e <-> kc row 32ks + 8g + e
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int ca = (wm * 64 + i * 16) >> 3, cb = (wn * 64 + i * 16) >> 3;
+        const bf16x4 a0 = __builtin_amdgcn_ds_read_tr16_b64_v4bf16(LDS_PTR(bf16x4, sa + sw256(r0, ca + (p >> 1)) + 8 * (p & 1)));
+        const bf16x4 a1 = __builtin_amdgcn_ds_read_tr16_b64_v4bf16(LDS_PTR(bf16x4, sa + sw256(r0 + 4, ca + (p >> 1)) + 8 * (p & 1)));
+        const bf16x4 b0 = __builtin_amdgcn_ds_read_tr16_b64_v4bf16(LDS_PTR(bf16x4, sb + sw256(r0, cb + (p >> 1)) + 8 * (p & 1)));
+        const bf16x4 b1 = __builtin_amdgcn_ds_read_tr16_b64_v4bf16(LDS_PTR(bf16x4, sb + sw256(r0 + 4, cb + (p >> 1)) + 8 * (p & 1)));
+        af[i] = __builtin_shufflevector(a0, a1, 0, 1, 2, 3, 4, 5, 6, 7);
+        bfr[i] = __builtin_shufflevector(b0, b1, 0, 1, 2, 3, 4, 5, 6, 7);
+      }
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[j], af[i], acc[i][j], 0, 0, 0);
+    }
+    if (kt + 1 < nk) TN_STORE_TILE(cur ^ 1)
+    if (kt + 2 < nk) TN_LOAD_TILE(kt + 2)
+    __syncthreads();
+  }
+#undef TN_LOAD_TILE
+#undef TN_STORE_TILE
+
+  const bool ldc_vec = (ldc & 3) == 0;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int m = m0 + wm * 64 + i * 16 + (lane & 15);
+    if (m >= M) continue;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int n = n0 + wn * 64 + j * 16 + 4 * (lane >> 4);
+      if (n >= N) continue;
+      const int nvalid = (N - n) >= 4 ? 4 : (N - n);
+      const float v[4] = {acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]};
+      store4(Cs + (long)m * ldc + n, v, ldc_vec && nvalid == 4, nvalid);
+    }
+  }
+}
+
+// C[m][n] = (accumulate ? C : 0) + sum_s slab[s][m][n]   (fixed order: deterministic)
+__global__ void splitk_reduce_kernel(const float* __restrict__ slabs, long slab_stride, int S, float* C, int ldc, int M,
+                                     int N, int accumulate) {
+  const long total = (long)M * N;
+  for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
+    const int m = (int)(idx / N), n = (int)(idx - (long)m * N);
+    float s = 0.f;
+    for (int k = 0; k < S; ++k) s += slabs[(long)k * slab_stride + idx];
+    float* c = C + (long)m * ldc + n;
+    *c = accumulate ? (*c + s) : s;
+  }
+}
+
+// ---- column sums (bias gradient): partial[y][c] = sum over this block's rows of x[r][c] -------------
+template <typename T>
+__global__ __launch_bounds__(256) void colsum_partial_kernel(const T* __restrict__ x, long ld, float* __restrict__ partial,
+                                                             long rows, int cols, int rows_per_block) {
+  __shared__ float red[4][256];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int c = blockIdx.x * 256 + lane * 4;
+  const long r_begin = (long)blockIdx.y * rows_per_block;
+  long r_end = r_begin + rows_per_block;
+  if (r_end > rows) r_end = rows;
+  float s[4] = {0.f, 0.f, 0.f, 0.f};
+  if (c < cols) {
+    const bool vec = (c + 4 <= cols) && ((ld & 3) == 0);
+    for (long r = r_begin + wave; r < r_end; r += 4) {
+      const T* p = x + r * ld + c;
+      if (vec) {
+        if constexpr (sizeof(T) == 4) {
+          const float4 v = *reinterpret_cast<const float4*>(p);
+          s[0] += v.x; s[1] += v.y; s[2] += v.z; s[3] += v.w;
+        } else {
+          const bf16x4 v = *reinterpret_cast<const bf16x4*>(p);
+          s[0] += (float)v[0]; s[1] += (float)v[1]; s[2] += (float)v[2]; s[3] += (float)v[3];
+        }
+      } else {
+        for (int e = 0; e < 4 && c + e < cols; ++e) s[e] += (float)p[e];
+      }
+    }
+  }
+#pragma unroll
+  for (int e = 0; e < 4; ++e) red[wave][lane * 4 + e] = s[e];
+  __syncthreads();
+  const int cc = blockIdx.x * 256 + threadIdx.x;
+  if (cc < cols) {
+    const int i = threadIdx.x;
+    partial[(long)blockIdx.y * cols + cc] = (red[0][i] + red[1][i]) + (red[2][i] + red[3][i]);
+  }
+}
+
+__global__ void colsum_finish_kernel(const float* __restrict__ partial, int nparts, int cols, float* out, int accumulate) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= cols) return;
+  float s = 0.f;
+  for (int k = 0; k < nparts; ++k) s += partial[(long)k * cols + c];
+  out[c] = accumulate ? (out[c] + s) : s;
+}
+
+int colsum_parts(long rows) {
+  long p = (rows + 255) / 256;
+  if (p < 1) p = 1;
+  if (p > 256) p = 256;
+  return (int)p;
+}
+
+struct TnPlan {
+  int tiles_m, tiles_n, splits, steps_per_split;
+};
+
+TnPlan tn_plan(int M, int N, int Kc) {
+  TnPlan pl;
+  pl.tiles_m = mv_cdiv(M, BM);
+  pl.tiles_n = mv_cdiv(N, BN);
+  const int tiles = pl.tiles_m * pl.tiles_n;
+  const int nk = mv_cdiv(Kc, BK) < 1 ? 1 : mv_cdiv(Kc, BK);
+  int s = mv_cdiv(512, tiles);          // aim for >= 2 workgroups per CU
+  const int max_s = mv_cdiv(nk, 8);     // at least 8 K-steps (512 tokens) per split
+  if (s > max_s) s = max_s;
+  if (s > 64) s = 64;
+  if (s < 1) s = 1;
+  pl.steps_per_split = mv_cdiv(nk, s);
+  pl.splits = mv_cdiv(nk, pl.steps_per_split);
+  return pl;
+}
+
+template <typename K>
+int set_smem(K kernel) {
+  return hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                             SMEM_BYTES) == hipSuccess
+             ? 0
+             : -1;
+}
+
+template <int EPI, typename CT>
+int launch_nt(const void* A, int lda, const void* B, int ldb, void* C, int ldc, int M, int N, int K, EpiArgs ep,
+              hipStream_t s) {
+  static const int attr = set_smem(gemm_nt_kernel<EPI, CT>);
+  if (attr != 0) return MV_ERR_LAUNCH;
+  const int tiles_m = mv_cdiv(M, BM), tiles_n = mv_cdiv(N, BN);
+  gemm_nt_kernel<EPI, CT><<<tiles_m * tiles_n, 256, SMEM_BYTES, s>>>((const bf16_t*)A, lda, (const bf16_t*)B, ldb,
+                                                                      (CT*)C, ldc, M, N, K, tiles_n, ep);
+  MV_CHECK_LAUNCH();
+  return MV_OK;
+}
+
+}  // namespace
+
+extern "C" int mv_gemm_nt_bf16(const void* A, int lda, const void* B, int ldb, void* C, int ldc, int c_dtype, int M,
+                               int N, int K, const float* bias, int epilogue, const void* aux, int ld_aux, int aux_i,
+                               void* out2, int ld_out2, mv_stream_t stream) {
+  MV_REQUIRE(M >= 0 && N >= 0 && K >= 0, MV_ERR_SHAPE);
+  if (M == 0 || N == 0) return MV_OK;
+  MV_REQUIRE(lda % 8 == 0 && ldb % 8 == 0 && lda >= ((K + 7) & ~7) && ldb >= ((K + 7) & ~7), MV_ERR_ALIGN);
+  MV_REQUIRE(mv_aligned16(A) && mv_aligned16(B) && mv_aligned16(C), MV_ERR_ALIGN);
+  hipStream_t s = (hipStream_t)stream;
+  EpiArgs ep{bias, aux, ld_aux, aux_i, out2, ld_out2};
+  switch (epilogue) {
+    case MV_EPI_NONE:
+      return c_dtype == MV_F32 ? launch_nt<MV_EPI_NONE, float>(A, lda, B, ldb, C, ldc, M, N, K, ep, s)
+                               : launch_nt<MV_EPI_NONE, bf16_t>(A, lda, B, ldb, C, ldc, M, N, K, ep, s);
+    case MV_EPI_GELU:
+      MV_REQUIRE(c_dtype == MV_BF16, MV_ERR_UNSUPPORTED);
+      return launch_nt<MV_EPI_GELU, bf16_t>(A, lda, B, ldb, C, ldc, M, N, K, ep, s);
+    case MV_EPI_RESIDUAL:
+      MV_REQUIRE(c_dtype == MV_F32 && aux, MV_ERR_UNSUPPORTED);
+      return launch_nt<MV_EPI_RESIDUAL, float>(A, lda, B, ldb, C, ldc, M, N, K, ep, s);
+    case MV_EPI_DGELU:
+      MV_REQUIRE(c_dtype == MV_BF16 && aux, MV_ERR_UNSUPPORTED);
+      return launch_nt<MV_EPI_DGELU, bf16_t>(A, lda, B, ldb, C, ldc, M, N, K, ep, s);
+    case MV_EPI_EMBED:
+      MV_REQUIRE(c_dtype == MV_F32 && aux && aux_i > 0, MV_ERR_UNSUPPORTED);
+      return launch_nt<MV_EPI_EMBED, float>(A, lda, B, ldb, C, ldc, M, N, K, ep, s);
+    default:
+      return MV_ERR_UNSUPPORTED;
+  }
+}
+
+extern "C" size_t mv_gemm_tn_workspace_bytes(int M, int N, int Kc) {
+  const TnPlan pl = tn_plan(M, N, Kc);
+  const size_t slabs = (size_t)pl.splits * (size_t)M * (size_t)N * sizeof(float);
+  const size_t cs = (size_t)colsum_parts(Kc) * (size_t)M * sizeof(float);
+  return slabs + cs + 256;
+}
+
+extern "C" int mv_colsum(const void* x, int x_dtype, long ld, float* out, int accumulate, long rows, int cols,
+                         float* workspace, size_t workspace_bytes, mv_stream_t stream) {
+  MV_REQUIRE(rows >= 0 && cols > 0, MV_ERR_SHAPE);
+  MV_REQUIRE(x_dtype == MV_F32 || x_dtype == MV_BF16, MV_ERR_UNSUPPORTED);
+  const int parts = colsum_parts(rows);
+  MV_REQUIRE(workspace_bytes >= (size_t)parts * cols * sizeof(float), MV_ERR_WORKSPACE);
+  hipStream_t s = (hipStream_t)stream;
+  const int rpb = (int)((rows + parts - 1) / parts);
+  dim3 grid(mv_cdiv(cols, 256), parts);
+  if (x_dtype == MV_F32)
+    colsum_partial_kernel<float><<<grid, 256, 0, s>>>((const float*)x, ld, workspace, rows, cols, rpb < 1 ? 1 : rpb);
+  else
+    colsum_partial_kernel<bf16_t><<<grid, 256, 0, s>>>((const bf16_t*)x, ld, workspace, rows, cols, rpb < 1 ? 1 : rpb);
+  MV_CHECK_LAUNCH();
+  colsum_finish_kernel<<<mv_cdiv(cols, 256), 256, 0, s>>>(workspace, parts, cols, out, accumulate);
+  MV_CHECK_LAUNCH();
+  return MV_OK;
+}
+
+extern "C" int mv_gemm_tn_bf16(const void* A, int lda, const void* B, int ldb, float* C, int ldc, int M, int N, int Kc,
+                               int accumulate, float* colsum, float* workspace, size_t workspace_bytes,
+                               mv_stream_t stream) {
+  MV_REQUIRE(M > 0 && N > 0 && Kc >= 0, MV_ERR_SHAPE);
+  MV_REQUIRE(lda % 8 == 0 && ldb % 8 == 0 && lda >= ((M + 7) & ~7) && ldb >= ((N + 7) & ~7), MV_ERR_ALIGN);
+  MV_REQUIRE(mv_aligned16(A) && mv_aligned16(B) && mv_aligned16(C) && mv_aligned16(workspace), MV_ERR_ALIGN);
+  MV_REQUIRE(workspace_bytes >= mv_gemm_tn_workspace_bytes(M, N, Kc), MV_ERR_WORKSPACE);
+  static const int attr = set_smem(gemm_tn_kernel);
+  if (attr != 0) return MV_ERR_LAUNCH;
+  hipStream_t s = (hipStream_t)stream;
+  const TnPlan pl = tn_plan(M, N, Kc);
+  const int tiles_mn = pl.tiles_m * pl.tiles_n;
+  const bool direct = pl.splits == 1 && !accumulate;
+  const long slab_stride = (long)M * N;
+  gemm_tn_kernel<<<tiles_mn * pl.splits, 256, SMEM_BYTES, s>>>(
+      (const bf16_t*)A, lda, (const bf16_t*)B, ldb, direct ? C : workspace, direct ? (long)ldc : (long)N,
+      direct ? 0 : slab_stride, M, N, Kc, pl.tiles_n, tiles_mn, pl.steps_per_split);
+  MV_CHECK_LAUNCH();
+  if (!direct) {
+    int grid = mv_cdiv(slab_stride, 256);
+    if (grid > 2048) grid = 2048;
+    splitk_reduce_kernel<<<grid, 256, 0, s>>>(workspace, slab_stride, pl.splits, C, ldc, M, N, accumulate);
+    MV_CHECK_LAUNCH();
+  }
+  if (colsum) {
+    float* cs_ws = workspace + (size_t)pl.splits * (size_t)slab_stride;
+    const int rc = mv_colsum(A, MV_BF16, lda, colsum, accumulate, Kc, M, cs_ws,
+                             (size_t)colsum_parts(Kc) * (size_t)M * sizeof(float), stream);
+    if (rc != MV_OK) return rc;
+  }
+  return MV_OK;
+}

@@ -1,0 +1,245 @@
+// LayerNorm forward/backward for the ViT residual stream (reference: nn.LayerNorm(dim), eps 1e-5,
+// vit.py:37,41 PreNorm; :332,:353 decoder norms).
+//
+// HBM-bound.  One wave64 per row: the row lives in registers (VPL float4 per lane), statistics are
+// two-pass in registers (mean, then centred sum of squares -- matches ATen's accuracy) reduced with
+// wave shuffles; no LDS, no re-read.  Algorithmic bytes per row: forward 4*dim (x) + sizeof(y)*dim;
+// backward 4*dim (x) + sizeof(dy)*dim + 4*dim (dx) [+ 4*dim dx_add].
+#include "mv_common.h"
+
+namespace {
+
+template <int VPL, typename YT>
+__global__ __launch_bounds__(256) void ln_fwd_kernel(const float* __restrict__ x, long ldx,
+                                                     const float* __restrict__ gamma,
+                                                     const float* __restrict__ beta, YT* __restrict__ y,
+                                                     float* __restrict__ mean, float* __restrict__ rstd, int rows,
+                                                     int dim, float eps) {
+  const int lane = threadIdx.x & 63;
+  const int wave = threadIdx.x >> 6;
+  const int nvec = dim >> 2;
+  const float inv_dim = 1.0f / (float)dim;
+  for (long row = (long)blockIdx.x * 4 + wave; row < rows; row += (long)gridDim.x * 4) {
+    const float4* xr = reinterpret_cast<const float4*>(x + row * ldx);
+    float4 v[VPL];
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < VPL; ++i) {
+      const int c = lane + 64 * i;
+      v[i] = (c < nvec) ? xr[c] : make_float4(0.f, 0.f, 0.f, 0.f);
+      s += (v[i].x + v[i].y) + (v[i].z + v[i].w);
+    }
+    const float mu = wave_sum(s) * inv_dim;
+    float q = 0.f;
+#pragma unroll
+    for (int i = 0; i < VPL; ++i) {
+      const int c = lane + 64 * i;
+      if (c < nvec) {
+        const float a = v[i].x - mu, b = v[i].y - mu, cc = v[i].z - mu, d = v[i].w - mu;
+        q += (a * a + b * b) + (cc * cc + d * d);
+      }
+    }
+    const float rs = rsqrtf(wave_sum(q) * inv_dim + eps);
+    if (lane == 0) {
+      mean[row] = mu;
+      rstd[row] = rs;
+    }
+    YT* yr = y + row * (long)dim;
+#pragma unroll
+    for (int i = 0; i < VPL; ++i) {
+      const int c = lane + 64 * i;
+      if (c < nvec) {
+        const float4 g = reinterpret_cast<const float4*>(gamma)[c];
+        const float4 b = reinterpret_cast<const float4*>(beta)[c];
+        const float o0 = (v[i].x - mu) * rs * g.x + b.x, o1 = (v[i].y - mu) * rs * g.y + b.y;
+        const float o2 = (v[i].z - mu) * rs * g.z + b.z, o3 = (v[i].w - mu) * rs * g.w + b.w;
+        if constexpr (sizeof(YT) == 4) {
+          reinterpret_cast<float4*>(yr)[c] = make_float4(o0, o1, o2, o3);
+        } else {
+          bf16x4 o = {(bf16_t)o0, (bf16_t)o1, (bf16_t)o2, (bf16_t)o3};
+          reinterpret_cast<bf16x4*>(yr)[c] = o;
+        }
+      }
+    }
+  }
+}
+
+// Backward.  dx = rstd * (g - mean(g) - xhat * mean(g * xhat)),  g = dy * gamma  (+ dx_add).
+// Per-lane partial dgamma/dbeta are kept in registers across the rows a wave visits (a lane owns the
+// same columns for every row), reduced across the block's 4 waves through LDS, and written as one
+// partial row per block; ln_bwd_finish sums the partial rows (deterministic, no atomics).
+template <int VPL, typename DT>
+__global__ __launch_bounds__(256) void ln_bwd_kernel(const DT* __restrict__ dy, const float* __restrict__ x, long ldx,
+                                                     const float* __restrict__ gamma, const float* __restrict__ mean,
+                                                     const float* __restrict__ rstd, const float* dx_add, float* dx,
+                                                     long lddx, float* __restrict__ partial, int rows, int dim) {
+  __shared__ float red[4][VPL * 64 * 4 * 2];
+  const int lane = threadIdx.x & 63;
+  const int wave = threadIdx.x >> 6;
+  const int nvec = dim >> 2;
+  const float inv_dim = 1.0f / (float)dim;
+  float4 g4[VPL], dg[VPL], db[VPL];
+#pragma unroll
+  for (int i = 0; i < VPL; ++i) {
+    const int c = lane + 64 * i;
+    g4[i] = (c < nvec) ? reinterpret_cast<const float4*>(gamma)[c] : make_float4(0.f, 0.f, 0.f, 0.f);
+    dg[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+    db[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+  }
+  for (long row = (long)blockIdx.x * 4 + wave; row < rows; row += (long)gridDim.x * 4) {
+    const float4* xr = reinterpret_cast<const float4*>(x + row * ldx);
+    const DT* dyr = dy + row * (long)dim;
+    const float mu = mean[row], rs = rstd[row];
+    float4 xh[VPL], gg[VPL];
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int i = 0; i < VPL; ++i) {
+      const int c = lane + 64 * i;
+      float4 d = make_float4(0.f, 0.f, 0.f, 0.f), xv = make_float4(mu, mu, mu, mu);
+      if (c < nvec) {
+        xv = xr[c];
+        if constexpr (sizeof(DT) == 4) {
+          d = reinterpret_cast<const float4*>(dyr)[c];
+        } else {
+          const bf16x4 t = reinterpret_cast<const bf16x4*>(dyr)[c];
+          d = make_float4((float)t[0], (float)t[1], (float)t[2], (float)t[3]);
+        }
+      }
+      xh[i] = make_float4((xv.x - mu) * rs, (xv.y - mu) * rs, (xv.z - mu) * rs, (xv.w - mu) * rs);
+      gg[i] = make_float4(d.x * g4[i].x, d.y * g4[i].y, d.z * g4[i].z, d.w * g4[i].w);
+      s1 += (gg[i].x + gg[i].y) + (gg[i].z + gg[i].w);
+      s2 += (gg[i].x * xh[i].x + gg[i].y * xh[i].y) + (gg[i].z * xh[i].z + gg[i].w * xh[i].w);
+      dg[i].x += d.x * xh[i].x; dg[i].y += d.y * xh[i].y; dg[i].z += d.z * xh[i].z; dg[i].w += d.w * xh[i].w;
+      db[i].x += d.x; db[i].y += d.y; db[i].z += d.z; db[i].w += d.w;
+    }
+    const float c1 = wave_sum(s1) * inv_dim;
+    const float c2 = wave_sum(s2) * inv_dim;
+    float4* dxr = reinterpret_cast<float4*>(dx + row * lddx);
+    const float4* addr = dx_add ? reinterpret_cast<const float4*>(dx_add + row * lddx) : nullptr;
+#pragma unroll
+    for (int i = 0; i < VPL; ++i) {
+      const int c = lane + 64 * i;
+      if (c < nvec) {
+        float4 o = make_float4(rs * (gg[i].x - c1 - xh[i].x * c2), rs * (gg[i].y - c1 - xh[i].y * c2),
+                               rs * (gg[i].z - c1 - xh[i].z * c2), rs * (gg[i].w - c1 - xh[i].w * c2));
+        if (addr) {
+          const float4 a = addr[c];
+          o.x += a.x; o.y += a.y; o.z += a.z; o.w += a.w;
+        }
+        dxr[c] = o;
+      }
+    }
+  }
+  // block reduction of the per-wave column partials
+#pragma unroll
+  for (int i = 0; i < VPL; ++i) {
+    float* r = &red[wave][(i * 64 + lane) * 8];
+    r[0] = dg[i].x; r[1] = dg[i].y; r[2] = dg[i].z; r[3] = dg[i].w;
+    r[4] = db[i].x; r[5] = db[i].y; r[6] = db[i].z; r[7] = db[i].w;
+  }
+  __syncthreads();
+  float* prow = partial + (long)blockIdx.x * 2 * dim;
+  for (int idx = threadIdx.x; idx < VPL * 64 * 8; idx += 256) {
+    const int vec = idx >> 3, e = idx & 7;       // vec = i*64 + lane -> column block c = lane + 64*i
+    const int i = vec >> 6, l = vec & 63;
+    const int c = l + 64 * i;
+    if (c < nvec) {
+      const float s = (red[0][idx] + red[1][idx]) + (red[2][idx] + red[3][idx]);
+      const int col = c * 4 + (e & 3);
+      prow[(e >> 2) * dim + col] = s;
+    }
+  }
+}
+
+__global__ void ln_bwd_finish(const float* __restrict__ partial, int nblocks, int dim, float* dgamma, float* dbeta,
+                              int accumulate) {
+  const int j = blockIdx.x * blockDim.x + threadIdx.x;  // 0 .. 2*dim-1
+  if (j >= 2 * dim) return;
+  float s = 0.f;
+  for (int b = 0; b < nblocks; ++b) s += partial[(long)b * 2 * dim + j];
+  float* out = (j < dim) ? (dgamma + j) : (dbeta + (j - dim));
+  *out = accumulate ? (*out + s) : s;
+}
+
+int ln_grid(int rows) {
+  int g = mv_cdiv(rows, 4);
+  return g < 1 ? 1 : (g > 1024 ? 1024 : g);
+}
+
+}  // namespace
+
+extern "C" size_t mv_layernorm_bwd_workspace_bytes(int rows, int dim) {
+  return (size_t)ln_grid(rows) * 2 * (size_t)dim * sizeof(float);
+}
+
+#define LN_FWD_CASE(V)                                                                                      \
+  case V:                                                                                                   \
+    if (y_dtype == MV_F32)                                                                                  \
+      ln_fwd_kernel<V, float><<<grid, 256, 0, s>>>(x, ldx, gamma, beta, (float*)y, mean, rstd, rows, dim, eps); \
+    else                                                                                                    \
+      ln_fwd_kernel<V, bf16_t><<<grid, 256, 0, s>>>(x, ldx, gamma, beta, (bf16_t*)y, mean, rstd, rows, dim, eps); \
+    break;
+
+extern "C" int mv_layernorm_fwd(const float* x, long ldx, const float* gamma, const float* beta, void* y, int y_dtype,
+                                float* mean, float* rstd, int rows, int dim, float eps, mv_stream_t stream) {
+  MV_REQUIRE(rows >= 0 && dim > 0 && dim % 4 == 0 && dim <= 4096 && ldx % 4 == 0, MV_ERR_SHAPE);
+  MV_REQUIRE(y_dtype == MV_F32 || y_dtype == MV_BF16, MV_ERR_UNSUPPORTED);
+  MV_REQUIRE(mv_aligned16(x) && mv_aligned16(gamma) && mv_aligned16(beta) && mv_aligned16(y), MV_ERR_ALIGN);
+  if (rows == 0) return MV_OK;
+  hipStream_t s = (hipStream_t)stream;
+  int grid = mv_cdiv(rows, 4);
+  if (grid > 2048) grid = 2048;  // grid-stride beyond 8 blocks per CU
+  const int vpl = mv_cdiv(dim / 4, 64);
+  switch (vpl) {
+    LN_FWD_CASE(1) LN_FWD_CASE(2) LN_FWD_CASE(3) LN_FWD_CASE(4)
+    case 5: case 6: case 7: case 8:
+      if (y_dtype == MV_F32)
+        ln_fwd_kernel<8, float><<<grid, 256, 0, s>>>(x, ldx, gamma, beta, (float*)y, mean, rstd, rows, dim, eps);
+      else
+        ln_fwd_kernel<8, bf16_t><<<grid, 256, 0, s>>>(x, ldx, gamma, beta, (bf16_t*)y, mean, rstd, rows, dim, eps);
+      break;
+    default:
+      if (y_dtype == MV_F32)
+        ln_fwd_kernel<16, float><<<grid, 256, 0, s>>>(x, ldx, gamma, beta, (float*)y, mean, rstd, rows, dim, eps);
+      else
+        ln_fwd_kernel<16, bf16_t><<<grid, 256, 0, s>>>(x, ldx, gamma, beta, (bf16_t*)y, mean, rstd, rows, dim, eps);
+  }
+  MV_CHECK_LAUNCH();
+  return MV_OK;
+}
+
+#define LN_BWD_LAUNCH(V)                                                                                     \
+  if (dy_dtype == MV_F32)                                                                                    \
+    ln_bwd_kernel<V, float><<<grid, 256, 0, s>>>((const float*)dy, x, ldx, gamma, mean, rstd, dx_add, dx, lddx, \
+                                                 workspace, rows, dim);                                      \
+  else                                                                                                       \
+    ln_bwd_kernel<V, bf16_t><<<grid, 256, 0, s>>>((const bf16_t*)dy, x, ldx, gamma, mean, rstd, dx_add, dx, lddx, \
+                                                  workspace, rows, dim);
+
+extern "C" int mv_layernorm_bwd(const void* dy, int dy_dtype, const float* x, long ldx, const float* gamma,
+                                const float* mean, const float* rstd, const float* dx_add, float* dx, long lddx,
+                                float* dgamma, float* dbeta, int accumulate, float* workspace, size_t workspace_bytes,
+                                int rows, int dim, mv_stream_t stream) {
+  MV_REQUIRE(rows >= 0 && dim > 0 && dim % 4 == 0 && dim <= 2048 && ldx % 4 == 0 && lddx % 4 == 0, MV_ERR_SHAPE);
+  MV_REQUIRE(dy_dtype == MV_F32 || dy_dtype == MV_BF16, MV_ERR_UNSUPPORTED);
+  MV_REQUIRE(mv_aligned16(x) && mv_aligned16(gamma) && mv_aligned16(dy) && mv_aligned16(dx) &&
+                 (!dx_add || mv_aligned16(dx_add)),
+             MV_ERR_ALIGN);
+  MV_REQUIRE(workspace_bytes >= mv_layernorm_bwd_workspace_bytes(rows, dim), MV_ERR_WORKSPACE);
+  hipStream_t s = (hipStream_t)stream;
+  const int grid = ln_grid(rows);
+  if (rows > 0) {
+    const int vpl = mv_cdiv(dim / 4, 64);
+    switch (vpl) {
+      case 1: LN_BWD_LAUNCH(1) break;
+      case 2: LN_BWD_LAUNCH(2) break;
+      case 3: LN_BWD_LAUNCH(3) break;
+      case 4: LN_BWD_LAUNCH(4) break;
+      default: LN_BWD_LAUNCH(8) break;
+    }
+    MV_CHECK_LAUNCH();
+  }
+  ln_bwd_finish<<<mv_cdiv(2 * dim, 256), 256, 0, s>>>(workspace, rows > 0 ? grid : 0, dim, dgamma, dbeta, accumulate);
+  MV_CHECK_LAUNCH();
+  return MV_OK;
+}

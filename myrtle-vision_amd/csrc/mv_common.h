@@ -1,0 +1,60 @@
+// Shared device/host helpers for the myrtle_vision HIP kernels (gfx950 / CDNA4 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/myrtle_vision_hip.h"
+
+typedef __bf16 bf16_t;
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
+typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef __attribute__((ext_vector_type(2))) float f32x2;
+// 16-byte staging register.  NOT HIP's uint4: that is a struct, and a select between structs goes through
+// memory (scratch); a select between native vectors stays in VGPRs.
+typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
+
+#define MV_WAVE 64
+#define LDS_PTR(T, p) ((__attribute__((address_space(3))) T*)(p))
+
+// ---- launch plumbing ------------------------------------------------------------------------
+#define MV_CHECK_LAUNCH()                                   \
+  do {                                                      \
+    hipError_t e__ = hipGetLastError();                     \
+    if (e__ != hipSuccess) return MV_ERR_LAUNCH;            \
+  } while (0)
+
+#define MV_REQUIRE(cond, code) \
+  do {                         \
+    if (!(cond)) return (code); \
+  } while (0)
+
+static inline bool mv_aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
+static inline int mv_cdiv(long a, long b) { return (int)((a + b - 1) / b); }
+
+// ---- dtype-generic element access -------------------------------------------------------------
+template <typename T>
+__device__ __forceinline__ float mv_ld(const T* p) { return (float)(*p); }
+template <typename T>
+__device__ __forceinline__ void mv_st(T* p, float v) { *p = (T)v; }
+
+// wave64 reductions (DPP/shuffle); every lane ends with the full result
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+  return v;
+}
+
+// exact-erf GELU and its derivative (reference: nn.GELU() default, vit.py:49)
+__device__ __forceinline__ float gelu_f(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
+__device__ __forceinline__ float dgelu_f(float x) {
+  const float cdf = 0.5f * (1.0f + erff(x * 0.70710678118654752440f));
+  const float pdf = 0.39894228040143267794f * __expf(-0.5f * x * x);
+  return cdf + x * pdf;
+}

@@ -1,0 +1,71 @@
+"""Build libmyrtle_vision_hip.so for gfx950 with hipcc (cross-compiles without a GPU).
+
+    python -m myrtle_vision.hip.build [--force]
+
+The library is built IN TREE (``myrtle-vision_amd/lib/``) so it travels with the source snapshot.
+"""
+import hashlib
+import os
+import subprocess
+import sys
+from concurrent.futures import ThreadPoolExecutor
+
+PKG_ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))  # myrtle-vision_amd/
+CSRC = os.path.join(PKG_ROOT, "csrc")
+LIB_DIR = os.path.join(PKG_ROOT, "lib")
+LIB_PATH = os.path.join(LIB_DIR, "libmyrtle_vision_hip.so")
+INCLUDE = os.path.join(os.path.dirname(PKG_ROOT), "include")
+SOURCES = ["layernorm.hip", "gemm_bf16.hip", "gemm_f32.hip", "attention.hip", "elementwise.hip"]
+FLAGS = ["--offload-arch=gfx950", "-O3", "-fPIC", "-std=c++17", "-Wall", "-Wno-unused-function"]
+
+
+def _hipcc():
+    for c in (os.environ.get("HIPCC"), "/opt/rocm/bin/hipcc", "hipcc"):
+        if c and (os.path.isabs(c) and os.path.exists(c) or not os.path.isabs(c)):
+            return c
+    return "hipcc"
+
+
+def _digest():
+    h = hashlib.sha256()
+    for f in sorted(os.listdir(CSRC)) + ["../../include/myrtle_vision_hip.h"]:
+        with open(os.path.join(CSRC, f), "rb") as fh:
+            h.update(f.encode() + b"\0" + fh.read())
+    h.update(" ".join(FLAGS).encode())
+    return h.hexdigest()
+
+
+def build(force: bool = False, verbose: bool = True) -> str:
+    os.makedirs(LIB_DIR, exist_ok=True)
+    stamp = os.path.join(LIB_DIR, "build.sha256")
+    dig = _digest()
+    if not force and os.path.exists(LIB_PATH) and os.path.exists(stamp) and open(stamp).read().strip() == dig:
+        return LIB_PATH
+    hipcc = _hipcc()
+    objs = []
+
+    def compile_one(src):
+        obj = os.path.join(LIB_DIR, src.replace(".hip", ".o"))
+        cmd = [hipcc] + FLAGS + ["-I", INCLUDE, "-c", os.path.join(CSRC, src), "-o", obj]
+        r = subprocess.run(cmd, capture_output=True, text=True)
+        if r.returncode != 0:
+            raise RuntimeError(f"hipcc failed for {src}:\n{r.stderr}")
+        if verbose and r.stderr.strip():
+            sys.stderr.write(r.stderr)
+        return obj
+
+    with ThreadPoolExecutor(max_workers=min(5, os.cpu_count() or 1)) as ex:
+        objs = list(ex.map(compile_one, SOURCES))
+    r = subprocess.run([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB_PATH] + objs,
+                       capture_output=True, text=True)
+    if r.returncode != 0:
+        raise RuntimeError(f"link failed:\n{r.stderr}")
+    with open(stamp, "w") as f:
+        f.write(dig)
+    if verbose:
+        print(f"built {LIB_PATH}")
+    return LIB_PATH
+
+
+if __name__ == "__main__":
+    build(force="--force" in sys.argv)

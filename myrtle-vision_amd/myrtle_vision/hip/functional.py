@@ -1,0 +1,554 @@
+"""Autograd functions of the ViT hot path on the HIP kernels.
+
+Granular functions (``layer_norm``, ``linear``, ``gelu``, ``attention_core``, ``patch_embed`` ...) mirror one
+reference module each and compose freely (used when fake-quant stubs sit between modules, or when a submodule
+is called on its own).  The fused functions ``attn_block`` / ``mlp_block`` implement one whole
+``Residual(PreNorm(...))`` of the reference (vit.py:131-151) with everything fusable fused into GEMM epilogues:
+
+    attn_block:  LN -> QKV GEMM(+bias) -> fused attention -> proj GEMM(+bias +residual)
+    mlp_block :  LN -> fc1 GEMM(+bias, GELU, keeps pre-activation) -> fc2 GEMM(+bias +residual)
+    backward  :  dX GEMMs (fc2's with the GELU' epilogue), dW GEMMs (transposed LDS reads, split-K),
+                 attention backward, LN backward with the residual gradient folded in.
+
+The residual stream and all gradients w.r.t. parameters are fp32; activations are bf16 (``prec='bf16'``) or fp32
+(``prec='fp32'``: exact-parity mode).  Backward runs on autograd's worker thread: everything here is stateless
+apart from caches keyed by tensor identity.
+"""
+import torch
+from torch.autograd import Function
+
+from . import ops
+from .ops import EPI_DGELU, EPI_EMBED, EPI_GELU, EPI_NONE, EPI_RESIDUAL
+
+
+def _c(t):
+    return t if t.is_contiguous() else t.contiguous()
+
+
+# ------------------------------------------------------------------------------------------------------------
+# granular functions
+# ------------------------------------------------------------------------------------------------------------
+class _LayerNorm(Function):
+    """nn.LayerNorm over the last dim (vit.py:37).  Input fp32 (any leading shape), output ``out_dtype``."""
+
+    @staticmethod
+    def forward(ctx, x, gamma, beta, out_dtype, eps):
+        ops.require_cuda(x, gamma, beta)
+        x = _c(x.float())
+        dim = x.shape[-1]
+        rows = x.numel() // dim
+        y, mean, rstd = ops.layernorm_fwd(x, dim, rows, dim, gamma, beta, out_dtype, eps)
+        ctx.save_for_backward(x, gamma, mean, rstd)
+        return y.view(x.shape)
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, gamma, mean, rstd = ctx.saved_tensors
+        dim = x.shape[-1]
+        rows = x.numel() // dim
+        dy = _c(dy)
+        dx = torch.empty_like(x)
+        dg, db = ops.layernorm_bwd(dy, x, dim, gamma, mean, rstd, None, dx, dim, rows, dim)
+        return dx, dg, db, None, None
+
+
+def layer_norm(x, gamma, beta, out_dtype=torch.float32, eps=1e-5):
+    return _LayerNorm.apply(x, gamma, beta, out_dtype, eps)
+
+
+class _Linear(Function):
+    """nn.Linear: y = x W^T + b (vit.py:72,74,48,51,220,333).  x dtype selects the kernel family."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, out_dtype):
+        ops.require_cuda(x, weight, bias)
+        K = x.shape[-1]
+        N = weight.shape[0]
+        x2 = _c(x).view(-1, K)
+        M = x2.shape[0]
+        if x2.dtype == torch.bfloat16 and K % 8 != 0:
+            raise RuntimeError(f"bf16 Linear needs in_features % 8 == 0 (got {K}); use precision='fp32'")
+        out = torch.empty(M, N, dtype=out_dtype, device=x.device)
+        ops.linear_fwd(x2, M, K, weight, bias, out, N)
+        ctx.save_for_backward(x2, weight)
+        ctx.has_bias = bias is not None
+        ctx.in_shape = x.shape
+        return out.view(*x.shape[:-1], N)
+
+    @staticmethod
+    def backward(ctx, dy):
+        x2, weight = ctx.saved_tensors
+        M, K = x2.shape
+        N = weight.shape[0]
+        dy2 = _c(dy).view(M, N)
+        if dy2.dtype != x2.dtype:
+            dy2 = ops.cast(dy2, x2.dtype)
+        ld_dy = N
+        if dy2.dtype == torch.bfloat16 and N % 8 != 0:      # pad the contraction dim of dX / rows of dW^T with zeros
+            ld_dy = ops.pad8(N)
+            padded = torch.zeros(M, ld_dy, dtype=dy2.dtype, device=dy2.device)
+            padded[:, :N] = dy2
+            dy2 = padded
+        dx = None
+        if ctx.needs_input_grad[0]:
+            dx = torch.empty(M, K, dtype=x2.dtype, device=x2.device)
+            ops.linear_dx(dy2, M, N, weight, dx, K, ld_dy=ld_dy)
+            dx = dx.view(ctx.in_shape)
+        dw, db = ops.linear_dw(dy2, x2, M, N, K, ld_dy=ld_dy, want_bias=ctx.has_bias)
+        return dx, dw, db, None
+
+
+def linear(x, weight, bias, out_dtype=None):
+    return _Linear.apply(x, weight, bias, x.dtype if out_dtype is None else out_dtype)
+
+
+class _Gelu(Function):
+    @staticmethod
+    def forward(ctx, x):
+        ops.require_cuda(x)
+        x = _c(x)
+        ctx.save_for_backward(x)
+        return ops.gelu_fwd(x)
+
+    @staticmethod
+    def backward(ctx, dy):
+        (x,) = ctx.saved_tensors
+        dy = _c(dy)
+        if dy.dtype != x.dtype:
+            dy = ops.cast(dy, x.dtype)
+        return ops.gelu_bwd(x, dy)
+
+
+def gelu(x):
+    return _Gelu.apply(x)
+
+
+class _Cast(Function):
+    @staticmethod
+    def forward(ctx, x, dtype):
+        ctx.src_dtype = x.dtype
+        return ops.cast(_c(x), dtype)
+
+    @staticmethod
+    def backward(ctx, dy):
+        return ops.cast(_c(dy), ctx.src_dtype), None
+
+
+def cast(x, dtype):
+    return x if x.dtype == dtype else _Cast.apply(x, dtype)
+
+
+class _Add(Function):
+    """FloatFunctional.add of the residual (vit.py:27) in the unfused path."""
+
+    @staticmethod
+    def forward(ctx, a, b):
+        ops.require_cuda(a, b)
+        return ops.add_f32(_c(a.float()), _c(b.float()))
+
+    @staticmethod
+    def backward(ctx, d):
+        return d, d
+
+
+def add(a, b):
+    return _Add.apply(a, b)
+
+
+class _AttentionFused(Function):
+    """softmax(q k^T * scale) v on the fused MFMA kernel.  qkv bf16 [B, N, 3*H*64] -> [B, N, H*64]."""
+
+    @staticmethod
+    def forward(ctx, qkv, heads, scale):
+        B, N, three_d = qkv.shape
+        qkv = _c(qkv)
+        out, lse = ops.attention_fwd(qkv, B, N, heads, scale)
+        ctx.save_for_backward(qkv, out, lse)
+        ctx.heads, ctx.scale = heads, scale
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        qkv, out, lse = ctx.saved_tensors
+        B, N, _ = qkv.shape
+        dout = _c(dout)
+        if dout.dtype != torch.bfloat16:
+            dout = ops.cast(dout, torch.bfloat16)
+        return ops.attention_bwd(qkv, out, dout, lse, B, N, ctx.heads, ctx.scale), None, None
+
+
+class _AttentionProbs(Function):
+    """Materialised fp32 path, part 1: probs = softmax(q k^T * scale)  [B, H, N, N] (vit.py:92-93)."""
+
+    @staticmethod
+    def forward(ctx, qkv, heads, scale):
+        B, N, three_d = qkv.shape
+        dh = three_d // (3 * heads)
+        qkv = _c(qkv)
+        probs = ops.attention_probs_fp32(qkv, B, N, heads, dh, scale)
+        ctx.save_for_backward(qkv, probs)
+        ctx.heads, ctx.scale, ctx.dh = heads, scale, dh
+        return probs
+
+    @staticmethod
+    def backward(ctx, dprobs):
+        qkv, probs = ctx.saved_tensors
+        B, N, _ = qkv.shape
+        H, dh, D = ctx.heads, ctx.dh, ctx.heads * ctx.dh
+        L = ops.lib()
+        dS = torch.empty_like(probs)
+        dprobs = _c(dprobs)
+        ops.check(L.mv_softmax_bwd(probs.data_ptr(), dprobs.data_ptr(), dS.data_ptr(), B * H * N, N, ctx.scale, ops._s()),
+                  "softmax_bwd")
+        dqkv = torch.zeros_like(qkv)
+        flat, dflat = qkv.view(-1), dqkv.view(-1)
+        bq, hq, bp, hp = N * 3 * D, dh, H * N * N, N * N
+        ops.check(L.mv_gemm_f32(dS.data_ptr(), N, 1, bp, hp, flat[D:].data_ptr(), 3 * D, 1, bq, hq, dqkv.data_ptr(), 3 * D, 1,
+                                bq, hq, N, dh, N, B, H, 1.0, 0, None, EPI_NONE, None, 0, 0, None, 0, ops._s()), "gemm_f32(dQ)")
+        ops.check(L.mv_gemm_f32(dS.data_ptr(), 1, N, bp, hp, qkv.data_ptr(), 3 * D, 1, bq, hq, dflat[D:].data_ptr(), 3 * D, 1,
+                                bq, hq, N, dh, N, B, H, 1.0, 0, None, EPI_NONE, None, 0, 0, None, 0, ops._s()), "gemm_f32(dK)")
+        return dqkv, None, None
+
+
+class _AttentionPV(Function):
+    """Materialised fp32 path, part 2: out = (probs @ v).transpose(1,2).reshape(B,N,C) (vit.py:96)."""
+
+    @staticmethod
+    def forward(ctx, probs, qkv, heads):
+        B, N, three_d = qkv.shape
+        dh = three_d // (3 * heads)
+        probs, qkv = _c(probs), _c(qkv)
+        ctx.save_for_backward(probs, qkv)
+        ctx.heads, ctx.dh = heads, dh
+        return ops.attention_pv_fp32(probs, qkv, B, N, heads, dh)
+
+    @staticmethod
+    def backward(ctx, dout):
+        probs, qkv = ctx.saved_tensors
+        B, N, _ = qkv.shape
+        H, dh, D = ctx.heads, ctx.dh, ctx.heads * ctx.dh
+        L = ops.lib()
+        dout = _c(dout.float())
+        flat = qkv.view(-1)
+        bq, hq, bp, hp, bo, ho = N * 3 * D, dh, H * N * N, N * N, N * D, dh
+        dP = torch.empty_like(probs)
+        ops.check(L.mv_gemm_f32(dout.data_ptr(), D, 1, bo, ho, flat[2 * D:].data_ptr(), 1, 3 * D, bq, hq, dP.data_ptr(), N, 1,
+                                bp, hp, N, N, dh, B, H, 1.0, 0, None, EPI_NONE, None, 0, 0, None, 0, ops._s()), "gemm_f32(dP)")
+        dqkv = torch.zeros_like(qkv)
+        ops.check(L.mv_gemm_f32(probs.data_ptr(), 1, N, bp, hp, dout.data_ptr(), D, 1, bo, ho,
+                                dqkv.view(-1)[2 * D:].data_ptr(), 3 * D, 1, bq, hq, N, dh, N, B, H, 1.0, 0, None, EPI_NONE,
+                                None, 0, 0, None, 0, ops._s()), "gemm_f32(dV)")
+        return dP, dqkv, None
+
+
+def attention_core(qkv, heads, scale, probs_hook=None):
+    """Attention.forward lines vit.py:87-96 on a to_qkv output [B, N, 3*heads*dh].
+
+    ``probs_hook`` (callable or None) is the reference's ``attn_output`` Identity (vit.py:80-82,94): when it has
+    forward hooks the probabilities are materialised (fp32) and passed through it; otherwise bf16 inputs take the
+    fused kernel."""
+    B, N, three_d = qkv.shape
+    dh = three_d // (3 * heads)
+    if probs_hook is None and ops.attention_fused_supported(qkv.dtype, N, dh):
+        return _AttentionFused.apply(qkv, heads, scale)
+    src_dtype = qkv.dtype
+    q32 = cast(qkv, torch.float32)
+    probs = _AttentionProbs.apply(q32, heads, scale)
+    if probs_hook is not None:
+        probs = probs_hook(probs)
+    out = _AttentionPV.apply(probs, q32, heads)
+    return cast(out, src_dtype)
+
+
+class _PatchEmbed(Function):
+    """patchify + patch_to_embedding + cls token + positional embedding (vit.py:271-311) -> fp32 [B, T, D]."""
+
+    @staticmethod
+    def forward(ctx, img, weight, bias, cls_token, pos, patch, prec):
+        ops.require_cuda(img, weight, bias, cls_token, pos)
+        adt = ops.act_dtype(prec)
+        B, C, H, W = img.shape
+        npatch = (H // patch) * (W // patch)
+        T, D, pd = npatch + 1, weight.shape[0], weight.shape[1]
+        if adt == torch.bfloat16 and pd % 8 != 0:
+            raise RuntimeError(f"bf16 patch embedding needs patch_dim % 8 == 0 (got {pd}); use precision='fp32'")
+        patches = ops.patchify(img, patch, adt)
+        x = torch.empty(B, T, D, dtype=torch.float32, device=img.device)
+        pos2 = _c(pos.detach().float()).view(T, D)
+        ops.linear_fwd(patches, B * npatch, pd, weight, bias, x, D, epi=EPI_EMBED, aux=pos2, ld_aux=D, aux_i=npatch)
+        ops.embed_cls(_c(cls_token.detach()).view(D), pos2, x, B, T, D)
+        ctx.save_for_backward(patches)
+        ctx.dims = (B, T, D, pd, npatch)
+        ctx.pos_shape, ctx.cls_shape = pos.shape, cls_token.shape
+        return x
+
+    @staticmethod
+    def backward(ctx, dx):
+        (patches,) = ctx.saved_tensors
+        B, T, D, pd, npatch = ctx.dims
+        dx = _c(dx.float())
+        dpos, dcls = ops.embed_bwd(dx, B, T, D)
+        dy = ops.gather_patch_rows(dx, B, T, D, patches.dtype)
+        dw, db = ops.linear_dw(dy, patches, B * npatch, D, pd)
+        return None, dw, db, dcls.view(ctx.cls_shape), dpos.view(ctx.pos_shape), None, None
+
+
+def patch_embed(img, weight, bias, cls_token, pos, patch, prec):
+    if img.requires_grad:
+        raise RuntimeError("gradient w.r.t. the input image is not implemented (the reference never needs it)")
+    return _PatchEmbed.apply(img, weight, bias, cls_token, pos, patch, prec)
+
+
+# ------------------------------------------------------------------------------------------------------------
+# fused transformer blocks
+# ------------------------------------------------------------------------------------------------------------
+class _AttnBlock(Function):
+    """x + to_out(attention(to_qkv(LN(x))))  ==  Residual(PreNorm(dim, Attention)) (vit.py:131-141, 84-99)."""
+
+    @staticmethod
+    def forward(ctx, x, g, b, wqkv, bqkv, wo, bo, heads, scale, prec):
+        adt = ops.act_dtype(prec)
+        B, T, D = x.shape
+        M = B * T
+        x = _c(x)
+        y, mean, rstd = ops.layernorm_fwd(x, D, M, D, g, b, adt)
+        inner3 = wqkv.shape[0]
+        inner = inner3 // 3
+        qkv = torch.empty(B, T, inner3, dtype=adt, device=x.device)
+        ops.linear_fwd(y, M, D, wqkv, bqkv, qkv, inner3)
+        dh = inner // heads
+        if ops.attention_fused_supported(adt, T, dh):
+            o, lse = ops.attention_fwd(qkv, B, T, heads, scale)
+            probs = None
+        else:                                   # materialised fp32 probabilities (fp32 mode, or shapes the fused kernel lacks)
+            q32 = ops.cast(qkv, torch.float32)
+            probs = ops.attention_probs_fp32(q32, B, T, heads, dh, scale)
+            o = ops.cast(ops.attention_pv_fp32(probs, q32, B, T, heads, dh), adt)
+            lse = None
+        out = torch.empty_like(x)
+        ops.linear_fwd(o.view(M, inner), M, inner, wo, bo, out, D, epi=EPI_RESIDUAL, aux=x, ld_aux=D)
+        ctx.save_for_backward(x, g, mean, rstd, y, qkv, o, lse if lse is not None else probs, wqkv, wo)
+        ctx.cfg = (heads, scale, lse is not None)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        x, g, mean, rstd, y, qkv, o, lse_or_probs, wqkv, wo = ctx.saved_tensors
+        heads, scale, fused = ctx.cfg
+        B, T, D = x.shape
+        M = B * T
+        inner3 = wqkv.shape[0]
+        inner = inner3 // 3
+        adt = y.dtype
+        dout = _c(dout)
+        d_act = ops.cast(dout, adt).view(M, D)                    # dY of the projection, activation dtype
+        dwo, dbo = ops.linear_dw(d_act, o.view(M, inner), M, D, inner)
+        do = torch.empty(B, T, inner, dtype=adt, device=x.device)
+        ops.linear_dx(d_act, M, D, wo, do, inner)
+        if fused:
+            dqkv = ops.attention_bwd(qkv, o, do, lse_or_probs, B, T, heads, scale)
+        else:
+            dqkv = ops.cast(ops.attention_bwd_fp32(lse_or_probs, ops.cast(qkv, torch.float32), ops.cast(do, torch.float32),
+                                                   B, T, heads, inner // heads, scale), adt)
+        dwqkv, dbqkv = ops.linear_dw(dqkv.view(M, inner3), y, M, inner3, D)
+        dy = torch.empty(M, D, dtype=adt, device=x.device)
+        ops.linear_dx(dqkv.view(M, inner3), M, inner3, wqkv, dy, D)
+        dx = torch.empty_like(x)
+        dg, db = ops.layernorm_bwd(dy, x, D, g, mean, rstd, dout, dx, D, M, D)   # + residual gradient
+        return dx, dg, db, dwqkv, dbqkv, dwo, dbo, None, None, None
+
+
+def attn_block(x, g, b, wqkv, bqkv, wo, bo, heads, scale, prec):
+    return _AttnBlock.apply(x, g, b, wqkv, bqkv, wo, bo, heads, scale, prec)
+
+
+class _MlpBlock(Function):
+    """x + fc2(gelu(fc1(LN(x))))  ==  Residual(PreNorm(dim, FeedForward)) (vit.py:142-151, 44-56)."""
+
+    @staticmethod
+    def forward(ctx, x, g, b, w1, b1, w2, b2, prec):
+        adt = ops.act_dtype(prec)
+        B, T, D = x.shape
+        M = B * T
+        Hd = w1.shape[0]
+        x = _c(x)
+        y, mean, rstd = ops.layernorm_fwd(x, D, M, D, g, b, adt)
+        h = torch.empty(M, Hd, dtype=adt, device=x.device)     # pre-activation (kept for GELU')
+        a = torch.empty(M, Hd, dtype=adt, device=x.device)
+        ops.linear_fwd(y, M, D, w1, b1, a, Hd, epi=EPI_GELU, out2=h, ld_out2=Hd)
+        out = torch.empty_like(x)
+        ops.linear_fwd(a, M, Hd, w2, b2, out, D, epi=EPI_RESIDUAL, aux=x, ld_aux=D)
+        ctx.save_for_backward(x, g, mean, rstd, y, h, a, w1, w2)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        x, g, mean, rstd, y, h, a, w1, w2 = ctx.saved_tensors
+        B, T, D = x.shape
+        M = B * T
+        Hd = w1.shape[0]
+        adt = y.dtype
+        dout = _c(dout)
+        d_act = ops.cast(dout, adt).view(M, D)
+        dw2, db2 = ops.linear_dw(d_act, a, M, D, Hd)
+        dh = torch.empty(M, Hd, dtype=adt, device=x.device)
+        ops.linear_dx(d_act, M, D, w2, dh, Hd, epi=EPI_DGELU, aux=h, ld_aux=Hd)    # (dY W2) * gelu'(h)
+        dw1, db1 = ops.linear_dw(dh, y, M, Hd, D)
+        dy = torch.empty(M, D, dtype=adt, device=x.device)
+        ops.linear_dx(dh, M, Hd, w1, dy, D)
+        dx = torch.empty_like(x)
+        dg, db = ops.layernorm_bwd(dy, x, D, g, mean, rstd, dout, dx, D, M, D)
+        return dx, dg, db, dw1, db1, dw2, db2, None
+
+
+def mlp_block(x, g, b, w1, b1, w2, b2, prec):
+    return _MlpBlock.apply(x, g, b, w1, b1, w2, b2, prec)
+
+
+# ------------------------------------------------------------------------------------------------------------
+# decoders
+# ------------------------------------------------------------------------------------------------------------
+class _ClsHead(Function):
+    """ClassificationDecoder: linear(norm(x[:, 0])) (vit.py:335-342) -> fp32 logits [B, num_classes]."""
+
+    @staticmethod
+    def forward(ctx, x, g, b, w, bias, prec):
+        adt = ops.act_dtype(prec)
+        B, T, D = x.shape
+        C = w.shape[0]
+        x = _c(x)
+        y, mean, rstd = ops.layernorm_fwd(x, T * D, B, D, g, b, adt)        # rows = the cls tokens, T*D apart
+        logits = torch.empty(B, C, dtype=torch.float32, device=x.device)
+        ops.linear_fwd(y, B, D, w, bias, logits, C)
+        ctx.save_for_backward(x, g, mean, rstd, y, w)
+        return logits
+
+    @staticmethod
+    def backward(ctx, dlogits):
+        x, g, mean, rstd, y, w = ctx.saved_tensors
+        B, T, D = x.shape
+        C = w.shape[0]
+        adt = y.dtype
+        ld = ops.pad8(C) if adt == torch.bfloat16 else C
+        dl = torch.zeros(B, ld, dtype=adt, device=x.device)
+        dl[:, :C] = dlogits                                                # tiny (B x C) pad+cast: cold glue
+        dw, dbias = ops.linear_dw(dl, y, B, C, D, ld_dy=ld)
+        dy = torch.empty(B, D, dtype=adt, device=x.device)
+        ops.linear_dx(dl, B, C, w, dy, D, ld_dy=ld)
+        dx = torch.zeros_like(x)
+        dg, db = ops.layernorm_bwd(dy, x, T * D, g, mean, rstd, None, dx, T * D, B, D)
+        return dx, dg, db, dw, dbias, None
+
+
+def cls_head(x, g, b, w, bias, prec):
+    return _ClsHead.apply(x, g, b, w, bias, prec)
+
+
+class _SegHead(Function):
+    """SegmentationDecoder: upsample(rearrange(linear(norm(x[:, 1:])))) (vit.py:359-374) -> fp32 [B, C, S, S]."""
+
+    @staticmethod
+    def forward(ctx, x, g, b, w, bias, grid, size, prec):
+        adt = ops.act_dtype(prec)
+        B, T, D = x.shape
+        C = w.shape[0]
+        npatch = T - 1
+        x = _c(x)
+        xp = ops.gather_patch_rows(x, B, T, D, torch.float32)                # x[:, 1:] as dense rows
+        M = B * npatch
+        y, mean, rstd = ops.layernorm_fwd(xp, D, M, D, g, b, adt)
+        small = torch.empty(M, C, dtype=torch.float32, device=x.device)      # [B, h*w, C]
+        ops.linear_fwd(y, M, D, w, bias, small, C)
+        big = ops.upsample_bilinear_fwd(small, npatch * C, 1, C, B, C, grid, grid, size, size)
+        ctx.save_for_backward(xp, g, mean, rstd, y, w)
+        ctx.dims = (B, T, D, C, grid, size)
+        return big
+
+    @staticmethod
+    def backward(ctx, dbig):
+        xp, g, mean, rstd, y, w = ctx.saved_tensors
+        B, T, D, C, grid, size = ctx.dims
+        npatch = T - 1
+        M = B * npatch
+        adt = y.dtype
+        dbig = _c(dbig.float())
+        dsmall = torch.empty(M, C, dtype=torch.float32, device=dbig.device)
+        ops.upsample_bilinear_bwd(dbig, dsmall, npatch * C, 1, C, B, C, grid, grid, size, size)
+        ld = ops.pad8(C) if adt == torch.bfloat16 else C
+        if adt == torch.bfloat16:
+            dl = torch.zeros(M, ld, dtype=adt, device=dbig.device)
+            dl[:, :C] = dsmall                                                # (B*196 x 17) pad+cast: cold glue
+        else:
+            dl = dsmall
+        dw, dbias = ops.linear_dw(dl, y, M, C, D, ld_dy=ld)
+        dy = torch.empty(M, D, dtype=adt, device=dbig.device)
+        ops.linear_dx(dl, M, C, w, dy, D, ld_dy=ld)
+        dx = torch.zeros(B, T, D, dtype=torch.float32, device=dbig.device)
+        # rows of image b start at dx[b, 1]: the patch rows of one image are contiguous, images are T*D apart
+        dxp = torch.empty(M, D, dtype=torch.float32, device=dbig.device)
+        dg, db = ops.layernorm_bwd(dy, xp, D, g, mean, rstd, None, dxp, D, M, D)
+        dx[:, 1:, :] = dxp.view(B, npatch, D)
+        return dx, dg, db, dw, dbias, None, None, None
+
+
+def seg_head(x, g, b, w, bias, grid, size, prec):
+    return _SegHead.apply(x, g, b, w, bias, grid, size, prec)
+
+
+# ------------------------------------------------------------------------------------------------------------
+# loss
+# ------------------------------------------------------------------------------------------------------------
+class _CrossEntropy(Function):
+    """nn.CrossEntropyLoss() (mean) with the gradient produced in the same pass (classification/train.py:170,250)."""
+
+    @staticmethod
+    def forward(ctx, logits, labels):
+        ops.require_cuda(logits, labels)
+        loss, dl, _ = ops.cross_entropy(logits.float(), labels, want_grad=True)
+        ctx.save_for_backward(dl)
+        ctx.shape = logits.shape
+        return loss.view(())
+
+    @staticmethod
+    def backward(ctx, g):
+        (dl,) = ctx.saved_tensors
+        return (dl.view(ctx.shape) * g), None
+
+
+def cross_entropy(logits, labels):
+    return _CrossEntropy.apply(logits, labels)
+
+
+class CrossEntropyLoss(torch.nn.Module):
+    """Drop-in for ``torch.nn.CrossEntropyLoss()`` (mean reduction, no weights) on the HIP kernel."""
+
+    def forward(self, logits, labels):
+        return cross_entropy(logits, labels)
+
+
+# ------------------------------------------------------------------------------------------------------------
+# fake quantisation with straight-through gradient (utils/quantize.py:77-89)
+# ------------------------------------------------------------------------------------------------------------
+class _FakeQuant(Function):
+    @staticmethod
+    def forward(ctx, x, kind, a, b):
+        dtype = x.dtype
+        if kind == "float":
+            y = ops.quant_float(x, a, b)
+        elif kind == "fixed":
+            y = ops.quant_fixed(x, a, b)
+        else:
+            raise ValueError(kind)
+        return y.to(dtype).view(x.shape)
+
+    @staticmethod
+    def backward(ctx, g):
+        return g, None, None, None
+
+
+def fake_quant_float(x, exp_bits, man_bits):
+    return _FakeQuant.apply(x, "float", exp_bits, man_bits)
+
+
+def fake_quant_fixed(x, wl, fl):
+    return _FakeQuant.apply(x, "fixed", wl, fl)

@@ -1,0 +1,86 @@
+"""ctypes binding of the C ABI in ``include/myrtle_vision_hip.h``.
+
+The library is loaded once per process.  There is deliberately NO fallback: if the shared object is missing the
+import of this module's ``lib()`` raises, so a machine without the built HIP path can never silently compute on
+something else.
+"""
+import ctypes
+import os
+import threading
+
+from .build import LIB_PATH
+
+MV_F32, MV_BF16 = 0, 1
+EPI_NONE, EPI_GELU, EPI_RESIDUAL, EPI_DGELU, EPI_EMBED = 0, 1, 2, 3, 4
+
+_P, _I, _L, _F, _Z = ctypes.c_void_p, ctypes.c_int, ctypes.c_long, ctypes.c_float, ctypes.c_size_t
+_KIND = {"p": _P, "i": _I, "l": _L, "f": _F, "z": _Z}
+
+# name -> (argument kinds, return type); one line per declaration in include/myrtle_vision_hip.h, same order
+SIGNATURES = {
+    "mv_version": ("", _I),
+    "mv_error_string": ("i", ctypes.c_char_p),
+    "mv_gemm_tn_workspace_bytes": ("iii", _Z),
+    "mv_layernorm_bwd_workspace_bytes": ("ii", _Z),
+    "mv_layernorm_fwd": ("plpppipp" "iifp", _I),
+    "mv_layernorm_bwd": ("pi" "plp" "pp" "ppl" "ppi" "pz" "iip", _I),
+    "mv_gemm_nt_bf16": ("pipipii" "iii" "pi" "pii" "pi" "p", _I),
+    "mv_gemm_tn_bf16": ("pipipi" "iii" "i" "p" "pz" "p", _I),
+    "mv_gemm_f32": ("pllll" "pllll" "pllll" "iii" "ii" "fi" "pi" "pli" "pl" "p", _I),
+    "mv_attention_fwd": ("ppp" "iii" "f" "p", _I),
+    "mv_attention_bwd": ("ppppp" "iii" "f" "p", _I),
+    "mv_softmax_fwd": ("pp" "li" "f" "p", _I),
+    "mv_softmax_bwd": ("ppp" "li" "f" "p", _I),
+    "mv_patchify": ("ppi" "iiiii" "p", _I),
+    "mv_embed_cls": ("ppp" "iii" "p", _I),
+    "mv_embed_bwd": ("ppp" "i" "iii" "p", _I),
+    "mv_gather_patch_rows": ("ppi" "iii" "p", _I),
+    "mv_cast": ("pipi" "l" "p", _I),
+    "mv_weight_prep": ("ppipi" "ii" "p", _I),
+    "mv_colsum": ("pil" "pi" "li" "pz" "p", _I),
+    "mv_gelu_fwd": ("ppi" "l" "p", _I),
+    "mv_gelu_bwd": ("pppi" "l" "p", _I),
+    "mv_add_f32": ("ppp" "l" "p", _I),
+    "mv_quant_float": ("pp" "l" "ii" "p", _I),
+    "mv_quant_fixed": ("pp" "l" "iiii" "p", _I),
+    "mv_quant_affine": ("pp" "l" "f" "iii" "p", _I),
+    "mv_minmax": ("pl" "p" "p", _I),
+    "mv_cross_entropy": ("ppp" "pii" "p" "lil" "f" "p", _I),
+    "mv_upsample_bilinear_fwd": ("plll" "p" "iiiiii" "p", _I),
+    "mv_upsample_bilinear_bwd": ("pplll" "iiiiii" "p", _I),
+    "mv_adamw": ("pppp" "l" "ffffffff" "p", _I),
+}
+
+_lock = threading.Lock()
+_lib = None
+
+
+class HipLibraryMissing(RuntimeError):
+    pass
+
+
+def lib():
+    """The loaded library (loads on first use)."""
+    global _lib
+    if _lib is None:
+        with _lock:
+            if _lib is None:
+                if not os.path.exists(LIB_PATH):
+                    raise HipLibraryMissing(
+                        f"{LIB_PATH} not found: the myrtle_vision HIP path is not built and there is no CPU "
+                        "fallback. Build it with `python -m myrtle_vision.hip.build` (needs hipcc, gfx950).")
+                handle = ctypes.CDLL(LIB_PATH)
+                for name, (kinds, ret) in SIGNATURES.items():
+                    fn = getattr(handle, name)          # AttributeError here = header/library mismatch
+                    fn.argtypes = [_KIND[k] for k in kinds]
+                    fn.restype = ret
+                _lib = handle
+    return _lib
+
+
+def check(rc: int, op: str, **dims):
+    """Map a nonzero C return code to RuntimeError with the op name and its dimensions."""
+    if rc != 0:
+        msg = lib().mv_error_string(rc).decode()
+        d = ", ".join(f"{k}={v}" for k, v in dims.items())
+        raise RuntimeError(f"myrtle_vision HIP op {op} failed: {msg} (code {rc}; {d})")

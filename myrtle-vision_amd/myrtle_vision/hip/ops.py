@@ -1,0 +1,410 @@
+"""Tensor-level wrappers over the C ABI (no autograd here; see ``functional.py``).
+
+Every wrapper takes CUDA (ROCm) tensors owned by PyTorch, passes raw device pointers plus the current stream to
+``libmyrtle_vision_hip.so`` and returns immediately (asynchronous).  PyTorch is used only for device memory and
+streams.  CPU tensors are rejected: there is no CPU compute path in this package.
+
+Precision: ``"bf16"`` = bf16 activations and weights on MFMA with fp32 accumulation and an fp32 residual stream
+(the benchmark configuration); ``"fp32"`` = every contraction in fp32 FMA chains (exact-parity mode).
+"""
+import weakref
+
+import torch
+
+from . import lib as _l
+from .lib import EPI_DGELU, EPI_EMBED, EPI_GELU, EPI_NONE, EPI_RESIDUAL, MV_BF16, MV_F32, check, lib
+
+__all__ = ["EPI_NONE", "EPI_GELU", "EPI_RESIDUAL", "EPI_DGELU", "EPI_EMBED"]
+
+_DT = {torch.float32: MV_F32, torch.bfloat16: MV_BF16}
+
+
+def act_dtype(prec: str):
+    if prec == "bf16":
+        return torch.bfloat16
+    if prec == "fp32":
+        return torch.float32
+    raise ValueError(f"unknown precision {prec!r} (expected 'bf16' or 'fp32')")
+
+
+def require_cuda(*tensors):
+    for t in tensors:
+        if t is not None and not t.is_cuda:
+            raise RuntimeError(
+                "myrtle_vision computes only through its HIP kernels on an MI355X: got a CPU tensor "
+                "(there is no CPU fallback; move the model and inputs to 'cuda')")
+
+
+def _s():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _p(t):
+    return None if t is None else t.data_ptr()
+
+
+def pad8(n: int) -> int:
+    return (n + 7) & ~7
+
+
+_workspaces = {}
+
+
+def workspace(nbytes: int, device) -> torch.Tensor:
+    """Grow-only scratch buffer per (device, stream): ops on one stream execute in order, so they can share it."""
+    key = (device.index, _s())
+    w = _workspaces.get(key)
+    if w is None or w.numel() < nbytes:
+        w = torch.empty(max(nbytes, 1 << 20), dtype=torch.uint8, device=device)
+        _workspaces[key] = w
+    return w
+
+
+# ------------------------------------------------------------------------------------------------------------
+# weights prepared for the MFMA path
+# ------------------------------------------------------------------------------------------------------------
+class PreparedWeight:
+    """bf16 copies of one nn.Linear weight [N_out, K_in]: ``w`` [N_out, pad8(K_in)] for the forward product and
+    ``wt`` [K_in, pad8(N_out)] (transposed) for the input-gradient product; pads are zero."""
+
+    __slots__ = ("w", "wt", "ldw", "ldt", "n_out", "k_in", "version", "ptr")
+
+
+_prepared = {}   # id(parameter) -> PreparedWeight (identity-keyed: tensors define == elementwise); entries die with the tensor
+
+
+def prepared_weight(weight: torch.Tensor) -> PreparedWeight:
+    """Cached bf16 / transposed-bf16 copies, refreshed when the parameter changed (``_version`` or storage)."""
+    key = id(weight)
+    pw = _prepared.get(key)
+    if pw is not None and pw.version == weight._version and pw.ptr == weight.data_ptr():
+        return pw
+    require_cuda(weight)
+    n_out, k_in = weight.shape
+    if pw is None or pw.n_out != n_out or pw.k_in != k_in or pw.w.device != weight.device:
+        pw = PreparedWeight()
+        pw.n_out, pw.k_in = n_out, k_in
+        pw.ldw, pw.ldt = pad8(k_in), pad8(n_out)
+        pw.w = torch.empty(n_out, pw.ldw, dtype=torch.bfloat16, device=weight.device)
+        pw.wt = torch.empty(k_in, pw.ldt, dtype=torch.bfloat16, device=weight.device)
+        if key not in _prepared:
+            weakref.finalize(weight, _prepared.pop, key, None)
+        _prepared[key] = pw
+    wd = weight.detach()
+    if not wd.is_contiguous():
+        wd = wd.contiguous()
+    check(lib().mv_weight_prep(_p(wd), _p(pw.w), pw.ldw, _p(pw.wt), pw.ldt, n_out, k_in, _s()), "weight_prep",
+          R=n_out, C=k_in)
+    pw.version, pw.ptr = weight._version, weight.data_ptr()
+    return pw
+
+
+# ------------------------------------------------------------------------------------------------------------
+# LayerNorm
+# ------------------------------------------------------------------------------------------------------------
+def layernorm_fwd(x, ldx, rows, dim, gamma, beta, out_dtype, eps=1e-5):
+    """x: fp32 tensor whose data_ptr is row 0; rows are ``ldx`` elements apart.  -> (y [rows, dim], mean, rstd)"""
+    require_cuda(x, gamma, beta)
+    y = torch.empty(rows, dim, dtype=out_dtype, device=x.device)
+    mean = torch.empty(rows, dtype=torch.float32, device=x.device)
+    rstd = torch.empty(rows, dtype=torch.float32, device=x.device)
+    check(lib().mv_layernorm_fwd(_p(x), ldx, _p(gamma), _p(beta), _p(y), _DT[out_dtype], _p(mean), _p(rstd), rows, dim,
+                                 eps, _s()), "layernorm_fwd", rows=rows, dim=dim, ldx=ldx)
+    return y, mean, rstd
+
+
+def layernorm_bwd(dy, x, ldx, gamma, mean, rstd, dx_add, dx, lddx, rows, dim):
+    """Writes dx (fp32 rows ``lddx`` apart; ``dx_add`` added if given, same layout) -> (dgamma, dbeta)."""
+    require_cuda(dy, x, dx)
+    dgamma = torch.empty(dim, dtype=torch.float32, device=x.device)
+    dbeta = torch.empty(dim, dtype=torch.float32, device=x.device)
+    nbytes = lib().mv_layernorm_bwd_workspace_bytes(rows, dim)
+    ws = workspace(nbytes, x.device)
+    check(lib().mv_layernorm_bwd(_p(dy), _DT[dy.dtype], _p(x), ldx, _p(gamma), _p(mean), _p(rstd), _p(dx_add), _p(dx),
+                                 lddx, _p(dgamma), _p(dbeta), 0, _p(ws), ws.numel(), rows, dim, _s()),
+          "layernorm_bwd", rows=rows, dim=dim)
+    return dgamma, dbeta
+
+
+# ------------------------------------------------------------------------------------------------------------
+# contractions.  Logical shapes: x [M, K], W [N, K] (nn.Linear layout), y [M, N]
+# ------------------------------------------------------------------------------------------------------------
+def linear_fwd(x, M, K, weight, bias, out, ldc, *, lda=None, epi=EPI_NONE, aux=None, ld_aux=0, aux_i=0, out2=None,
+               ld_out2=0):
+    """out[M, N] (+epilogue) = x[M, K] @ weight[N, K]^T + bias.  Dispatches on x.dtype (bf16 -> MFMA, fp32 -> FMA)."""
+    N = weight.shape[0]
+    lda = K if lda is None else lda
+    if x.dtype == torch.bfloat16:
+        pw = prepared_weight(weight)
+        check(lib().mv_gemm_nt_bf16(_p(x), lda, _p(pw.w), pw.ldw, _p(out), ldc, _DT[out.dtype], M, N, K, _p(bias), epi,
+                                    _p(aux), ld_aux, aux_i, _p(out2), ld_out2, _s()),
+              "gemm_nt_bf16", M=M, N=N, K=K, epi=epi)
+    else:
+        w = weight.detach()
+        check(lib().mv_gemm_f32(_p(x), lda, 1, 0, 0, _p(w), 1, w.stride(0), 0, 0, _p(out), ldc, 1, 0, 0, M, N, K, 1, 1,
+                                1.0, 0, _p(bias), epi, _p(aux), ld_aux, aux_i, _p(out2), ld_out2, _s()),
+              "gemm_f32", M=M, N=N, K=K, epi=epi)
+    return out
+
+
+def linear_dx(dy, M, N, weight, out, ldc, *, ld_dy=None, epi=EPI_NONE, aux=None, ld_aux=0):
+    """out[M, K] = dy[M, N] @ weight[N, K]  (optionally * gelu'(aux))."""
+    K = weight.shape[1]
+    ld_dy = N if ld_dy is None else ld_dy
+    if dy.dtype == torch.bfloat16:
+        pw = prepared_weight(weight)
+        check(lib().mv_gemm_nt_bf16(_p(dy), ld_dy, _p(pw.wt), pw.ldt, _p(out), ldc, _DT[out.dtype], M, K, N, None, epi,
+                                    _p(aux), ld_aux, 0, None, 0, _s()), "gemm_nt_bf16(dx)", M=M, N=K, K=N, epi=epi)
+    else:
+        w = weight.detach()
+        check(lib().mv_gemm_f32(_p(dy), ld_dy, 1, 0, 0, _p(w), w.stride(0), 1, 0, 0, _p(out), ldc, 1, 0, 0, M, K, N, 1,
+                                1, 1.0, 0, None, epi, _p(aux), ld_aux, 0, None, 0, _s()),
+              "gemm_f32(dx)", M=M, N=K, K=N, epi=epi)
+    return out
+
+
+def linear_dw(dy, x, M, N, K, *, ld_dy=None, ldx=None, want_bias=True):
+    """dW[N, K] = dy[M, N]^T @ x[M, K] (fp32), db[N] = column sums of dy."""
+    ld_dy = N if ld_dy is None else ld_dy
+    ldx = K if ldx is None else ldx
+    dw = torch.empty(N, K, dtype=torch.float32, device=x.device)
+    db = torch.empty(N, dtype=torch.float32, device=x.device) if want_bias else None
+    if dy.dtype == torch.bfloat16:
+        nbytes = lib().mv_gemm_tn_workspace_bytes(N, K, M)
+        ws = workspace(nbytes, x.device)
+        check(lib().mv_gemm_tn_bf16(_p(dy), ld_dy, _p(x), ldx, _p(dw), K, N, K, M, 0, _p(db), _p(ws), ws.numel(), _s()),
+              "gemm_tn_bf16", M=N, N=K, Kc=M)
+    else:
+        check(lib().mv_gemm_f32(_p(dy), 1, ld_dy, 0, 0, _p(x), ldx, 1, 0, 0, _p(dw), K, 1, 0, 0, N, K, M, 1, 1, 1.0, 0,
+                                None, EPI_NONE, None, 0, 0, None, 0, _s()), "gemm_f32(dw)", M=N, N=K, K=M)
+        if want_bias:
+            colsum(dy, M, N, ld_dy, db)
+    return dw, db
+
+
+def colsum(x, rows, cols, ld, out):
+    ws = workspace(256 * cols * 4 + 1024, x.device)
+    check(lib().mv_colsum(_p(x), _DT[x.dtype], ld, _p(out), 0, rows, cols, _p(ws), ws.numel(), _s()), "colsum",
+          rows=rows, cols=cols)
+    return out
+
+
+# ------------------------------------------------------------------------------------------------------------
+# attention
+# ------------------------------------------------------------------------------------------------------------
+def attention_fused_supported(qkv_dtype, N, dim_head):
+    return qkv_dtype == torch.bfloat16 and dim_head == 64 and N <= 320
+
+
+def attention_fwd(qkv, B, N, H, scale):
+    """qkv bf16 [B, N, 3*H*64] -> (out bf16 [B, N, H*64], lse fp32 [B, H, N])"""
+    require_cuda(qkv)
+    out = torch.empty(B, N, H * 64, dtype=torch.bfloat16, device=qkv.device)
+    lse = torch.empty(B, H, N, dtype=torch.float32, device=qkv.device)
+    check(lib().mv_attention_fwd(_p(qkv), _p(out), _p(lse), B, N, H, scale, _s()), "attention_fwd", B=B, N=N, H=H)
+    return out, lse
+
+
+def attention_bwd(qkv, out, dout, lse, B, N, H, scale):
+    dqkv = torch.empty_like(qkv)
+    check(lib().mv_attention_bwd(_p(qkv), _p(out), _p(dout), _p(lse), _p(dqkv), B, N, H, scale, _s()), "attention_bwd",
+          B=B, N=N, H=H)
+    return dqkv
+
+
+def attention_probs_fp32(qkv, B, N, H, dh, scale):
+    """Materialised path (fp32): probs[B, H, N, N] = softmax(q k^T * scale).  qkv fp32 [B, N, 3, H, dh]."""
+    D = H * dh
+    scores = torch.empty(B, H, N, N, dtype=torch.float32, device=qkv.device)
+    # A = q: [m=n, k=d] strides (3D, 1), batches b: N*3D, h: dh.  B[k=d][n=j] = k[j][d]: strides (1, 3D), offset D
+    k_view = qkv.view(-1)[D:]
+    check(lib().mv_gemm_f32(_p(qkv), 3 * D, 1, N * 3 * D, dh, _p(k_view), 1, 3 * D, N * 3 * D, dh, _p(scores), N, 1,
+                            H * N * N, N * N, N, N, dh, B, H, 1.0, 0, None, EPI_NONE, None, 0, 0, None, 0, _s()),
+          "gemm_f32(qk^T)", B=B, H=H, N=N)
+    probs = torch.empty_like(scores)
+    check(lib().mv_softmax_fwd(_p(scores), _p(probs), B * H * N, N, scale, _s()), "softmax_fwd", rows=B * H * N, cols=N)
+    return probs
+
+
+def attention_pv_fp32(probs, qkv, B, N, H, dh):
+    D = H * dh
+    out = torch.empty(B, N, D, dtype=torch.float32, device=qkv.device)
+    v_view = qkv.view(-1)[2 * D:]
+    check(lib().mv_gemm_f32(_p(probs), N, 1, H * N * N, N * N, _p(v_view), 3 * D, 1, N * 3 * D, dh, _p(out), D, 1,
+                            N * D, dh, N, dh, N, B, H, 1.0, 0, None, EPI_NONE, None, 0, 0, None, 0, _s()),
+          "gemm_f32(pv)", B=B, H=H, N=N)
+    return out
+
+
+def attention_bwd_fp32(probs, qkv, dout, B, N, H, dh, scale):
+    """-> dqkv fp32 [B, N, 3, H, dh]"""
+    D = H * dh
+    dev = qkv.device
+    L = lib()
+    dqkv = torch.empty_like(qkv)
+    flat, dflat = qkv.view(-1), dqkv.view(-1)
+    k_view, v_view = flat[D:], flat[2 * D:]
+    dk_view, dv_view = dflat[D:], dflat[2 * D:]
+    bq, hq = N * 3 * D, dh            # batch strides inside qkv-shaped tensors
+    bp, hp = H * N * N, N * N         # batch strides inside [B,H,N,N]
+    bo, ho = N * D, dh                # batch strides inside [B,N,D]
+    # dP[n][j] = sum_d dO[n][d] V[j][d]
+    dP = torch.empty(B, H, N, N, dtype=torch.float32, device=dev)
+    check(L.mv_gemm_f32(_p(dout), D, 1, bo, ho, _p(v_view), 1, 3 * D, bq, hq, _p(dP), N, 1, bp, hp, N, N, dh, B, H, 1.0, 0,
+                        None, EPI_NONE, None, 0, 0, None, 0, _s()), "gemm_f32(dP)")
+    # dV[j][d] = sum_n P[n][j] dO[n][d]
+    check(L.mv_gemm_f32(_p(probs), 1, N, bp, hp, _p(dout), D, 1, bo, ho, _p(dv_view), 3 * D, 1, bq, hq, N, dh, N, B, H, 1.0,
+                        0, None, EPI_NONE, None, 0, 0, None, 0, _s()), "gemm_f32(dV)")
+    dS = torch.empty_like(dP)
+    check(L.mv_softmax_bwd(_p(probs), _p(dP), _p(dS), B * H * N, N, scale, _s()), "softmax_bwd")
+    # dQ[n][d] = sum_j dS[n][j] K[j][d]
+    check(L.mv_gemm_f32(_p(dS), N, 1, bp, hp, _p(k_view), 3 * D, 1, bq, hq, _p(dqkv), 3 * D, 1, bq, hq, N, dh, N, B, H, 1.0,
+                        0, None, EPI_NONE, None, 0, 0, None, 0, _s()), "gemm_f32(dQ)")
+    # dK[j][d] = sum_n dS[n][j] Q[n][d]
+    check(L.mv_gemm_f32(_p(dS), 1, N, bp, hp, _p(qkv), 3 * D, 1, bq, hq, _p(dk_view), 3 * D, 1, bq, hq, N, dh, N, B, H, 1.0,
+                        0, None, EPI_NONE, None, 0, 0, None, 0, _s()), "gemm_f32(dK)")
+    return dqkv
+
+
+# ------------------------------------------------------------------------------------------------------------
+# embedding assembly, casts, elementwise
+# ------------------------------------------------------------------------------------------------------------
+def patchify(img, p, out_dtype):
+    require_cuda(img)
+    B, C, H, W = img.shape
+    if img.dtype != torch.float32 or not img.is_contiguous():
+        img = img.float().contiguous()
+    out = torch.empty(B * (H // p) * (W // p), p * p * C, dtype=out_dtype, device=img.device)
+    check(lib().mv_patchify(_p(img), _p(out), _DT[out_dtype], B, C, H, W, p, _s()), "patchify", B=B, C=C, H=H, W=W, p=p)
+    return out
+
+
+def embed_cls(cls, pos, x, B, T, D):
+    check(lib().mv_embed_cls(_p(cls), _p(pos), _p(x), B, T, D, _s()), "embed_cls", B=B, T=T, D=D)
+
+
+def embed_bwd(dx, B, T, D):
+    dpos = torch.empty(T, D, dtype=torch.float32, device=dx.device)
+    dcls = torch.empty(D, dtype=torch.float32, device=dx.device)
+    check(lib().mv_embed_bwd(_p(dx), _p(dpos), _p(dcls), 0, B, T, D, _s()), "embed_bwd", B=B, T=T, D=D)
+    return dpos, dcls
+
+
+def gather_patch_rows(src, B, T, D, out_dtype):
+    out = torch.empty(B * (T - 1), D, dtype=out_dtype, device=src.device)
+    check(lib().mv_gather_patch_rows(_p(src), _p(out), _DT[out_dtype], B, T, D, _s()), "gather_patch_rows", B=B, T=T, D=D)
+    return out
+
+
+def cast(src, out_dtype):
+    require_cuda(src)
+    if src.dtype == out_dtype:
+        return src
+    out = torch.empty(src.shape, dtype=out_dtype, device=src.device)
+    check(lib().mv_cast(_p(src), _DT[src.dtype], _p(out), _DT[out_dtype], src.numel(), _s()), "cast", n=src.numel())
+    return out
+
+
+def gelu_fwd(x):
+    y = torch.empty_like(x)
+    check(lib().mv_gelu_fwd(_p(x), _p(y), _DT[x.dtype], x.numel(), _s()), "gelu_fwd", n=x.numel())
+    return y
+
+
+def gelu_bwd(x, dy):
+    dx = torch.empty_like(x)
+    check(lib().mv_gelu_bwd(_p(x), _p(dy), _p(dx), _DT[x.dtype], x.numel(), _s()), "gelu_bwd", n=x.numel())
+    return dx
+
+
+def add_f32(a, b):
+    out = torch.empty_like(a)
+    check(lib().mv_add_f32(_p(a), _p(b), _p(out), a.numel(), _s()), "add_f32", n=a.numel())
+    return out
+
+
+# ------------------------------------------------------------------------------------------------------------
+# fake quantisation
+# ------------------------------------------------------------------------------------------------------------
+def quant_float(x, exp_bits, man_bits):
+    require_cuda(x)
+    xf = x.detach().float().contiguous()
+    y = torch.empty_like(xf)
+    check(lib().mv_quant_float(_p(xf), _p(y), xf.numel(), exp_bits, man_bits, _s()), "quant_float", n=xf.numel())
+    return y
+
+
+def quant_fixed(x, wl, fl, clamp=True, symmetric=False):
+    require_cuda(x)
+    xf = x.detach().float().contiguous()
+    y = torch.empty_like(xf)
+    check(lib().mv_quant_fixed(_p(xf), _p(y), xf.numel(), wl, fl, int(clamp), int(symmetric), _s()), "quant_fixed",
+          n=xf.numel())
+    return y
+
+
+def quant_affine(x, scale, zero_point, qmin, qmax):
+    require_cuda(x)
+    xf = x.detach().float().contiguous()
+    y = torch.empty_like(xf)
+    check(lib().mv_quant_affine(_p(xf), _p(y), xf.numel(), float(scale), int(zero_point), qmin, qmax, _s()),
+          "quant_affine", n=xf.numel())
+    return y
+
+
+def minmax_update(x, state):
+    """state: fp32 [4] on device, [0]=running min, [1]=running max (init +inf/-inf)."""
+    xf = x.detach().float().contiguous()
+    check(lib().mv_minmax(_p(xf), xf.numel(), _p(state), _s()), "minmax", n=xf.numel())
+
+
+# ------------------------------------------------------------------------------------------------------------
+# loss, upsample, optimizer
+# ------------------------------------------------------------------------------------------------------------
+def cross_entropy(logits, labels, *, want_grad, grad_dtype=torch.float32, ld_dl=None, want_argmax=False):
+    """Mean CE.  logits fp32 [B, C] or [B, C, H, W]; labels int64.  -> (loss[1], dlogits|None, argmax|None)"""
+    require_cuda(logits, labels)
+    logits = logits.contiguous()
+    labels = labels.contiguous()
+    if labels.dtype != torch.int64:
+        labels = labels.long()
+    C = logits.shape[1]
+    outer = logits.shape[0]
+    inner = 1
+    for s in logits.shape[2:]:
+        inner *= s
+    loss = torch.empty(1, dtype=torch.float32, device=logits.device)
+    dl = None
+    if want_grad:
+        if inner == 1:
+            ld_dl = C if ld_dl is None else ld_dl
+            dl = torch.empty(outer, ld_dl, dtype=grad_dtype, device=logits.device)
+        else:
+            ld_dl = C
+            dl = torch.empty(logits.shape, dtype=grad_dtype, device=logits.device)
+    am = torch.empty(labels.shape, dtype=torch.int64, device=logits.device) if want_argmax else None
+    check(lib().mv_cross_entropy(_p(logits), _p(labels), _p(loss), _p(dl), _DT[grad_dtype], ld_dl or C, _p(am), outer, C,
+                                 inner, 1.0, _s()), "cross_entropy", outer=outer, C=C, inner=inner)
+    return loss, dl, am
+
+
+def upsample_bilinear_fwd(small, sb, sc, sp, B, C, h, w, H, W):
+    big = torch.empty(B, C, H, W, dtype=torch.float32, device=small.device)
+    check(lib().mv_upsample_bilinear_fwd(_p(small), sb, sc, sp, _p(big), B, C, h, w, H, W, _s()), "upsample_fwd",
+          B=B, C=C, h=h, w=w, H=H, W=W)
+    return big
+
+
+def upsample_bilinear_bwd(dbig, dsmall, sb, sc, sp, B, C, h, w, H, W):
+    check(lib().mv_upsample_bilinear_bwd(_p(dbig), _p(dsmall), sb, sc, sp, B, C, h, w, H, W, _s()), "upsample_bwd",
+          B=B, C=C, h=h, w=w, H=H, W=W)
+    return dsmall
+
+
+def adamw_step(p, g, m, v, *, lr, beta1, beta2, eps, weight_decay, step, grad_scale=1.0):
+    """In-place AdamW on flat fp32 tensors (torch.optim.AdamW semantics)."""
+    require_cuda(p, g, m, v)
+    bc1 = 1.0 - beta1 ** step
+    bc2 = 1.0 - beta2 ** step
+    check(lib().mv_adamw(_p(p), _p(g), _p(m), _p(v), p.numel(), lr, beta1, beta2, eps, weight_decay, bc1, bc2,
+                         grad_scale, _s()), "adamw", n=p.numel())

@@ -1,0 +1,409 @@
+"""Vision Transformer -- MI355X-native drop-in for the reference ``src/myrtle_vision/models/vit.py``.
+
+Same classes (``Residual, PreNorm, FeedForward, Attention, Transformer, ViT, ClassificationDecoder,
+SegmentationDecoder, DetectionDecoder``), constructor kwargs, attribute names (hence state-dict keys and the
+checkpoint wire format), the ``attn_output`` hook point, ``.convert()`` and ``.quantizer`` as the reference; the
+arithmetic runs in the HIP kernels of ``csrc/`` through ``myrtle_vision.hip.functional``.
+
+One extension: ``ViT(..., precision="bf16" | "fp32")`` (default: env ``MYRTLE_VISION_PRECISION`` or ``"bf16"``).
+``bf16`` is the benchmark configuration (MFMA, fp32 accumulate, fp32 residual stream); ``fp32`` is the
+exact-parity mode.  Any fake-quantised ``q_format`` runs in ``fp32`` (its values are fp32 by definition,
+utils/quantize.py:84).
+
+There is no CPU compute path: ``forward`` on CPU tensors raises.
+"""
+import os
+from contextlib import nullcontext
+from typing import Optional, Union
+
+import torch
+import torch.autograd.profiler as profiler
+import torch.nn.functional as TF
+from torch import nn
+
+from myrtle_vision.hip import functional as F
+from myrtle_vision.hip import ops
+from myrtle_vision.utils.quantize import DeQuantStub, FloatFunctional, ModelQuantizer, QFormat, QuantStub
+
+MIN_NUM_PATCHES = 16  # reference vit.py:14
+
+
+def _default_precision() -> str:
+    return os.environ.get("MYRTLE_VISION_PRECISION", "bf16")
+
+
+class _HipModule:
+    """Mixin: the precision the HIP kernels run in (set for a whole model by ``ViT.set_precision``)."""
+
+    precision = "bf16"
+
+    @property
+    def act_dtype(self):
+        return ops.act_dtype(self.precision)
+
+
+# ---- leaf modules: torch parameter containers whose forward runs on the HIP kernels ----------------------
+class Linear(nn.Linear, _HipModule):
+    """nn.Linear parameters/initialisation; forward = bf16-MFMA or fp32 HIP GEMM chosen by the input dtype."""
+
+    def forward(self, x):
+        ops.require_cuda(x, self.weight)
+        if x.dtype != self.act_dtype:
+            x = F.cast(x, self.act_dtype)
+        return F.linear(x, self.weight, self.bias)
+
+
+class LayerNorm(nn.LayerNorm, _HipModule):
+    def forward(self, x):
+        ops.require_cuda(x, self.weight)
+        return F.layer_norm(x, self.weight, self.bias, self.act_dtype, self.eps)
+
+
+class GELU(nn.GELU, _HipModule):
+    def forward(self, x):
+        ops.require_cuda(x)
+        return F.gelu(x)
+
+
+class Dropout(nn.Dropout):
+    """Every shipped config uses p = 0 (train_configs/*.json); p > 0 in training mode is not implemented."""
+
+    def forward(self, x):
+        if self.p == 0.0 or not self.training:
+            return x
+        raise NotImplementedError("dropout with p > 0 is not implemented on the HIP path (reference configs use 0.0)")
+
+
+def _plain(module, cls):
+    """True if ``module`` is exactly our leaf class with no forward hooks (i.e. safe to fuse through)."""
+    return type(module) is cls and not module._forward_hooks and not module._forward_pre_hooks
+
+
+# ---- reference vit.py:17-27 ---------------------------------------------------------------------------------
+class Residual(nn.Module):
+    def __init__(self, fn: nn.Module):
+        super().__init__()
+        self.fn = fn
+        self.res_add = FloatFunctional()
+
+    def forward(self, x: torch.Tensor):
+        fused = self._fused(x)
+        if fused is not None:
+            return fused
+        return self.res_add.add(self.fn(x), x)
+
+    def _fused(self, x):
+        """One HIP-fused call for Residual(PreNorm(Attention | FeedForward)) when nothing observes the insides."""
+        pn = self.fn
+        if not (type(pn) is PreNorm and _plain(pn.norm, LayerNorm) and self.res_add.plain()):
+            return None
+        if pn._forward_hooks or pn._forward_pre_hooks or x.dim() != 3:
+            return None
+        ops.require_cuda(x)
+        inner = pn.fn
+        prec = pn.norm.precision
+        x = x.float()
+        if type(inner) is Attention and inner.fusable():
+            lin_o = inner.to_out[0]
+            return F.attn_block(x, pn.norm.weight, pn.norm.bias, inner.to_qkv.weight, inner.to_qkv.bias, lin_o.weight,
+                                lin_o.bias, inner.heads, inner.scale, prec)
+        if type(inner) is FeedForward and inner.fusable():
+            fc1, fc2 = inner.net[0], inner.net[3]
+            return F.mlp_block(x, pn.norm.weight, pn.norm.bias, fc1.weight, fc1.bias, fc2.weight, fc2.bias, prec)
+        return None
+
+
+# ---- reference vit.py:30-41 ---------------------------------------------------------------------------------
+class PreNorm(nn.Module):
+    def __init__(self, dim: int, fn: nn.Module):
+        super().__init__()
+        self.norm = LayerNorm(dim)
+        self.fn = fn
+
+    def forward(self, x: torch.Tensor):
+        return self.fn(self.norm(x))
+
+
+# ---- reference vit.py:44-56 ---------------------------------------------------------------------------------
+class FeedForward(nn.Module):
+    def __init__(self, dim: int, hidden_dim: int, dropout: float = 0.0):
+        super().__init__()
+        self.net = nn.Sequential(
+            Linear(dim, hidden_dim),
+            GELU(),
+            Dropout(dropout),
+            Linear(hidden_dim, dim),
+            Dropout(dropout),
+        )
+
+    def fusable(self):
+        n = self.net
+        return (not self._forward_hooks and not n._forward_hooks and _plain(n[0], Linear) and _plain(n[1], GELU)
+                and _plain(n[3], Linear) and all(type(n[i]) is Dropout and (n[i].p == 0.0 or not n[i].training)
+                                                 and not n[i]._forward_hooks for i in (2, 4)))
+
+    def forward(self, x: torch.Tensor):
+        return self.net(x)
+
+
+# ---- reference vit.py:59-99 ---------------------------------------------------------------------------------
+class Attention(nn.Module):
+    def __init__(self, dim: int, heads: int = 8, dim_head: int = 64, dropout: float = 0.0):
+        super().__init__()
+        inner_dim = dim_head * heads
+        self.heads = heads
+        self.scale = dim_head ** -0.5
+
+        self.to_qkv = Linear(dim, inner_dim * 3, bias=True)
+        self.to_out = nn.Sequential(
+            Linear(inner_dim, dim),
+            Dropout(dropout),
+        )
+
+        self.dequant_qkv = DeQuantStub()
+        self.quant_out = QuantStub()
+        # Identity layer kept so that a forward hook can collect attention maps (reference vit.py:80-82)
+        self.attn_output = nn.Identity()
+
+    def fusable(self):
+        d = self.to_out[1]
+        return (not self._forward_hooks and _plain(self.to_qkv, Linear) and _plain(self.to_out[0], Linear)
+                and not self.to_out._forward_hooks and type(d) is Dropout and (d.p == 0.0 or not d.training)
+                and not self.attn_output._forward_hooks and self.dequant_qkv.plain() and self.quant_out.plain())
+
+    def forward(self, x: torch.Tensor):
+        # reference vit.py:85-99; the reshape/permute/transpose of the reference are index arithmetic inside the
+        # attention kernels (qkv stays [B, N, 3, H, dh])
+        qkv = self.dequant_qkv(self.to_qkv(x))
+        hook = self.attn_output if self.attn_output._forward_hooks else None
+        out = F.attention_core(qkv, self.heads, self.scale, hook)
+        out = self.quant_out(out)
+        out = self.to_out(out)
+        return out
+
+
+# ---- reference vit.py:102-161 -------------------------------------------------------------------------------
+class Transformer(nn.Module):
+    def __init__(self, dim: int, depth: int, heads: int, dim_head: int, mlp_dim: int, dropout: float, profile: bool):
+        super().__init__()
+        if profile:
+            self.cm_attention = profiler.record_function("transformer:attention")
+            self.cm_feedforward = profiler.record_function("transformer:feedforward")
+        else:
+            self.cm_attention = nullcontext()
+            self.cm_feedforward = nullcontext()
+
+        self.layers = nn.ModuleList([])
+        for _ in range(depth):
+            self.layers.append(
+                nn.Sequential(
+                    Residual(PreNorm(dim, Attention(dim, heads=heads, dim_head=dim_head, dropout=dropout))),
+                    Residual(PreNorm(dim, FeedForward(dim, mlp_dim, dropout=dropout))),
+                )
+            )
+
+    def forward(self, x: torch.Tensor):
+        for transformer_block in self.layers:
+            with self.cm_attention:
+                x = transformer_block[0](x)
+            with self.cm_feedforward:
+                x = transformer_block[1](x)
+        return x
+
+
+# ---- reference vit.py:164-323 -------------------------------------------------------------------------------
+class ViT(nn.Module):
+    def __init__(
+        self,
+        *,
+        decoder: str,
+        image_size: int,
+        patch_size: int,
+        num_classes: int,
+        dim: int,
+        depth: int,
+        heads: int,
+        mlp_dim: int,
+        pool: str = "cls",
+        channels: int = 3,
+        dim_head: int = 64,
+        dropout: float = 0.0,
+        emb_dropout: float = 0.0,
+        num_det_tokens: int = 100,
+        profile: bool = False,
+        q_format: Optional[Union[str, QFormat]] = None,
+        precision: Optional[str] = None,
+    ):
+        super().__init__()
+        assert image_size % patch_size == 0, "Image dimensions must be divisible by the patch size."
+        num_patches = (image_size // patch_size) ** 2
+        patch_dim = channels * patch_size ** 2
+        assert num_patches > MIN_NUM_PATCHES, (
+            f"your number of patches ({num_patches}) is way too small for "
+            f"attention to be effective (at least 16). Try decreasing your "
+            f"patch size"
+        )
+        assert decoder in {
+            "classification",
+            "segmentation",
+            "detection",
+        }, "decoder must be either classification, segmentation, or detection"
+        if heads * dim_head != dim:
+            # the reference reshapes with c_dim // heads (vit.py:88), so it only works when heads*dim_head == dim
+            raise ValueError(f"heads * dim_head must equal dim (got {heads} * {dim_head} != {dim})")
+        self.patch_size = patch_size
+
+        if profile:
+            self.cm_patch_to_embedding = profiler.record_function("patch_to_embedding")
+            self.cm_transformer = profiler.record_function("transformer")
+            self.cm_mlp_head = profiler.record_function("mlp_head")
+        else:
+            self.cm_patch_to_embedding = nullcontext()
+            self.cm_transformer = nullcontext()
+            self.cm_mlp_head = nullcontext()
+
+        # parameters in the reference's registration order (vit.py:218-222): state-dict order is part of the format
+        self.pos_embedding = nn.Parameter(torch.randn(1, 14 * 14 + 1, dim))
+        self.pos_embedding_det = nn.Parameter(torch.randn(1, num_det_tokens, dim))
+        self.patch_to_embedding = Linear(patch_dim, dim)
+        self.cls_token = nn.Parameter(torch.randn(1, 1, dim))
+        self.det_tokens = nn.Parameter(torch.randn(1, num_det_tokens, dim))
+        self.dropout = Dropout(emb_dropout)
+
+        self.transformer = Transformer(dim, depth, heads, dim_head, mlp_dim, dropout, profile)
+
+        if decoder == "classification":
+            self.decoder = ClassificationDecoder(dim, num_classes)
+        elif decoder == "segmentation":
+            self.decoder = SegmentationDecoder(dim, num_classes, image_size, patch_size)
+        elif decoder == "detection":
+            self.decoder = DetectionDecoder(dim, num_classes, num_det_tokens)
+
+        self.quant_img = QuantStub()
+        self.quant_pos_embedding = QuantStub()
+        self.quant_cls_token = QuantStub()
+        self.quant_det_tokens = QuantStub()
+        self.dequant_output = DeQuantStub()
+        self.cls_token_cat = FloatFunctional()
+        self.pos_embedding_add = FloatFunctional()
+        self.pos_embedding_cat = FloatFunctional()
+        self.set_precision(precision if precision is not None else _default_precision())
+        self.quantizer = ModelQuantizer(self)
+        self.quantizer.prepare_qat(q_format if q_format is not None else QFormat.FP32)
+
+    # -- precision plumbing ------------------------------------------------------------------------------
+    def set_precision(self, precision: str):
+        ops.act_dtype(precision)  # validates
+        self.precision = precision
+        for m in self.modules():
+            if isinstance(m, _HipModule):
+                m.precision = precision
+        return self
+
+    # -- positional embedding (reference vit.py:292-302) ---------------------------------------------------
+    def _pos_embedding(self, gh: int, gw: int) -> torch.Tensor:
+        """cls slot + 14x14 grid bicubically resized to (gh, gw).  At 224^2 the resize is the identity, and the
+        parameter is used as is; otherwise the tiny (1, D, 14, 14) resize is cold glue on torch."""
+        if gh == 14 and gw == 14:
+            return self.pos_embedding
+        cls_pos, grid = self.pos_embedding[:, 0:1, :], self.pos_embedding[:, 1:, :]
+        grid = grid.transpose(1, 2).reshape(1, -1, 14, 14)
+        grid = TF.interpolate(grid, size=(gh, gw), mode="bicubic", align_corners=False)
+        grid = grid.reshape(1, -1, gh * gw).transpose(1, 2)
+        return torch.cat((cls_pos, grid), dim=1)
+
+    def _embed_fusable(self):
+        return (_plain(self.patch_to_embedding, Linear) and self.quant_img.plain() and self.quant_cls_token.plain()
+                and self.quant_pos_embedding.plain() and self.cls_token_cat.plain() and self.pos_embedding_add.plain()
+                and self.pos_embedding_cat.plain())
+
+    def forward(self, img: torch.Tensor):
+        ops.require_cuda(img, self.pos_embedding)
+        b_dim, c_dim, h_dim, w_dim = img.shape
+        p = self.patch_size
+        gh, gw = h_dim // p, w_dim // p
+
+        if self._embed_fusable():
+            with self.cm_patch_to_embedding:
+                x = F.patch_embed(img, self.patch_to_embedding.weight, self.patch_to_embedding.bias, self.cls_token,
+                                  self._pos_embedding(gh, gw), p, self.precision)
+        else:
+            x = self._embed_unfused(img, gh, gw)
+        x = self.dropout(x)
+
+        with self.cm_transformer:
+            x = self.transformer(x)
+
+        with self.cm_mlp_head:
+            output = self.decoder(x)
+        output = self.dequant_output(output)
+        return output
+
+    def _embed_unfused(self, img, gh, gw):
+        """reference vit.py:271-311 module by module (used when quantisers sit between the steps)."""
+        b_dim = img.shape[0]
+        p = self.patch_size
+        x = ops.patchify(img, p, torch.float32).view(b_dim, gh * gw, -1)
+        x = self.quant_img(x)
+        with self.cm_patch_to_embedding:
+            x = F.cast(self.patch_to_embedding(x), torch.float32)
+        cls_tokens = self.quant_cls_token(self.cls_token.repeat(b_dim, 1, 1))
+        # det tokens are built and never used for these decoders (reference vit.py:285-290)
+        x = self.cls_token_cat.cat((cls_tokens, x), dim=1)
+        pos = self.pos_embedding_cat.post(self._pos_embedding(gh, gw))   # the reference's cat of (cls slot, grid)
+        return self.pos_embedding_add.add(x, self.quant_pos_embedding(pos.repeat(b_dim, 1, 1)))
+
+    def convert(self) -> None:
+        self.quantizer.convert()
+
+
+# ---- reference vit.py:325-342 -------------------------------------------------------------------------------
+class ClassificationDecoder(nn.Module):
+    def __init__(self, dim, num_classes):
+        super().__init__()
+        self.norm = LayerNorm(dim)
+        self.linear = Linear(dim, num_classes)
+
+    def forward(self, x: torch.Tensor):
+        if _plain(self.norm, LayerNorm) and _plain(self.linear, Linear) and x.dim() == 3:
+            ops.require_cuda(x)
+            return F.cls_head(x.float(), self.norm.weight, self.norm.bias, self.linear.weight, self.linear.bias,
+                              self.norm.precision)
+        x = x[:, 0]
+        x = self.norm(x)
+        x = self.linear(x)
+        return F.cast(x, torch.float32)
+
+
+# ---- reference vit.py:344-374 -------------------------------------------------------------------------------
+class SegmentationDecoder(nn.Module):
+    def __init__(self, dim, num_classes, image_size, patch_size):
+        super().__init__()
+        self.norm = LayerNorm(dim)
+        self.linear = Linear(dim, num_classes)
+        self.upsample = nn.Upsample(size=image_size, mode="bilinear")
+        self.image_size = image_size
+        self.image_size_in_patches = image_size // patch_size
+
+    def forward(self, x: torch.Tensor):
+        g = self.image_size_in_patches
+        if not (_plain(self.norm, LayerNorm) and _plain(self.linear, Linear)):
+            raise NotImplementedError("fake-quantised segmentation decoder is not implemented on the HIP path")
+        if x.shape[1] - 1 != g * g:
+            raise ValueError(f"expected {g * g} patch tokens for image_size {self.image_size}, got {x.shape[1] - 1}")
+        ops.require_cuda(x)
+        return F.seg_head(x.float(), self.norm.weight, self.norm.bias, self.linear.weight, self.linear.bias, g,
+                          self.image_size, self.norm.precision)
+
+
+# ---- reference vit.py:376-396 (detection is out of scope for the HIP path: SURVEY section 2 row 16) --------
+class DetectionDecoder(nn.Module):
+    def __init__(self, in_dim, num_classes, num_det_tokens):
+        super().__init__()
+        self.class_embed = Linear(in_dim, num_classes + 1)
+        self.bbox_embed = Linear(in_dim, 4)
+        self.num_det_tokens = num_det_tokens
+
+    def forward(self, x: torch.Tensor):
+        raise NotImplementedError(
+            "the detection decoder is outside the MI355X hot-path scope (classification + segmentation only)")

@@ -1,0 +1,384 @@
+"""Fake-quantisation plumbing -- drop-in for the reference ``src/myrtle_vision/utils/quantize.py``.
+
+Same public names (``QFormat, NumberFormat, Quantizer, QuantizerFunction, QLinear, QLayerNorm, ModelQuantizer``)
+and the same placement of quantisers as the reference's ``prepare_qat`` produces (pinned by the golden site
+lists in ``tests/golden/micro_cls_fp16_*.json``).  The qtorch CUDA quantisers (utils/quantize.py:46-72) are
+replaced by ONE fused HIP quant/dequant kernel family (``mv_quant_float / mv_quant_fixed / mv_quant_affine``); the
+``torch.quantization`` machinery (QuantStub/prepare_qat/convert) is replaced by small explicit modules because its
+converted int8 path only exists for x86/ARM CPUs.
+
+Rounding semantics = qtorch 0.3.0 nearest rounding as restated in ``oracle/quant_oracle.py`` (parity unpinned:
+qtorch is not available offline).
+"""
+import enum
+
+import torch
+from torch import nn
+
+from myrtle_vision.hip import functional as F
+from myrtle_vision.hip import ops
+
+
+class QFormat(enum.IntEnum):
+    """Quantization formats supported by ViT (reference utils/quantize.py:13-20)."""
+
+    FP32 = 0
+    PyTorchINT8 = 1
+    FP16_16 = 2
+    FP16_32 = 3
+    TF32 = 4
+
+
+class _FloatQ(nn.Module):
+    def __init__(self, exp, man):
+        super().__init__()
+        self.exp, self.man = exp, man
+
+    def forward(self, x):
+        return ops.quant_float(x, self.exp, self.man)
+
+
+class _FixedQ(nn.Module):
+    def __init__(self, wl, fl):
+        super().__init__()
+        self.wl, self.fl = wl, fl
+
+    def forward(self, x):
+        return ops.quant_fixed(x, self.wl, self.fl)
+
+
+class NumberFormat(enum.Enum):
+    """reference utils/quantize.py:23-74"""
+
+    SymmetricInt8 = enum.auto()
+    AsymmetricInt8 = enum.auto()
+    HalfPrecisionFloat = enum.auto()
+    SinglePrecisionFloat = enum.auto()
+    TensorFloat32 = enum.auto()
+    FixedPoint11Integral2 = enum.auto()
+    FixedPoint11Integral3 = enum.auto()
+    FixedPoint11Integral4 = enum.auto()
+
+    @staticmethod
+    def quantizer(number_format):
+        """Module mapping an fp32 tensor to an fp32 tensor constrained to ``number_format`` (HIP kernel)."""
+        if number_format == NumberFormat.HalfPrecisionFloat:
+            return _FloatQ(5, 10)
+        elif number_format == NumberFormat.SinglePrecisionFloat:
+            return nn.Identity()
+        elif number_format == NumberFormat.TensorFloat32:
+            return _FloatQ(8, 10)
+        elif number_format == NumberFormat.FixedPoint11Integral2:
+            return _FixedQ(11, 9)
+        elif number_format == NumberFormat.FixedPoint11Integral3:
+            return _FixedQ(11, 8)
+        elif number_format == NumberFormat.FixedPoint11Integral4:
+            return _FixedQ(11, 7)
+        raise NotImplementedError(number_format)
+
+
+class QuantizerFunction(torch.autograd.Function):
+    """Fake quantisation with a straight-through gradient (reference utils/quantize.py:77-89)."""
+
+    @staticmethod
+    def forward(ctx, X, quant):
+        dtype = X.dtype
+        assert X.is_floating_point()
+        return quant(X.data.float()).to(dtype)
+
+    @staticmethod
+    def backward(ctx, grad_output):
+        return grad_output, None
+
+
+class Quantizer(nn.Module):
+    """reference utils/quantize.py:92-118"""
+
+    def __init__(self, number_format):
+        super().__init__()
+        self._number_format = number_format
+        self._quant = NumberFormat.quantizer(number_format)
+
+    @property
+    def is_identity(self):
+        return isinstance(self._quant, nn.Identity)
+
+    def get_qparams(self):
+        raise NotImplementedError()
+
+    def forward(self, X):
+        if self.is_identity:
+            return X
+        return QuantizerFunction.apply(X, self._quant)
+
+    def forward_pre_hook(self, module, input):
+        assert len(input) == 1, f"{self.__class__.__name__} only supports single tensor input"
+        return self(input[0])
+
+    def __repr__(self):
+        return self.__class__.__name__ + f"({self._number_format})"
+
+
+# ---- explicit stand-ins for torch.quantization stubs ---------------------------------------------------------
+class QuantStub(nn.Module):
+    """Identity until ``prepare_qat`` attaches an ``activation_post_process`` (a Quantizer or an observer)."""
+
+    def __init__(self, activation_post_process=None):
+        super().__init__()
+        self.activation_post_process = activation_post_process
+
+    def plain(self):
+        return self.activation_post_process is None and not self._forward_hooks
+
+    def forward(self, x):
+        if self.activation_post_process is None:
+            return x
+        return self.activation_post_process(x)
+
+
+class DeQuantStub(nn.Module):
+    def plain(self):
+        return not self._forward_hooks
+
+    def forward(self, x):
+        return x
+
+
+class FloatFunctional(nn.Module):
+    """``torch.nn.quantized.FloatFunctional`` stand-in (reference vit.py:24,259-261): add / cat whose result passes
+    through ``activation_post_process``."""
+
+    def __init__(self):
+        super().__init__()
+        self.activation_post_process = None
+
+    def plain(self):
+        return self.activation_post_process is None and not self._forward_hooks
+
+    def post(self, r):
+        return r if self.activation_post_process is None else self.activation_post_process(r)
+
+    def add(self, a, b):
+        return self.post(F.add(a, b))
+
+    def cat(self, tensors, dim=0):
+        # cold glue: only reached on the unfused (fake-quant) embedding path
+        return self.post(torch.cat([t.float() for t in tensors], dim=dim))
+
+
+class MinMaxObserver(nn.Module):
+    """Running per-tensor min/max on the HIP reduction kernel (MinMaxObserver of utils/quantize.py:242-249)."""
+
+    def __init__(self, symmetric=False, qmin=0, qmax=255):
+        super().__init__()
+        self.symmetric, self.qmin, self.qmax = symmetric, qmin, qmax
+        self.register_buffer("state", torch.tensor([float("inf"), float("-inf"), 0.0, 0.0]))
+        self.frozen = None          # (scale, zero_point) once converted
+
+    def forward(self, x):
+        if self.frozen is not None:
+            s, z = self.frozen
+            return QuantizerFunction.apply(x, lambda t: ops.quant_affine(t, s, z, self.qmin, self.qmax))
+        ops.minmax_update(x, self.state)
+        return x
+
+    def calculate_qparams(self):
+        mn, mx = (float(v) for v in self.state[:2].tolist())
+        mn, mx = min(mn, 0.0), max(mx, 0.0)
+        eps = torch.finfo(torch.float32).eps
+        if self.symmetric:
+            scale = max(max(-mn, mx) / ((self.qmax - self.qmin) / 2), eps)
+            zp = 0 if self.qmin < 0 else 128
+        else:
+            scale = max((mx - mn) / float(self.qmax - self.qmin), eps)
+            zp = int(min(max(self.qmin - round(mn / scale), self.qmin), self.qmax))
+        return scale, zp
+
+    def freeze(self):
+        self.frozen = self.calculate_qparams()
+
+
+# ---- quantised leaf modules -----------------------------------------------------------------------------------
+def _hip_linear(x, weight, bias, act_dtype):
+    if x.dtype != act_dtype:
+        x = F.cast(x, act_dtype)
+    return F.linear(x, weight, bias)
+
+
+class QATLinear(nn.Linear):
+    """Linear whose weight passes through ``weight_fake_quant`` on every forward and whose output passes through
+    ``activation_post_process`` (what torch's prepare_qat turns nn.Linear into: reference SURVEY 3.5)."""
+
+    precision = "fp32"
+    weight_fake_quant = None
+    activation_post_process = None
+
+    def forward(self, x):
+        w = self.weight_fake_quant(self.weight) if self.weight_fake_quant is not None else self.weight
+        y = _hip_linear(x, w, self.bias, ops.act_dtype(self.precision))
+        return y if self.activation_post_process is None else self.activation_post_process(y)
+
+
+class QLinear(nn.Linear):
+    """reference utils/quantize.py:121-143: weights already quantised once (``from_float``)."""
+
+    precision = "fp32"
+
+    def __init__(self, *args, activation_post_process=None, **kwargs):
+        super().__init__(*args, **kwargs)
+        self.activation_post_process = activation_post_process
+
+    def forward(self, input):
+        output = _hip_linear(input, self.weight, self.bias, ops.act_dtype(self.precision))
+        if self.activation_post_process is not None:
+            output = self.activation_post_process(output)
+        return output
+
+    @classmethod
+    def from_float(cls, mod, qconfig=None):
+        mod.weight.data = mod.weight_fake_quant(mod.weight).data if mod.weight_fake_quant is not None else mod.weight.data
+        mod.__class__ = cls
+        mod.weight_fake_quant = None
+        mod.activation_post_process = None
+        return mod
+
+
+class QLayerNorm(nn.LayerNorm):
+    """reference utils/quantize.py:146-166"""
+
+    precision = "fp32"
+
+    def forward(self, input):
+        return F.layer_norm(input, self.weight, self.bias, ops.act_dtype(self.precision), self.eps)
+
+    @classmethod
+    def from_float(cls, mod):
+        wq = getattr(mod, "weight_quantizer", None)
+        if wq is not None:
+            mod.weight.data = wq(mod.weight).data
+        mod.__class__ = cls
+        mod.activation_post_process = None
+        return mod
+
+
+class _QATLayerNorm(nn.LayerNorm):
+    """LayerNorm in prepared mode: output passes through activation_post_process (FP16_16 only); the weight is
+    quantised only by convert() (reference QLayerNorm.from_float)."""
+
+    precision = "fp32"
+    activation_post_process = None
+    weight_quantizer = None
+
+    def forward(self, x):
+        y = F.layer_norm(x, self.weight, self.bias, ops.act_dtype(self.precision), self.eps)
+        return y if self.activation_post_process is None else self.activation_post_process(y)
+
+
+class _QATGELU(nn.GELU):
+    activation_post_process = None
+
+    def forward(self, x):
+        return F.gelu(x)
+
+
+class ModelQuantizer:
+    """reference utils/quantize.py:187-348"""
+
+    def __init__(self, model):
+        self.model = model
+
+    def prepare_qat(self, q_format):
+        """Make the model simulate `q_format`."""
+        if hasattr(self, "q_format") and self.q_format != QFormat.FP32:
+            raise ValueError("model already quantized")
+        if isinstance(q_format, str):
+            q_format = QFormat[q_format]
+
+        if q_format == QFormat.FP32:
+            pass
+        elif q_format == QFormat.PyTorchINT8:
+            self._prepare_qat_pytorch_int8()
+        elif q_format == QFormat.FP16_16:
+            self._prepare_float(NumberFormat.HalfPrecisionFloat, NumberFormat.HalfPrecisionFloat, outputs=True)
+        elif q_format == QFormat.FP16_32:
+            self._prepare_float(NumberFormat.HalfPrecisionFloat, NumberFormat.HalfPrecisionFloat, outputs=False)
+        elif q_format == QFormat.TF32:
+            self._prepare_float(NumberFormat.TensorFloat32, NumberFormat.TensorFloat32, outputs=False)
+        else:
+            raise NotImplementedError(f"unknown q_format={q_format}")
+        if q_format != QFormat.FP32 and hasattr(self.model, "set_precision"):
+            # fake-quantised values are fp32 by definition (utils/quantize.py:84): never squeeze them through bf16
+            self.model.set_precision("fp32")
+        self.q_format: QFormat = q_format
+
+    # -- helpers ---------------------------------------------------------------------------------------------
+    def _reassign_attrs(self, reassign):
+        for name, mod in reassign.items():
+            inner = self.model
+            names = name.split(".")
+            for sub_name in names[:-1]:
+                inner = getattr(inner, sub_name)
+            setattr(inner, names[-1], mod)
+
+    def _prepare_float(self, act_fmt, weight_fmt, outputs):
+        """FP16_32 / TF32 (reference :289-327): quantise the INPUT of every Linear and LayerNorm and every Linear
+        weight.  FP16_16 (reference :253-287, ``outputs=True``) additionally quantises the outputs of Linear and
+        LayerNorm, the GELU input and every FloatFunctional result.  Modules are wrapped as
+        ``Sequential(QuantStub, module)`` exactly like the reference, so state-dict keys gain the same ``.1.``."""
+        reassign = {}
+        for name, module in list(self.model.named_modules()):
+            if isinstance(module, FloatFunctional) and outputs:
+                module.activation_post_process = Quantizer(act_fmt)
+            elif isinstance(module, nn.Linear):
+                module.__class__ = QATLinear
+                module.weight_fake_quant = Quantizer(weight_fmt)
+                module.activation_post_process = Quantizer(act_fmt) if outputs else None
+                reassign[name] = nn.Sequential(QuantStub(Quantizer(act_fmt)), module)
+            elif isinstance(module, nn.LayerNorm):
+                module.__class__ = _QATLayerNorm
+                module.weight_quantizer = Quantizer(weight_fmt)
+                module.activation_post_process = Quantizer(act_fmt) if outputs else None
+                reassign[name] = nn.Sequential(QuantStub(Quantizer(act_fmt)), module)
+            elif isinstance(module, nn.GELU) and outputs:
+                module.__class__ = _QATGELU
+                reassign[name] = nn.Sequential(QuantStub(Quantizer(act_fmt)), module)
+        self._reassign_attrs(reassign)
+
+    def _prepare_qat_pytorch_int8(self):
+        """reference :230-251 installs MinMaxObservers (activations quint8 affine, weights qint8 symmetric) that
+        only RECORD ranges in prepared mode.  Build-defined placement (the reference's converted path does not run,
+        SURVEY 9.2): one activation observer in front of every Linear, one weight observer per Linear."""
+        reassign = {}
+        for name, module in list(self.model.named_modules()):
+            if isinstance(module, nn.Linear):
+                module.__class__ = QATLinear
+                module.weight_fake_quant = None
+                module.weight_observer = MinMaxObserver(symmetric=True, qmin=-128, qmax=127)
+                reassign[name] = nn.Sequential(QuantStub(MinMaxObserver(symmetric=False, qmin=0, qmax=255)), module)
+        self._reassign_attrs(reassign)
+
+    def convert(self):
+        if self.q_format == QFormat.FP32:
+            return
+        if self.q_format == QFormat.PyTorchINT8:
+            for module in self.model.modules():
+                if isinstance(module, nn.Sequential) and len(module) == 2 and isinstance(module[0], QuantStub) \
+                        and isinstance(module[0].activation_post_process, MinMaxObserver):
+                    module[0].activation_post_process.freeze()
+                    lin = module[1]
+                    obs = lin.weight_observer.to(lin.weight.device)
+                    obs(lin.weight.data)
+                    obs.freeze()
+                    lin.weight.data = obs(lin.weight.data).data
+            return
+        if self.q_format in (QFormat.FP16_16, QFormat.FP16_32, QFormat.TF32):
+            # reference :340-346: Linear and LayerNorm weights quantised once; activation quantisers removed
+            for module in list(self.model.modules()):
+                if isinstance(module, QATLinear):
+                    QLinear.from_float(module)
+                elif isinstance(module, _QATLayerNorm):
+                    QLayerNorm.from_float(module)
+                elif isinstance(module, (QuantStub, FloatFunctional)):
+                    module.activation_post_process = None
+            return
+        raise NotImplementedError(f"unknown q_format={self.q_format}")

@@ -1,0 +1,342 @@
+"""GPU parity tests of every C-ABI entry point against CPU restatements (torch fp32/fp64 math or oracle/).
+
+Run on a real MI355X:  python -m pytest tests -m gpu -q
+Tolerances are written next to each check.  bf16 MFMA kernels are compared with references computed in
+fp64 FROM THE SAME bf16-ROUNDED INPUTS, so the only error left is fp32 accumulation order (~1e-6) plus, where the
+output is bf16, one final rounding (2^-9 relative).
+"""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from oracle import quant_oracle  # noqa: E402
+from oracle.vit_oracle import gelu_erf, layer_norm as ln_oracle, patchify as patchify_oracle  # noqa: E402
+
+
+@pytest.fixture(scope="module")
+def ops():
+    from myrtle_vision.hip import ops as _ops
+    _ops.lib()
+    assert torch.cuda.is_available(), "these tests need a GPU"
+    return _ops
+
+
+def g(seed):
+    return torch.Generator().manual_seed(seed)
+
+
+def relerr(got, want):
+    got, want = got.detach().double().cpu(), want.detach().double().cpu()
+    return float((got - want).abs().max() / want.abs().max().clamp_min(1e-30))
+
+
+def bf(x):
+    return x.to(torch.bfloat16)
+
+
+def dgelu64(x):
+    x = x.double()
+    return 0.5 * (1 + torch.erf(x / 2 ** 0.5)) + x * torch.exp(-0.5 * x * x) / (2 * np.pi) ** 0.5
+
+
+# ---------------------------------------------------------------- LayerNorm
+@pytest.mark.parametrize("rows,dim", [(1576, 192), (394, 768), (7, 1000), (5, 64)])
+@pytest.mark.parametrize("odt", [torch.float32, torch.bfloat16])
+def test_layernorm_fwd_bwd(ops, rows, dim, odt):
+    x = torch.randn(rows, dim, generator=g(1)) * 2 + 0.5
+    gam = torch.randn(dim, generator=g(2)) * 0.1 + 1
+    bet = torch.randn(dim, generator=g(3)) * 0.1
+    dy = torch.randn(rows, dim, generator=g(4))
+    xr = x.double().requires_grad_(True)
+    gr, br = gam.double().requires_grad_(True), bet.double().requires_grad_(True)
+    yr = ln_oracle(xr, gr, br)
+    dyq = dy.to(odt).double()
+    yr.backward(dyq)
+    xd, gd, bd = x.cuda(), gam.cuda(), bet.cuda()
+    y, mean, rstd = ops.layernorm_fwd(xd, dim, rows, dim, gd, bd, odt)
+    tol = 2e-6 if odt == torch.float32 else 2.0 ** -8
+    assert relerr(y.float(), yr) < tol
+    add = torch.randn(rows, dim, generator=g(5))
+    dx = torch.empty(rows, dim, device="cuda")
+    dgam, dbet = ops.layernorm_bwd(dy.to(odt).cuda(), xd, dim, gd, mean, rstd, add.cuda(), dx, dim, rows, dim)
+    assert relerr(dx, xr.grad + add.double()) < 5e-6
+    assert relerr(dgam, gr.grad) < 5e-6
+    assert relerr(dbet, br.grad) < 5e-6
+
+
+def test_layernorm_strided_rows(ops):
+    B, T, D = 6, 197, 192
+    x = torch.randn(B, T, D, generator=g(1)).cuda()
+    gam, bet = torch.ones(D).cuda(), torch.zeros(D).cuda()
+    y, mean, rstd = ops.layernorm_fwd(x, T * D, B, D, gam, bet, torch.float32)       # the cls rows
+    want = torch.nn.functional.layer_norm(x[:, 0].cpu(), (D,))
+    assert relerr(y, want) < 2e-6
+
+
+# ---------------------------------------------------------------- bf16 MFMA GEMMs
+NT_SHAPES = [(1576, 192, 192), (1576, 576, 192), (394, 768, 768), (256, 1000, 768), (300, 45, 192), (129, 130, 200),
+             (64, 17, 72), (1, 8, 8), (2560, 3072, 768)]
+
+
+@pytest.mark.parametrize("M,N,K", NT_SHAPES)
+def test_gemm_nt_bias_f32_out(ops, M, N, K):
+    a, w, b = bf(torch.randn(M, K, generator=g(1))), bf(torch.randn(N, K, generator=g(2)) * K ** -0.5), torch.randn(N, generator=g(3))
+    want = a.double() @ w.double().t() + b.double()
+    wp = w.float().cuda()
+    out = torch.empty(M, N, device="cuda")
+    ops.linear_fwd(a.cuda(), M, K, wp, b.cuda(), out, N)
+    assert relerr(out, want) < 3e-6                      # fp32 accumulation of exact bf16 products
+    out16 = torch.empty(M, N, device="cuda", dtype=torch.bfloat16)
+    ops.linear_fwd(a.cuda(), M, K, wp, b.cuda(), out16, N)
+    assert relerr(out16.float(), want) < 2.0 ** -8        # + one bf16 rounding
+
+
+def test_gemm_nt_epilogues(ops):
+    M, N, K = 1576, 768, 192
+    a, w, b = bf(torch.randn(M, K, generator=g(1))), bf(torch.randn(N, K, generator=g(2)) * K ** -0.5), torch.randn(N, generator=g(3)) * 0.1
+    pre = a.double() @ w.double().t() + b.double()
+    wp = w.float().cuda()
+    # GELU: C = gelu(pre) bf16, out2 = pre bf16
+    act = torch.empty(M, N, device="cuda", dtype=torch.bfloat16)
+    h = torch.empty(M, N, device="cuda", dtype=torch.bfloat16)
+    ops.linear_fwd(a.cuda(), M, K, wp, b.cuda(), act, N, epi=ops.EPI_GELU, out2=h, ld_out2=N)
+    assert relerr(h.float(), pre) < 2.0 ** -8
+    assert relerr(act.float(), gelu_erf(pre)) < 2.0 ** -8
+    # RESIDUAL: fp32
+    res = torch.randn(M, N, generator=g(4))
+    out = torch.empty(M, N, device="cuda")
+    ops.linear_fwd(a.cuda(), M, K, wp, b.cuda(), out, N, epi=ops.EPI_RESIDUAL, aux=res.cuda(), ld_aux=N)
+    assert relerr(out, pre + res.double()) < 3e-6
+    # DGELU via the dX entry point: out[M,K] = (dy[M,N] @ W[N,K]) * gelu'(hh[M,K])
+    dy = bf(torch.randn(M, N, generator=g(5)))
+    hh = bf(torch.randn(M, K, generator=g(6)))
+    want = (dy.double() @ w.double()) * dgelu64(hh)
+    dx = torch.empty(M, K, device="cuda", dtype=torch.bfloat16)
+    ops.linear_dx(dy.cuda(), M, N, wp, dx, K, epi=ops.EPI_DGELU, aux=hh.cuda(), ld_aux=K)
+    assert relerr(dx.float(), want) < 2.0 ** -8
+
+
+def test_gemm_nt_embed_epilogue(ops):
+    B, npatch, D, pd = 3, 196, 192, 768
+    a, w, b = bf(torch.randn(B * npatch, pd, generator=g(1))), bf(torch.randn(D, pd, generator=g(2)) * pd ** -0.5), torch.randn(D, generator=g(3))
+    pos = torch.randn(npatch + 1, D, generator=g(4))
+    x = torch.full((B, npatch + 1, D), 7.0, device="cuda")
+    ops.linear_fwd(a.cuda(), B * npatch, pd, w.float().cuda(), b.cuda(), x, D, epi=ops.EPI_EMBED, aux=pos.cuda(), ld_aux=D, aux_i=npatch)
+    want = (a.double() @ w.double().t() + b.double()).view(B, npatch, D) + pos[1:].double()
+    assert relerr(x[:, 1:], want) < 3e-6
+    assert (x[:, 0] == 7.0).all()                          # cls rows untouched
+
+
+TN_SHAPES = [(1576, 192, 576), (1576, 768, 192), (5000, 768, 768), (256, 48, 768), (100, 136, 200), (63, 8, 8),
+             (20000, 3072, 768)]
+
+
+@pytest.mark.parametrize("Kc,M,N", TN_SHAPES)
+def test_gemm_tn_dw_and_colsum(ops, Kc, M, N):
+    dy, x = bf(torch.randn(Kc, M, generator=g(1))), bf(torch.randn(Kc, N, generator=g(2)))
+    want = dy.double().t() @ x.double()
+    dw, db = ops.linear_dw(dy.cuda(), x.cuda(), Kc, M, N)
+    assert relerr(dw, want) < 3e-6
+    assert relerr(db, dy.double().sum(0)) < 3e-6
+
+
+def test_misaligned_leading_dimension_is_rejected(ops):
+    dy, x = bf(torch.randn(100, 130)), bf(torch.randn(100, 200))
+    with pytest.raises(RuntimeError, match="not aligned"):
+        ops.linear_dw(dy.cuda(), x.cuda(), 100, 130, 200)
+
+
+def test_gemm_tn_padded_rows(ops):
+    # class dim 45 padded to 48 with zero columns (ld_dy = 48): only the first 45 output rows exist
+    Kc, C, D = 256, 45, 192
+    dy = torch.zeros(Kc, 48)
+    dy[:, :C] = torch.randn(Kc, C, generator=g(1))
+    dy, x = bf(dy), bf(torch.randn(Kc, D, generator=g(2)))
+    dw, db = ops.linear_dw(dy.cuda(), x.cuda(), Kc, C, D, ld_dy=48)
+    assert dw.shape == (C, D)
+    assert relerr(dw, dy[:, :C].double().t() @ x.double()) < 3e-6
+    assert relerr(db, dy[:, :C].double().sum(0)) < 3e-6
+
+
+# ---------------------------------------------------------------- fp32 strided GEMM
+def test_gemm_f32_linear_forms(ops):
+    M, N, K = 333, 77, 130
+    x, w, b = torch.randn(M, K, generator=g(1)), torch.randn(N, K, generator=g(2)), torch.randn(N, generator=g(3))
+    out = torch.empty(M, N, device="cuda")
+    ops.linear_fwd(x.cuda(), M, K, w.cuda(), b.cuda(), out, N)
+    assert relerr(out, x.double() @ w.double().t() + b.double()) < 2e-6
+    dy = torch.randn(M, N, generator=g(4))
+    dx = torch.empty(M, K, device="cuda")
+    ops.linear_dx(dy.cuda(), M, N, w.cuda(), dx, K)
+    assert relerr(dx, dy.double() @ w.double()) < 2e-6
+    dw, db = ops.linear_dw(dy.cuda(), x.cuda(), M, N, K)
+    assert relerr(dw, dy.double().t() @ x.double()) < 2e-6
+    assert relerr(db, dy.double().sum(0)) < 2e-6
+
+
+# ---------------------------------------------------------------- attention
+def attn_ref(qkv, H, scale):
+    B, N, _ = qkv.shape
+    dh = qkv.shape[2] // (3 * H)
+    q, k, v = qkv.double().view(B, N, 3, H, dh).permute(2, 0, 3, 1, 4)
+    p = ((q @ k.transpose(-2, -1)) * scale).softmax(-1)
+    return (p @ v).transpose(1, 2).reshape(B, N, H * dh), p
+
+
+@pytest.mark.parametrize("B,N,H", [(2, 197, 3), (1, 257, 2), (3, 50, 1), (1, 17, 12)])
+def test_attention_fused_fwd_bwd(ops, B, N, H):
+    scale = 64 ** -0.5
+    qkv = bf(torch.randn(B, N, 3 * H * 64, generator=g(1)) * 1.5)
+    dout = bf(torch.randn(B, N, H * 64, generator=g(2)))
+    ref_in = qkv.double().requires_grad_(True)
+    want, _ = attn_ref(ref_in, H, scale)
+    want.backward(dout.double())
+    out, lse = ops.attention_fwd(qkv.cuda(), B, N, H, scale)
+    # P is rounded to bf16 before P.V (2^-9 per element, averaged over keys) and the output once more
+    assert relerr(out.float(), want) < 1.5e-2
+    q, k, _ = qkv.double().view(B, N, 3, H, 64).permute(2, 0, 3, 1, 4)
+    lse_ref = torch.logsumexp((q @ k.transpose(-2, -1)) * scale, dim=-1)
+    assert float((lse.cpu().double() - lse_ref).abs().max()) < 1e-4
+    dqkv = ops.attention_bwd(qkv.cuda(), out, dout.cuda(), lse, B, N, H, scale)
+    got, ref = dqkv.float().cpu().view(B, N, 3, H, 64), ref_in.grad.view(B, N, 3, H, 64)
+    for i, name in enumerate("qkv"):
+        assert relerr(got[:, :, i], ref[:, :, i]) < 3e-2, name
+
+
+@pytest.mark.parametrize("B,N,H,dh", [(2, 197, 3, 64), (1, 40, 2, 32)])
+def test_attention_materialised_fp32(ops, B, N, H, dh):
+    scale = dh ** -0.5
+    qkv = torch.randn(B, N, 3 * H * dh, generator=g(1))
+    dout = torch.randn(B, N, H * dh, generator=g(2))
+    ref_in = qkv.double().requires_grad_(True)
+    want, p_ref = attn_ref(ref_in, H, scale)
+    want.backward(dout.double())
+    probs = ops.attention_probs_fp32(qkv.cuda(), B, N, H, dh, scale)
+    assert relerr(probs, p_ref) < 5e-6
+    out = ops.attention_pv_fp32(probs, qkv.cuda(), B, N, H, dh)
+    assert relerr(out, want) < 5e-6
+    dqkv = ops.attention_bwd_fp32(probs, qkv.cuda(), dout.cuda(), B, N, H, dh, scale)
+    assert relerr(dqkv, ref_in.grad) < 2e-5
+
+
+# ---------------------------------------------------------------- elementwise / layout
+@pytest.mark.parametrize("B,C,H,W,p", [(3, 3, 224, 224, 16), (2, 3, 256, 256, 16), (2, 1, 32, 48, 8), (1, 3, 30, 30, 6)])
+def test_patchify_exact(ops, B, C, H, W, p):
+    img = torch.randn(B, C, H, W, generator=g(1))
+    want = patchify_oracle(img, p).reshape(-1, p * p * C)
+    assert torch.equal(ops.patchify(img.cuda(), p, torch.float32).cpu(), want)
+    assert torch.equal(ops.patchify(img.cuda(), p, torch.bfloat16).cpu(), bf(want))
+
+
+def test_embed_helpers(ops):
+    B, T, D = 5, 197, 192
+    cls, pos = torch.randn(D, generator=g(1)), torch.randn(T, D, generator=g(2))
+    x = torch.zeros(B, T, D, device="cuda")
+    ops.embed_cls(cls.cuda(), pos.cuda(), x, B, T, D)
+    assert torch.equal(x[:, 0].cpu(), (cls + pos[0]).expand(B, D))
+    dx = torch.randn(B, T, D, generator=g(3))
+    dpos, dcls = ops.embed_bwd(dx.cuda(), B, T, D)
+    assert relerr(dpos, dx.double().sum(0)) < 1e-6 and relerr(dcls, dx[:, 0].double().sum(0)) < 1e-6
+    rows = ops.gather_patch_rows(dx.cuda(), B, T, D, torch.bfloat16)
+    assert torch.equal(rows.cpu(), bf(dx[:, 1:].reshape(-1, D)))
+
+
+def test_cast_weightprep_gelu_add(ops):
+    x = torch.randn(1000003, generator=g(1))
+    assert torch.equal(ops.cast(x.cuda(), torch.bfloat16).cpu(), bf(x))
+    assert torch.equal(ops.cast(bf(x).cuda(), torch.float32).cpu(), bf(x).float())
+    w = torch.randn(45, 192, generator=g(2))
+    pw = ops.prepared_weight(w.cuda())
+    assert pw.w.shape == (45, 192) and pw.wt.shape == (192, 48)
+    assert torch.equal(pw.w.cpu(), bf(w)) and torch.equal(pw.wt[:, :45].cpu(), bf(w.t())) and (pw.wt[:, 45:] == 0).all()
+    h = torch.randn(4099, generator=g(3)) * 2
+    assert relerr(ops.gelu_fwd(h.cuda()), gelu_erf(h.double())) < 1e-6
+    dy = torch.randn(4099, generator=g(4))
+    assert relerr(ops.gelu_bwd(h.cuda(), dy.cuda()), dy.double() * dgelu64(h)) < 2e-6
+    assert torch.equal(ops.add_f32(h.cuda(), dy.cuda()).cpu(), h + dy)
+
+
+# ---------------------------------------------------------------- quantisers: bit-exact vs the oracle restatement
+def test_quant_float_bit_exact(ops):
+    gg = g(7)
+    x = torch.randn(300001, generator=gg) * torch.exp(torch.randn(300001, generator=gg) * 5)
+    x[:8] = torch.tensor([0.0, -0.0, 65504.0, 65520.0, 1e9, 2.0 ** -24, 2.0 ** -25, -2.0 ** -26])
+    for e, m in [(5, 10), (8, 10), (4, 3), (8, 7)]:
+        got = ops.quant_float(x.cuda(), e, m).cpu().numpy()
+        want = quant_oracle.float_quantize(x.numpy(), e, m)
+        assert np.array_equal(got.view(np.uint32), want.view(np.uint32)), (e, m)
+
+
+def test_quant_fixed_and_affine_bit_exact(ops):
+    x = torch.randn(100001, generator=g(8)) * 3
+    for wl, fl in [(11, 9), (11, 8), (11, 7), (8, 4)]:
+        got = ops.quant_fixed(x.cuda(), wl, fl).cpu().numpy()
+        assert np.array_equal(got, quant_oracle.fixed_point_quantize(x.numpy(), wl, fl)), (wl, fl)
+    s, z = quant_oracle.affine_qparams(float(x.min()), float(x.max()), 0, 255, False)
+    got = ops.quant_affine(x.cuda(), s, z, 0, 255).cpu().numpy()
+    assert np.array_equal(got, quant_oracle.fake_quant_affine(x.numpy(), s, z, 0, 255))
+    st = torch.tensor([float("inf"), float("-inf"), 0, 0]).cuda()
+    ops.minmax_update(x.cuda(), st)
+    ops.minmax_update((x * 0.5 - 20).cuda(), st)
+    assert float(st[0]) == float((x * 0.5 - 20).min()) and float(st[1]) == float(x.max())
+
+
+# ---------------------------------------------------------------- loss / upsample / optimiser
+@pytest.mark.parametrize("B,C", [(8, 45), (256, 1000), (3, 17)])
+def test_cross_entropy_cls(ops, B, C):
+    logits = torch.randn(B, C, generator=g(1)) * 3
+    labels = torch.randint(0, C, (B,), generator=g(2))
+    ref = logits.double().requires_grad_(True)
+    l = torch.nn.functional.cross_entropy(ref, labels)
+    l.backward()
+    loss, dl, am = ops.cross_entropy(logits.cuda(), labels.cuda(), want_grad=True, want_argmax=True)
+    assert abs(float(loss) - float(l)) < 1e-5 * max(1, abs(float(l)))
+    assert relerr(dl, ref.grad) < 1e-5
+    assert torch.equal(am.cpu(), logits.argmax(1))
+    ld = (C + 7) & ~7
+    _, dlp, _ = ops.cross_entropy(logits.cuda(), labels.cuda(), want_grad=True, grad_dtype=torch.bfloat16, ld_dl=ld)
+    assert dlp.shape == (B, ld) and (dlp[:, C:] == 0).all()
+    assert relerr(dlp[:, :C].float(), ref.grad) < 2.0 ** -8
+
+
+def test_cross_entropy_seg(ops):
+    B, C, S = 2, 17, 56
+    logits = torch.randn(B, C, S, S, generator=g(1)) * 2
+    labels = torch.randint(0, C, (B, S, S), generator=g(2))
+    ref = logits.double().requires_grad_(True)
+    l = torch.nn.functional.cross_entropy(ref, labels)
+    l.backward()
+    loss, dl, am = ops.cross_entropy(logits.cuda(), labels.cuda(), want_grad=True, want_argmax=True)
+    assert abs(float(loss) - float(l)) < 1e-5 * abs(float(l))
+    assert relerr(dl, ref.grad) < 1e-5
+    assert torch.equal(am.cpu(), logits.argmax(1))
+
+
+@pytest.mark.parametrize("g_in,size", [(14, 224), (16, 256), (7, 20)])
+def test_upsample_bilinear(ops, g_in, size):
+    B, C = 2, 17
+    small = torch.randn(B, g_in * g_in, C, generator=g(1))              # decoder GEMM layout [B, h*w, C]
+    ref = small.double().transpose(1, 2).reshape(B, C, g_in, g_in).requires_grad_(True)
+    want = torch.nn.functional.interpolate(ref, size=(size, size), mode="bilinear", align_corners=False)
+    dbig = torch.randn(B, C, size, size, generator=g(2))
+    want.backward(dbig.double())
+    big = ops.upsample_bilinear_fwd(small.cuda(), g_in * g_in * C, 1, C, B, C, g_in, g_in, size, size)
+    assert relerr(big, want) < 2e-6
+    dsmall = torch.empty(B, g_in * g_in, C, device="cuda")
+    ops.upsample_bilinear_bwd(dbig.cuda(), dsmall, g_in * g_in * C, 1, C, B, C, g_in, g_in, size, size)
+    assert relerr(dsmall, ref.grad.reshape(B, C, -1).transpose(1, 2)) < 5e-6
+
+
+def test_adamw_matches_torch(ops):
+    n = 100003
+    p0, gr = torch.randn(n, generator=g(1)), torch.randn(n, generator=g(2))
+    ref = torch.nn.Parameter(p0.clone())
+    opt = torch.optim.AdamW([ref], lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.05)
+    p, m, v = p0.clone().cuda(), torch.zeros(n).cuda(), torch.zeros(n).cuda()
+    for step in range(1, 4):
+        ref.grad = gr * step
+        opt.step()
+        ops.adamw_step(p, (gr * step).cuda(), m, v, lr=1e-3, beta1=0.9, beta2=0.999, eps=1e-8, weight_decay=0.05, step=step)
+    assert relerr(p, ref.data) < 2e-6

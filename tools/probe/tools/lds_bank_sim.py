@@ -1,0 +1,87 @@
+#!/usr/bin/env python3
+"""LDS bank-conflict simulator for gfx950 (rules: MI355X_MICROARCH.md section LDS).
+
+Used at design time to check the swizzled LDS images of csrc/*.hip: for each access pattern it
+prints the LDS cycles per wave-instruction (ideal: b128 = 4, b64/tr = 2, write_b128 = 8).
+"""
+B128_GROUPS = [list(range(0, 4)) + list(range(12, 16)) + list(range(20, 28)),
+               list(range(4, 12)) + list(range(16, 20)) + list(range(28, 32)),
+               list(range(32, 36)) + list(range(44, 48)) + list(range(52, 60)),
+               list(range(36, 44)) + list(range(48, 52)) + list(range(60, 64))]
+HALVES = [list(range(0, 32)), list(range(32, 64))]
+W128_GROUPS = [list(range(8 * i, 8 * i + 8)) for i in range(8)]
+
+
+def cycles(addrs, nbytes, groups, nbanks):
+    """addrs: byte address per lane (64).  One LDS cycle per group when conflict-free."""
+    total = 0
+    for g in groups:
+        banks = {}
+        for l in g:
+            for d in range(nbytes // 4):
+                a = addrs[l] + 4 * d
+                banks.setdefault((a // 4) % nbanks, set()).add(a // 4)
+        total += max(len(v) for v in banks.values())
+    return total
+
+
+def sw128(row, ch):          # 128-byte rows (64 bf16): image used by gemm NT tiles and attention tiles
+    return 128 * row + 16 * (ch ^ (((row >> 1) & 3) << 1))
+
+
+def sw256(row, ch):          # 256-byte rows (128 bf16): image used by gemm TN tiles (guide T10 image (b))
+    return 256 * row + 16 * (ch ^ (((row & 3) << 2) | ((row >> 2) & 3)))
+
+
+def main():
+    worst = 0
+    # 1. MFMA 16x16x32 A/B fragment as ds_read_b128 from 128-B rows: lane l -> row base+(l&15), chunk 4ks+(l>>4)
+    for base in (0, 16, 48):
+        for ks in (0, 1):
+            a = [sw128(base + (l & 15), 4 * ks + (l >> 4)) for l in range(64)]
+            c = cycles(a, 16, B128_GROUPS, 64); worst = max(worst, c - 4)
+            print(f"b128 row read  base={base:2d} ks={ks}: {c} cycles (ideal 4)")
+    # 2. staging writes, 128-B rows: thread t -> row t>>3, chunk t&7
+    a = [sw128(l >> 3, l & 7) for l in range(64)]
+    print("write_b128 128B rows:", cycles(a, 16, W128_GROUPS, 32), "(ideal 8)")
+    # 3. tr read, 128-B rows, 'accumulator k-order': group g reads rows t0+4g+q, cols 16c..16c+15
+    for t0 in (0, 16):
+        for c in range(4):
+            a = []
+            for l in range(64):
+                g, i = l >> 4, l & 15
+                q, p = i >> 2, i & 3
+                a.append(sw128(t0 + 4 * g + q, 2 * c + (p >> 1)) + 8 * (p & 1))
+            cy = cycles(a, 8, HALVES, 64); worst = max(worst, cy - 2)
+            print(f"tr read 128B rows (rows 4g+q) t0={t0} c={c}: {cy} cycles (ideal 2)")
+    # 3b. tr read, 128-B rows, 'natural k-order': group g reads rows t0+8g+4s+q
+    for s in (0, 1):
+        a = []
+        for l in range(64):
+            g, i = l >> 4, l & 15
+            q, p = i >> 2, i & 3
+            a.append(sw128(8 * g + 4 * s + q, 2 * 1 + (p >> 1)) + 8 * (p & 1))
+        cy = cycles(a, 8, HALVES, 64); worst = max(worst, cy - 2)
+        print(f"tr read 128B rows (rows 8g+4s+q) s={s}: {cy} cycles (ideal 2)")
+    # 4. tr read, 256-B rows (TN gemm): group g reads rows m0+8g+4s+q, cols 16c..16c+15
+    for s in (0, 1):
+        for c in (0, 3, 7):
+            a = []
+            for l in range(64):
+                g, i = l >> 4, l & 15
+                q, p = i >> 2, i & 3
+                a.append(sw256(8 * g + 4 * s + q, 2 * c + (p >> 1)) + 8 * (p & 1))
+            cy = cycles(a, 8, HALVES, 64); worst = max(worst, cy - 2)
+            print(f"tr read 256B rows s={s} c={c}: {cy} cycles (ideal 2)")
+    a = [sw256(l >> 4, l & 15) for l in range(64)]
+    print("write_b128 256B rows:", cycles(a, 16, W128_GROUPS, 32), "(ideal 8)")
+    # 5. b64 row read (two 4-element halves of a k-permuted fragment), 128-B rows: lane -> row l&15, byte 8*(l>>4)+32*j
+    for j in (0, 1):
+        a = [sw128((l & 15), (8 * (l >> 4) + 32 * j) // 16) + (8 * (l >> 4) + 32 * j) % 16 for l in range(64)]
+        cy = cycles(a, 8, HALVES, 64)
+        print(f"b64 row read (k-permuted) j={j}: {cy} cycles (ideal 2)")
+    print("worst excess:", worst)
+
+
+if __name__ == "__main__":
+    main()
