@@ -1,0 +1,174 @@
+#!/usr/bin/env python3
+"""Headline benchmark: ViT-B/16 224^2 bf16 training step, images/sec (BASELINE.json `metric`).
+
+    python bench.py --gpus N --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+        bench.py --gpus N --steps K --warmup W
+
+One process per GPU.  A "step" = zero_grad + forward + cross-entropy + backward (+ gradient all-reduce over
+RCCL/xGMI overlapped with backward when N > 1) + AdamW, on a synthetic batch that is already resident in HBM
+(per-GPU batch 256, weak scaling: global batch = 256 * N).  Rank 0 prints ONE JSON line.
+
+`roofline`: the dominant kernel is gemm_nt_kernel (mv_gemm_nt_bf16: every nn.Linear forward and input-gradient
+product, 2/3 of all FLOPs).  achieved = sum of algorithmic FLOPs (2*M*N*K per launch) / sum of launch durations,
+measured with events recorded on the launch stream around every launch inside the timed region.
+`cpu_baseline`: the CPU oracle (oracle/vit_oracle.py, kind "port") timed on this host's cores, rank 0, N=1 only.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.join(ROOT, "myrtle-vision_amd"))
+sys.path.insert(0, ROOT)
+
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+TRAIN_GFLOP_PER_IMG = 105.38        # fwd 35.13 GFLOP x 3
+BF16_DENSE_PEAK_TFLOPS = 2500.0     # MI355X_MICROARCH.md: ~2.5 PF dense bf16
+VIT_B = dict(decoder="classification", image_size=224, patch_size=16, num_classes=1000, dim=768, depth=12, heads=12,
+             mlp_dim=3072, dropout=0.0, emb_dropout=0.0)
+
+
+def cpu_baseline(seconds_budget=25.0):
+    """Reference-equivalent CPU path (the oracle) on the host cores: ViT-B/16 B=8 fp32 fwd+bwd."""
+    from oracle.detinit import det_state_dict
+    from oracle.vit_oracle import ViTConfig, loss_and_grads
+    # the GPU box exposes every host cpu but a 1-GPU job owns a 16-core share: oversubscribing 256 threads made this
+    # 200x slower.  Use the affinity mask, capped at 16.
+    try:
+        ncores = len(os.sched_getaffinity(0))
+    except AttributeError:
+        ncores = os.cpu_count() or 1
+    torch.set_num_threads(max(1, min(ncores, 16)))
+    cfg = ViTConfig(decoder="classification", image_size=224, patch_size=16, num_classes=1000, dim=768, depth=12,
+                    heads=12, mlp_dim=3072)
+    params = det_state_dict(cfg.param_shapes())
+    g = torch.Generator().manual_seed(1234)
+    img = torch.randn(8, 3, 224, 224, generator=g)
+    labels = torch.randint(0, 1000, (8,), generator=g)
+    loss_and_grads(params, img, labels, cfg)            # warm-up
+    times = []
+    t_start = time.perf_counter()
+    while len(times) < 5 and (time.perf_counter() - t_start) < seconds_budget:
+        t0 = time.perf_counter()
+        loss_and_grads(params, img, labels, cfg)
+        times.append(time.perf_counter() - t0)
+    times.sort()
+    med = times[len(times) // 2]
+    return {"value": round(8.0 / med, 3), "unit": "images/sec", "cores": torch.get_num_threads(), "kind": "port",
+            "sample": f"ViT-B/16 224^2 fp32 fwd+bwd, batch 8, median of {len(times)} after 1 warm-up "
+                      f"(oracle/vit_oracle.py on {os.cpu_count()} host cpus)"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--batch", type=int, default=256, help="per-GPU batch")
+    ap.add_argument("--precision", default="bf16")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-kernel-timer", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run "
+                         f"--nproc-per-node {args.gpus} (one process per GPU)")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: the HIP path has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+
+    from myrtle_vision.hip import ops
+    from myrtle_vision.hip.functional import cross_entropy
+    from myrtle_vision.models.vit import ViT
+    from myrtle_vision.utils.ddp import GradAllReducer, broadcast_parameters
+    from myrtle_vision.utils.optim import AdamW, ParamArena
+    from myrtle_vision.utils.utils import seed_everything
+
+    seed_everything(1234)                                   # same initial weights on every rank
+    vit = ViT(precision=args.precision, q_format="FP32", **VIT_B).to(dev)
+    arena = ParamArena(vit.named_parameters(), skip=vit.unused_parameter_names())
+    opt = AdamW(arena, lr=6.25e-5, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.05)      # vit_base.json
+    reducer = GradAllReducer(arena)
+    broadcast_parameters(arena)
+    opt.grad_scale = reducer.grad_scale
+
+    g = torch.Generator().manual_seed(1234 + rank)          # per-rank shard of the synthetic global batch
+    img = torch.randn(args.batch, 3, 224, 224, generator=g).to(dev)
+    labels = torch.randint(0, 1000, (args.batch,), generator=g).to(dev)
+    vit.train()
+
+    def step():
+        opt.zero_grad()
+        logits = vit(img)
+        loss = cross_entropy(logits, labels)
+        loss.backward()
+        reducer.finish()
+        opt.step()
+        return loss
+
+    for _ in range(args.warmup):
+        loss = step()
+    timer = None if args.no_kernel_timer else ops.KernelTimer()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    ops.set_kernel_timer(timer)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        loss = step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+    ops.set_kernel_timer(None)
+    final_loss = float(loss.detach())
+    if world > 1:
+        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t)
+
+    if rank == 0:
+        img_s = args.batch * world * args.steps / elapsed
+        out = {
+            "metric": "images/sec (train fwd+bwd) ViT-B/16 224^2 bf16",
+            "value": round(img_s, 2), "unit": "images/sec", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(1e3 * elapsed / args.steps, 3), "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": args.precision, "data": "synthetic",
+            "config": {"workload": "ViT-B/16 224^2 classification training step: zero_grad + fwd + CE + bwd + "
+                                   "grad all-reduce + AdamW; 1000 classes; random-init weights; batch resident in HBM",
+                       "per_gpu_batch": args.batch, "global_batch": args.batch * world,
+                       "parallelism": f"dp{world}", "final_loss": round(final_loss, 4)},
+            "step_mfma_frac": round(img_s / world * TRAIN_GFLOP_PER_IMG * 1e9 / (BF16_DENSE_PEAK_TFLOPS * 1e12), 4),
+        }
+        if timer is not None:
+            summ = timer.summary()
+            k = summ.get("gemm_nt_bf16")
+            if k:
+                out["roofline"] = {"bound": "mfma", "kernel": "gemm_nt_kernel (mv_gemm_nt_bf16)",
+                                   "achieved": round(k["tflops"], 1), "peak": BF16_DENSE_PEAK_TFLOPS, "unit": "TFLOP/s",
+                                   "frac": round(k["tflops"] / BF16_DENSE_PEAK_TFLOPS, 4), "traffic": None,
+                                   "launches": k["launches"], "avg_launch_us": round(k["avg_us"], 1),
+                                   "gflop_per_launch": round(k["flops_per_launch"] / 1e9, 2)}
+            out["kernels"] = {n: {"launches": v["launches"], "avg_us": round(v["avg_us"], 1), "tflops": round(v["tflops"], 1),
+                                  "ms_per_step": round(v["total_ms"] / args.steps, 3)} for n, v in summ.items()}
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline()
+        print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -559,7 +559,8 @@ extern "C" int mv_weight_prep(const float* w, void* w_bf16, int ldw, void* wt_bf
 }
 
 extern "C" int mv_gelu_fwd(const void* x, void* y, int dtype, long n, mv_stream_t stream) {
-  if (n <= 0) return n == 0 ? MV_OK : MV_ERR_SHAPE;
+  MV_REQUIRE(n >= 0, MV_ERR_SHAPE);
+  if (n == 0) return MV_OK;
   if (dtype == MV_F32)
     gelu_fwd_kernel<float><<<ew_grid(n), 256, 0, S_>>>((const float*)x, (float*)y, n);
   else if (dtype == MV_BF16)
@@ -571,7 +572,8 @@ extern "C" int mv_gelu_fwd(const void* x, void* y, int dtype, long n, mv_stream_
 }
 
 extern "C" int mv_gelu_bwd(const void* x, const void* dy, void* dx, int dtype, long n, mv_stream_t stream) {
-  if (n <= 0) return n == 0 ? MV_OK : MV_ERR_SHAPE;
+  MV_REQUIRE(n >= 0, MV_ERR_SHAPE);
+  if (n == 0) return MV_OK;
   if (dtype == MV_F32)
     gelu_bwd_kernel<float><<<ew_grid(n), 256, 0, S_>>>((const float*)x, (const float*)dy, (float*)dx, n);
   else if (dtype == MV_BF16)
@@ -583,7 +585,8 @@ extern "C" int mv_gelu_bwd(const void* x, const void* dy, void* dx, int dtype, l
 }
 
 extern "C" int mv_add_f32(const float* a, const float* b, float* out, long n, mv_stream_t stream) {
-  if (n <= 0) return n == 0 ? MV_OK : MV_ERR_SHAPE;
+  MV_REQUIRE(n >= 0, MV_ERR_SHAPE);
+  if (n == 0) return MV_OK;
   MV_REQUIRE(mv_aligned16(a) && mv_aligned16(b) && mv_aligned16(out), MV_ERR_ALIGN);
   add_kernel<<<ew_grid((n + 3) / 4), 256, 0, S_>>>(a, b, out, n);
   MV_CHECK_LAUNCH();

@@ -2,6 +2,8 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdio.h>
+#include <stdlib.h>
 
 #include "../../include/myrtle_vision_hip.h"
 
@@ -19,15 +21,24 @@ typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
 #define LDS_PTR(T, p) ((__attribute__((address_space(3))) T*)(p))
 
 // ---- launch plumbing ------------------------------------------------------------------------
-#define MV_CHECK_LAUNCH()                                   \
-  do {                                                      \
-    hipError_t e__ = hipGetLastError();                     \
-    if (e__ != hipSuccess) return MV_ERR_LAUNCH;            \
+#define MV_CHECK_LAUNCH()                                                                          \
+  do {                                                                                             \
+    hipError_t e__ = hipGetLastError();                                                            \
+    if (e__ != hipSuccess) {                                                                       \
+      if (getenv("MV_DEBUG"))                                                                      \
+        fprintf(stderr, "[myrtle_vision_hip] %s:%d: HIP error %d (%s)\n", __FILE__, __LINE__, (int)e__, \
+                hipGetErrorString(e__));                                                           \
+      return MV_ERR_LAUNCH;                                                                        \
+    }                                                                                              \
   } while (0)
 
-#define MV_REQUIRE(cond, code) \
-  do {                         \
-    if (!(cond)) return (code); \
+// Argument check.  It also CLEARS the runtime's sticky last-error: hipGetLastError() reports the last error of ANY
+// earlier runtime call on this thread (e.g. the host framework probing a pointer), which MV_CHECK_LAUNCH would
+// otherwise mistake for a failed launch.  Every entry point runs at least one MV_REQUIRE before it launches.
+#define MV_REQUIRE(cond, code)    \
+  do {                            \
+    (void)hipGetLastError();      \
+    if (!(cond)) return (code);   \
   } while (0)
 
 static inline bool mv_aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }

@@ -26,12 +26,41 @@ def _hipcc():
     return "hipcc"
 
 
+def _torch_lib_dir():
+    """Directory of the HIP runtime PyTorch-ROCm ships (found without importing torch), or None."""
+    try:
+        import importlib.util
+        spec = importlib.util.find_spec("torch")
+        d = os.path.join(list(spec.submodule_search_locations)[0], "lib")
+        return d if os.path.exists(os.path.join(d, "libamdhip64.so")) else None
+    except Exception:
+        return None
+
+
+def _link_command(hipcc, objs):
+    """ONE HIP runtime per process.  PyTorch-ROCm bundles its own runtime (file ``torch/lib/libamdhip64.so``, soname
+    ``libamdhip64.so.7``) and requests it by FILE name; this library requests ``libamdhip64.so.7``.  If torch is in
+    the process first, the dynamic loader satisfies our request with torch's already-loaded instance (soname match):
+    one runtime, shared streams and device state -- which is why ``lib.py`` imports torch before ``CDLL``.  Loaded the
+    other way round, torch's file-name request would NOT match the /opt/rocm instance and a second runtime would
+    start ("no ROCm-capable device" on the first launch, observed).  Linking with g++ against torch's copy (device
+    code is already embedded in the objects) only makes the RUNPATH prefer that copy; a non-torch host falls through
+    to /opt/rocm/lib."""
+    tl = _torch_lib_dir()
+    if tl is None:
+        return [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB_PATH] + objs
+    rocm = os.environ.get("ROCM_PATH", "/opt/rocm")
+    return ["g++", "-shared", "-fPIC", "-o", LIB_PATH] + objs + [
+        f"-L{tl}", "-l:libamdhip64.so", f"-Wl,-rpath,{tl}:{rocm}/lib", "-Wl,--enable-new-dtags"]
+
+
 def _digest():
     h = hashlib.sha256()
     for f in sorted(os.listdir(CSRC)) + ["../../include/myrtle_vision_hip.h"]:
         with open(os.path.join(CSRC, f), "rb") as fh:
             h.update(f.encode() + b"\0" + fh.read())
     h.update(" ".join(FLAGS).encode())
+    h.update(str(_torch_lib_dir()).encode())
     return h.hexdigest()
 
 
@@ -56,8 +85,7 @@ def build(force: bool = False, verbose: bool = True) -> str:
 
     with ThreadPoolExecutor(max_workers=min(5, os.cpu_count() or 1)) as ex:
         objs = list(ex.map(compile_one, SOURCES))
-    r = subprocess.run([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB_PATH] + objs,
-                       capture_output=True, text=True)
+    r = subprocess.run(_link_command(hipcc, objs), capture_output=True, text=True)
     if r.returncode != 0:
         raise RuntimeError(f"link failed:\n{r.stderr}")
     with open(stamp, "w") as f:

@@ -8,6 +8,8 @@ import ctypes
 import os
 import threading
 
+import torch  # noqa: F401  -- FIRST: brings PyTorch-ROCm's HIP runtime into the process so the library binds to it
+
 from .build import LIB_PATH
 
 MV_F32, MV_BF16 = 0, 1

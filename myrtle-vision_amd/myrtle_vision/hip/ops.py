@@ -47,6 +47,43 @@ def pad8(n: int) -> int:
     return (n + 7) & ~7
 
 
+class KernelTimer:
+    """Optional per-launch timing of the MFMA kernels with events recorded on the launch stream (the stream handed
+    to the C ABI is torch's current stream).  Used by bench.py for the live roofline figure; off by default."""
+
+    def __init__(self):
+        self.records = {}          # kernel name -> list of (start_event, end_event, algorithmic_flops)
+
+    def begin(self):
+        e = torch.cuda.Event(enable_timing=True)
+        e.record()
+        return e
+
+    def end(self, name, start, flops):
+        e = torch.cuda.Event(enable_timing=True)
+        e.record()
+        self.records.setdefault(name, []).append((start, e, flops))
+
+    def summary(self):
+        """-> {name: dict(launches, total_ms, avg_us, flops_per_launch, tflops)} (synchronises)."""
+        torch.cuda.synchronize()
+        out = {}
+        for name, recs in self.records.items():
+            ms = sum(s.elapsed_time(e) for s, e, _ in recs)
+            fl = sum(f for _, _, f in recs)
+            out[name] = dict(launches=len(recs), total_ms=ms, avg_us=1e3 * ms / len(recs), flops_per_launch=fl / len(recs),
+                             tflops=fl / (ms * 1e-3) / 1e12 if ms > 0 else 0.0)
+        return out
+
+
+_timer = None
+
+
+def set_kernel_timer(timer):
+    global _timer
+    _timer = timer
+
+
 _workspaces = {}
 
 
@@ -136,9 +173,12 @@ def linear_fwd(x, M, K, weight, bias, out, ldc, *, lda=None, epi=EPI_NONE, aux=N
     lda = K if lda is None else lda
     if x.dtype == torch.bfloat16:
         pw = prepared_weight(weight)
+        t0 = _timer.begin() if _timer is not None else None
         check(lib().mv_gemm_nt_bf16(_p(x), lda, _p(pw.w), pw.ldw, _p(out), ldc, _DT[out.dtype], M, N, K, _p(bias), epi,
                                     _p(aux), ld_aux, aux_i, _p(out2), ld_out2, _s()),
               "gemm_nt_bf16", M=M, N=N, K=K, epi=epi)
+        if t0 is not None:
+            _timer.end("gemm_nt_bf16", t0, 2.0 * M * N * K)
     else:
         w = weight.detach()
         check(lib().mv_gemm_f32(_p(x), lda, 1, 0, 0, _p(w), 1, w.stride(0), 0, 0, _p(out), ldc, 1, 0, 0, M, N, K, 1, 1,
@@ -153,8 +193,11 @@ def linear_dx(dy, M, N, weight, out, ldc, *, ld_dy=None, epi=EPI_NONE, aux=None,
     ld_dy = N if ld_dy is None else ld_dy
     if dy.dtype == torch.bfloat16:
         pw = prepared_weight(weight)
+        t0 = _timer.begin() if _timer is not None else None
         check(lib().mv_gemm_nt_bf16(_p(dy), ld_dy, _p(pw.wt), pw.ldt, _p(out), ldc, _DT[out.dtype], M, K, N, None, epi,
                                     _p(aux), ld_aux, 0, None, 0, _s()), "gemm_nt_bf16(dx)", M=M, N=K, K=N, epi=epi)
+        if t0 is not None:
+            _timer.end("gemm_nt_bf16", t0, 2.0 * M * N * K)
     else:
         w = weight.detach()
         check(lib().mv_gemm_f32(_p(dy), ld_dy, 1, 0, 0, _p(w), w.stride(0), 1, 0, 0, _p(out), ldc, 1, 0, 0, M, K, N, 1,
@@ -172,8 +215,11 @@ def linear_dw(dy, x, M, N, K, *, ld_dy=None, ldx=None, want_bias=True):
     if dy.dtype == torch.bfloat16:
         nbytes = lib().mv_gemm_tn_workspace_bytes(N, K, M)
         ws = workspace(nbytes, x.device)
+        t0 = _timer.begin() if _timer is not None else None
         check(lib().mv_gemm_tn_bf16(_p(dy), ld_dy, _p(x), ldx, _p(dw), K, N, K, M, 0, _p(db), _p(ws), ws.numel(), _s()),
               "gemm_tn_bf16", M=N, N=K, Kc=M)
+        if t0 is not None:
+            _timer.end("gemm_tn_bf16(+reduce+colsum)", t0, 2.0 * M * N * K)
     else:
         check(lib().mv_gemm_f32(_p(dy), 1, ld_dy, 0, 0, _p(x), ldx, 1, 0, 0, _p(dw), K, 1, 0, 0, N, K, M, 1, 1, 1.0, 0,
                                 None, EPI_NONE, None, 0, 0, None, 0, _s()), "gemm_f32(dw)", M=N, N=K, K=M)

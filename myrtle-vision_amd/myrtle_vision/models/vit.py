@@ -300,6 +300,13 @@ class ViT(nn.Module):
                 m.precision = precision
         return self
 
+    def unused_parameter_names(self):
+        """Parameters that never reach the loss for the classification / segmentation decoders: the detection
+        tokens are built but never concatenated (reference vit.py:285-290, ``self.decoder == "detection"`` is
+        always False).  The optimizer and the gradient all-reduce leave them alone, exactly as
+        torch.optim skips parameters whose ``.grad`` is None."""
+        return ("pos_embedding_det", "det_tokens")
+
     # -- positional embedding (reference vit.py:292-302) ---------------------------------------------------
     def _pos_embedding(self, gh: int, gw: int) -> torch.Tensor:
         """cls slot + 14x14 grid bicubically resized to (gh, gw).  At 224^2 the resize is the identity, and the

@@ -1,0 +1,178 @@
+"""Optimizer and LR schedule of the reference training loop on the HIP AdamW kernel.
+
+The reference builds them with ``timm.optim.create_optimizer`` / ``timm.scheduler.create_scheduler``
+(classification/train.py:161-166) from the namespace ``get_optimizer_args`` fills (utils/models.py:84-110).
+timm==0.5.4 is not available offline and the reference has no tests for it: the semantics below are a
+restatement (PARITY UNPINNED, see oracle/optim_oracle.py for the CPU restatement the tests compare with):
+
+* ``create_optimizer`` with opt="adamw": ``torch.optim.AdamW`` over two groups -- parameters with
+  ``ndim <= 1`` or a name ending in ``.bias`` get weight_decay 0, the rest ``weight_decay``; ViT defines no
+  ``no_weight_decay()`` so pos_embedding / cls_token ARE decayed.
+* ``create_scheduler`` with sched="cosine": ``CosineLRScheduler(t_initial=epochs, lr_min=min_lr,
+  warmup_lr_init=warmup_lr, warmup_t=warmup_epochs, cycle_limit=1, t_in_epochs=True)``, stepped with the
+  0-based epoch at epoch END (classification/train.py:287).
+
+MI355X-native layout: all trainable, *used* parameters live in ONE flat fp32 arena per weight-decay group
+(``ParamArena``); ``param.data`` and ``param.grad`` are views into it.  The optimizer step is then one kernel
+launch per group over 86 M contiguous elements (HBM-bound: 7 x 4 B per element), ``zero_grad`` is one memset, and
+the DDP gradient all-reduce (``utils/ddp.py``) works on contiguous slices of the same buffer with no packing.
+"""
+import math
+from typing import Iterable, List, Tuple
+
+import torch
+
+from myrtle_vision.hip import ops
+
+
+class ParamArena:
+    """Flat fp32 storage for parameters and their gradients, split into (decay, no_decay) regions."""
+
+    def __init__(self, named_params: Iterable[Tuple[str, torch.nn.Parameter]], skip=()):
+        named = [(n, p) for n, p in named_params if p.requires_grad and n not in set(skip)]
+        if not named:
+            raise ValueError("no trainable parameters")
+        dev = named[0][1].device
+        decay = [(n, p) for n, p in named if not (p.ndim <= 1 or n.endswith(".bias"))]
+        no_decay = [(n, p) for n, p in named if (p.ndim <= 1 or n.endswith(".bias"))]
+        self.names: List[str] = [n for n, _ in decay + no_decay]
+        self.params: List[torch.nn.Parameter] = [p for _, p in decay + no_decay]
+        # each tensor starts on a 16-byte boundary so kernels can use vector access on any slice
+        offs, total = [], 0
+        for _, p in decay + no_decay:
+            offs.append(total)
+            total += (p.numel() + 3) & ~3
+        self.n_decay = offs[len(decay)] if no_decay and decay else (total if decay else 0)
+        self.offsets, self.total = offs, total
+        self.flat_param = torch.zeros(total, dtype=torch.float32, device=dev)
+        self.flat_grad = torch.zeros(total, dtype=torch.float32, device=dev)
+        with torch.no_grad():
+            for p, o in zip(self.params, offs):
+                n = p.numel()
+                self.flat_param[o:o + n].copy_(p.detach().reshape(-1).float())
+                p.data = self.flat_param[o:o + n].view(p.shape)
+                p.grad = self.flat_grad[o:o + n].view(p.shape)
+
+    def zero_grad(self):
+        self.flat_grad.zero_()
+        for p, o in zip(self.params, self.offsets):     # re-attach if something set them to None
+            if p.grad is None or p.grad.data_ptr() != self.flat_grad.data_ptr() + 4 * o:
+                p.grad = self.flat_grad[o:o + p.numel()].view(p.shape)
+
+    def bump_versions(self):
+        """The AdamW kernel writes through raw pointers: tell autograd / the bf16 weight cache the data changed."""
+        for p in self.params:
+            torch.autograd.graph.increment_version(p)
+
+
+class AdamW:
+    """torch.optim.AdamW semantics on the fused HIP kernel over a ``ParamArena`` (one launch per decay group)."""
+
+    def __init__(self, arena: ParamArena, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.01):
+        self.arena = arena
+        self.defaults = dict(lr=lr, betas=tuple(betas), eps=eps, weight_decay=weight_decay)
+        nd = arena.n_decay
+        self.param_groups = [
+            dict(lr=lr, initial_lr=lr, weight_decay=weight_decay, range=(0, nd), name="decay"),
+            dict(lr=lr, initial_lr=lr, weight_decay=0.0, range=(nd, arena.total), name="no_decay"),
+        ]
+        self.exp_avg = torch.zeros_like(arena.flat_param)
+        self.exp_avg_sq = torch.zeros_like(arena.flat_param)
+        self.step_count = 0
+        self.grad_scale = 1.0            # e.g. 1/world_size after a SUM all-reduce
+
+    def zero_grad(self, set_to_none: bool = False):
+        self.arena.zero_grad()
+
+    @torch.no_grad()
+    def step(self):
+        self.step_count += 1
+        b1, b2 = self.defaults["betas"]
+        a = self.arena
+        for g in self.param_groups:
+            lo, hi = g["range"]
+            if hi > lo:
+                ops.adamw_step(a.flat_param[lo:hi], a.flat_grad[lo:hi], self.exp_avg[lo:hi], self.exp_avg_sq[lo:hi],
+                               lr=g["lr"], beta1=b1, beta2=b2, eps=self.defaults["eps"],
+                               weight_decay=g["weight_decay"], step=self.step_count, grad_scale=self.grad_scale)
+        a.bump_versions()
+
+    # checkpoint format: keyed by parameter NAME so it survives re-flattening
+    def state_dict(self):
+        a = self.arena
+        state = {}
+        for n, p, o in zip(a.names, a.params, a.offsets):
+            k = p.numel()
+            state[n] = {"exp_avg": self.exp_avg[o:o + k].view(p.shape).clone(),
+                        "exp_avg_sq": self.exp_avg_sq[o:o + k].view(p.shape).clone()}
+        return {"state": state, "step": self.step_count,
+                "param_groups": [{k: v for k, v in g.items() if k != "range"} for g in self.param_groups],
+                "defaults": self.defaults}
+
+    def load_state_dict(self, sd):
+        a = self.arena
+        for n, p, o in zip(a.names, a.params, a.offsets):
+            if n in sd["state"]:
+                k = p.numel()
+                self.exp_avg[o:o + k].copy_(sd["state"][n]["exp_avg"].reshape(-1))
+                self.exp_avg_sq[o:o + k].copy_(sd["state"][n]["exp_avg_sq"].reshape(-1))
+        self.step_count = sd["step"]
+        for g, s in zip(self.param_groups, sd["param_groups"]):
+            g.update({k: v for k, v in s.items() if k in ("lr", "initial_lr", "weight_decay")})
+
+
+class CosineLRScheduler:
+    """timm 0.5.4 ``CosineLRScheduler`` restated for cycle_limit=1, t_in_epochs=True, no noise, warmup_prefix False."""
+
+    def __init__(self, optimizer, t_initial, lr_min=0.0, warmup_t=0, warmup_lr_init=0.0):
+        self.optimizer = optimizer
+        self.t_initial, self.lr_min, self.warmup_t, self.warmup_lr_init = t_initial, lr_min, warmup_t, warmup_lr_init
+        self.base_values = [g["initial_lr"] for g in optimizer.param_groups]
+        if warmup_t:
+            self.warmup_steps = [(v - warmup_lr_init) / warmup_t for v in self.base_values]
+            self._update([warmup_lr_init for _ in self.base_values])   # timm sets warmup_lr_init at construction
+        else:
+            self.warmup_steps = [1 for _ in self.base_values]
+
+    def _get_lr(self, t):
+        if t < self.warmup_t:
+            return [self.warmup_lr_init + t * s for s in self.warmup_steps]
+        if t < self.t_initial:
+            return [self.lr_min + 0.5 * (v - self.lr_min) * (1 + math.cos(math.pi * t / self.t_initial))
+                    for v in self.base_values]
+        return [self.lr_min for _ in self.base_values]
+
+    def _update(self, values):
+        for g, v in zip(self.optimizer.param_groups, values):
+            g["lr"] = v
+
+    def step(self, epoch, metric=None):
+        self._update(self._get_lr(epoch))
+
+    def state_dict(self):
+        return {k: v for k, v in self.__dict__.items() if k != "optimizer"}
+
+    def load_state_dict(self, sd):
+        self.__dict__.update(sd)
+
+
+def create_optimizer(args, model, skip=None):
+    """Counterpart of ``timm.optim.create_optimizer(args, model)`` for the options the reference configs use."""
+    opt = str(args.opt).lower()
+    if opt != "adamw":
+        raise NotImplementedError(f"optimizer {args.opt!r}: only 'adamw' (every reference train_config) is implemented")
+    if skip is None:
+        skip = model.unused_parameter_names() if hasattr(model, "unused_parameter_names") else ()
+    arena = ParamArena(model.named_parameters(), skip=skip)
+    betas = tuple(args.opt_betas) if getattr(args, "opt_betas", None) else (0.9, 0.999)
+    eps = args.opt_eps if getattr(args, "opt_eps", None) is not None else 1e-8
+    return AdamW(arena, lr=args.lr, betas=betas, eps=eps, weight_decay=args.weight_decay)
+
+
+def create_scheduler(args, optimizer):
+    """Counterpart of ``timm.scheduler.create_scheduler(args, optimizer)`` -> (scheduler, num_epochs)."""
+    if str(args.sched).lower() != "cosine":
+        raise NotImplementedError(f"scheduler {args.sched!r}: only 'cosine' (every reference train_config) is implemented")
+    sched = CosineLRScheduler(optimizer, t_initial=args.epochs, lr_min=args.min_lr, warmup_t=args.warmup_epochs,
+                              warmup_lr_init=args.warmup_lr)
+    return sched, args.epochs + (getattr(args, "cooldown_epochs", 0) or 0)
