@@ -6,8 +6,15 @@
 //
 // Structure (both): 128x128 output tile per 256-thread workgroup (4 waves as 2x2, 64x64 per wave =
 // 4x4 MFMA tiles, 64 fp32 accumulator VGPRs), K-step 64, LDS double buffer (2 x 32 KiB, two workgroups
-// per CU), register-staged global->LDS copies issued one K-step ahead (loads of step t+2 are in flight
-// while step t+1 computes; the LDS write of t+1 happens after step t's barrier), one barrier per K-step.
+// per CU).  Two staging variants per kernel:
+//   *_glds_kernel (contraction length % 64 == 0: every ViT-B/Tiny layer at the benchmark sizes): tiles go
+//       HBM -> LDS directly with global_load_lds_dwordx4 (no VGPR round trip, no ds_write: the register-staged
+//       form measured LDS-WRITE bound, ds_write_b128 moves only ~79 B/clk/CU).  The LDS destination of one
+//       wave-instruction is lane-linear (1 KiB), so the XOR swizzle is applied to each lane's SOURCE address
+//       and to the fragment reads (same involution).  The load of K-step t+1 is issued before step t computes
+//       and retired by a COUNTED s_waitcnt vmcnt(8) + raw s_barrier, so it stays in flight across the MFMAs.
+//   *_kernel (register-staged fallback, any shape): global->VGPR loads issued one K-step ahead, zero-filled
+//       by select (never a conditional load), written to LDS after the barrier, one barrier per K-step.
 //
 // LDS images (checked with tools/lds_bank_sim.py against the gfx950 banking rules):
 //   NT: tiles are [128 rows][64 k] bf16 = 128-byte rows, 16-byte chunk index XORed with ((row>>1)&3)<<1.
@@ -22,6 +29,10 @@
 // Workgroup ids are remapped so the 8 XCDs each walk a contiguous run of tiles (n fastest): the blocks
 // sharing one A row-panel run on one XCD and hit its L2.
 #include "mv_common.h"
+
+#ifndef MV_ABLATE
+#define MV_ABLATE 0   // diagnostic builds only (tools/ablate_gemm.sh); 0 in the product
+#endif
 
 namespace {
 
@@ -62,6 +73,150 @@ __device__ __forceinline__ void store4(CT* p, const float v[4], bool vec, int nv
 #pragma unroll
     for (int r = 0; r < 4; ++r)
       if (r < nvalid) p[r] = (CT)v[r];
+  }
+}
+
+// ---- shared epilogue of the NT kernels.  Lane holds, for MFMA tile (i,j): row m = .. + (lane&15), 4 consecutive
+// columns n = .. + 4*(lane>>4) + 0..3 (the MFMA was issued transposed), so bias/aux/out are 8-/16-byte vectors.
+// erf to |err| <= 1.5e-7 (Abramowitz-Stegun 7.1.26) on v_rcp_f32 / v_exp_f32: ~13 VALU ops instead of libm erff's
+// branchy ~40.  Used only where the result is rounded to bf16 (2^-9) anyway; the fp32 parity path keeps erff.
+// Also returns e = exp(-u^2), which GELU' needs as its Gaussian factor.
+__device__ __forceinline__ float erf_fast(float u, float& e) {
+  const float au = fabsf(u);
+  const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f, au, 1.0f));
+  float p = fmaf(1.061405429f, t, -1.453152027f);
+  p = fmaf(p, t, 1.421413741f);
+  p = fmaf(p, t, -0.284496736f);
+  p = fmaf(p, t, 0.254829592f);
+  e = __builtin_amdgcn_exp2f(-1.4426950408889634f * u * u);
+  return copysignf(fmaf(-p * t, e, 1.0f), u);
+}
+__device__ __forceinline__ float gelu_fast(float x) {
+  float e;
+  return 0.5f * x * (1.0f + erf_fast(x * 0.70710678118654752440f, e));
+}
+__device__ __forceinline__ float dgelu_fast(float x) {
+  float e;
+  const float cdf = 0.5f * (1.0f + erf_fast(x * 0.70710678118654752440f, e));
+  return fmaf(x * 0.39894228040143267794f, e, cdf);          // e = exp(-x^2 / 2)
+}
+
+// ---- shared epilogue of the NT kernels.  Lane holds, for MFMA tile (i,j): row m = .. + (lane&15), 4 consecutive
+// columns n = .. + 4*(lane>>4) + 0..3 (the MFMA was issued transposed), so bias/aux/out are 8-/16-byte vectors.
+// Interior tiles take the fast path: ALL bias/aux vectors are loaded before the first store.  (aux and C are
+// different buffers by contract, but the compiler cannot know, and interleaving "load aux, store C" serialises
+// sixteen HBM round trips per lane: the +residual GEMM measured 242 TFLOP/s that way.)
+template <int EPI, typename CT>
+__device__ __forceinline__ void nt_epilogue(f32x4 (&acc)[4][4], CT* __restrict__ C, int ldc, int M, int N, int m0, int n0,
+                                            int wm, int wn, int lane, const EpiArgs& ep) {
+  // (m0, n0) = origin of the 128x128 region this call covers; wave (wm, wn) owns its 64x64 quadrant
+  const bool interior = (m0 + BM <= M) && (n0 + BN <= N) && ((ldc & 3) == 0) && ((ep.ld_aux & 3) == 0) &&
+                        ((ep.ld_out2 & 3) == 0) && ((reinterpret_cast<uintptr_t>(ep.bias) & 15) == 0);
+  if (interior) {
+    const int mb = m0 + wm * 64 + (lane & 15), nb = n0 + wn * 64 + 4 * (lane >> 4);
+    float4 bv[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+      bv[j] = ep.bias ? *reinterpret_cast<const float4*>(ep.bias + nb + j * 16) : make_float4(0.f, 0.f, 0.f, 0.f);
+    long crow[4];
+    int prow[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int m = mb + i * 16;
+      crow[i] = m;
+      prow[i] = 0;
+      if constexpr (EPI == MV_EPI_EMBED) {
+        const int img = m / ep.aux_i;
+        prow[i] = 1 + (m - img * ep.aux_i);
+        crow[i] = (long)img * (ep.aux_i + 1) + prow[i];
+      }
+    }
+    float4 ax[4][4];
+    if constexpr (EPI == MV_EPI_RESIDUAL || EPI == MV_EPI_EMBED) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const long arow = (EPI == MV_EPI_EMBED) ? prow[i] : (mb + i * 16);
+          ax[i][j] = *reinterpret_cast<const float4*>(reinterpret_cast<const float*>(ep.aux) + arow * ep.ld_aux + nb + j * 16);
+        }
+    } else if constexpr (EPI == MV_EPI_DGELU) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const bf16x4 h = *reinterpret_cast<const bf16x4*>(reinterpret_cast<const bf16_t*>(ep.aux) +
+                                                             (long)(mb + i * 16) * ep.ld_aux + nb + j * 16);
+          ax[i][j] = make_float4((float)h[0], (float)h[1], (float)h[2], (float)h[3]);
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        float v[4] = {acc[i][j][0] + bv[j].x, acc[i][j][1] + bv[j].y, acc[i][j][2] + bv[j].z, acc[i][j][3] + bv[j].w};
+        const int n = nb + j * 16;
+        if constexpr (EPI == MV_EPI_GELU) {
+          if (ep.out2) store4(reinterpret_cast<bf16_t*>(ep.out2) + (long)(mb + i * 16) * ep.ld_out2 + n, v, true, 4);
+#pragma unroll
+          for (int r = 0; r < 4; ++r) v[r] = gelu_fast(v[r]);
+        } else if constexpr (EPI == MV_EPI_RESIDUAL || EPI == MV_EPI_EMBED) {
+          v[0] += ax[i][j].x; v[1] += ax[i][j].y; v[2] += ax[i][j].z; v[3] += ax[i][j].w;
+        } else if constexpr (EPI == MV_EPI_DGELU) {
+          v[0] *= dgelu_fast(ax[i][j].x); v[1] *= dgelu_fast(ax[i][j].y);
+          v[2] *= dgelu_fast(ax[i][j].z); v[3] *= dgelu_fast(ax[i][j].w);
+        }
+        store4(C + crow[i] * ldc + n, v, true, 4);
+      }
+    return;
+  }
+  // ---- edge tiles: bounds-checked, element-wise where needed
+  const bool ldc_vec = (ldc & 3) == 0;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int m = m0 + wm * 64 + i * 16 + (lane & 15);
+    if (m >= M) continue;
+    long crow = m;
+    int patch = 0;
+    if constexpr (EPI == MV_EPI_EMBED) {
+      const int img = m / ep.aux_i;
+      patch = m - img * ep.aux_i;
+      crow = (long)img * (ep.aux_i + 1) + 1 + patch;
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int n = n0 + wn * 64 + j * 16 + 4 * (lane >> 4);
+      if (n >= N) continue;
+      const int nvalid = (N - n) >= 4 ? 4 : (N - n);
+      const bool vec = ldc_vec && nvalid == 4;
+      float v[4] = {acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]};
+      if (ep.bias) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+          if (r < nvalid) v[r] += ep.bias[n + r];
+      }
+      if constexpr (EPI == MV_EPI_GELU) {
+        if (ep.out2) store4(reinterpret_cast<bf16_t*>(ep.out2) + (long)m * ep.ld_out2 + n, v, vec && (ep.ld_out2 & 3) == 0, nvalid);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[r] = gelu_fast(v[r]);
+      } else if constexpr (EPI == MV_EPI_RESIDUAL) {
+        const float* ax = reinterpret_cast<const float*>(ep.aux) + (long)m * ep.ld_aux + n;
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+          if (r < nvalid) v[r] += ax[r];
+      } else if constexpr (EPI == MV_EPI_DGELU) {
+        const bf16_t* ax = reinterpret_cast<const bf16_t*>(ep.aux) + (long)m * ep.ld_aux + n;
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+          if (r < nvalid) v[r] *= dgelu_fast((float)ax[r]);
+      } else if constexpr (EPI == MV_EPI_EMBED) {
+        const float* ax = reinterpret_cast<const float*>(ep.aux) + (long)(1 + patch) * ep.ld_aux + n;
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+          if (r < nvalid) v[r] += ax[r];
+      }
+      store4(C + crow * ldc + n, v, vec, nvalid);
+    }
   }
 }
 
@@ -165,55 +320,334 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(const bf16_t* __restric
 #undef NT_LOAD_TILE
 #undef NT_STORE_TILE
 
-  // ---- epilogue: lane holds, for tile (i,j): row m = .. + (lane&15), cols n = .. + 4*(lane>>4) + 0..3
+  nt_epilogue<EPI, CT>(acc, C, ldc, M, N, m0, n0, wm, wn, lane, ep);
+}
+
+// ------------------------------------------------------------------------------------------------
+// NT kernel, direct-to-LDS staging (K % 64 == 0)
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ void glds16(const void* gsrc, void* lds_wave_base) {
+  // 16 B per lane; LDS destination = wave-uniform base (M0) + lane * 16
+  __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gsrc,
+                                   (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
+}
+
+template <int EPI, typename CT>
+__global__ __launch_bounds__(256, 2) void gemm_nt_glds_kernel(const bf16_t* __restrict__ A, int lda,
+                                                              const bf16_t* __restrict__ B, int ldb, CT* __restrict__ C,
+                                                              int ldc, int M, int N, int K, int tiles_n, EpiArgs ep) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int t = xcd_remap(blockIdx.x, gridDim.x);
+  const int m0 = (t / tiles_n) * BM, n0 = (t % tiles_n) * BN;
+
+  // Wave w stages rows [32w, 32w+32) of both tiles: 4 wave-instructions of 8 rows x 128 B each.  Lane L lands at
+  // LDS (row 8i + L/8, physical chunk L%8) and therefore fetches LOGICAL chunk (L%8) ^ swz(row) of that row.
+  // Rows beyond M / N are clamped to the last valid row (their products only reach outputs that are never stored).
+  const bf16_t* pa[4];
+  const bf16_t* pb[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int row = 32 * wave + 8 * i + (lane >> 3);
+    const int ch = (lane & 7) ^ (((row >> 1) & 3) << 1);
+    const int ar = m0 + row < M ? m0 + row : M - 1, br = n0 + row < N ? n0 + row : N - 1;
+    pa[i] = A + (long)ar * lda + ch * 8;
+    pb[i] = B + (long)br * ldb + ch * 8;
+  }
+  char* const wave_lds = smem + 32 * wave * 128;
+#define NT_ISSUE(stage_, kt_)                                                          \
+  {                                                                                    \
+    char* la_ = wave_lds + (stage_) * STAGE_BYTES;                                     \
+    char* lb_ = la_ + BM * BK * 2;                                                     \
+    const int ko_ = (kt_) * BK;                                                        \
+    glds16(pa[0] + ko_, la_);          glds16(pa[1] + ko_, la_ + 1024);                \
+    glds16(pa[2] + ko_, la_ + 2048);   glds16(pa[3] + ko_, la_ + 3072);                \
+    glds16(pb[0] + ko_, lb_);          glds16(pb[1] + ko_, lb_ + 1024);                \
+    glds16(pb[2] + ko_, lb_ + 2048);   glds16(pb[3] + ko_, lb_ + 3072);                \
+  }
+
+  f32x4 acc[4][4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  const int nk = K / BK;
+  const int frow = lane & 15, fch = lane >> 4;
+  NT_ISSUE(0, 0)
+  for (int kt = 0; kt < nk; ++kt) {
+    const int cur = kt & 1;
+    if (kt + 1 < nk) {
+      NT_ISSUE(cur ^ 1, kt + 1)                                  // stays in flight across this step's MFMAs
+      asm volatile("s_waitcnt vmcnt(8)" ::: "memory");         // all but the 8 youngest: this step's tile has landed
+    } else {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    __builtin_amdgcn_s_barrier();                                // every wave's share of the tile is visible
+    asm volatile("" ::: "memory");
+    const char* sa = smem + cur * STAGE_BYTES;
+    const char* sb = sa + BM * BK * 2;
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      bf16x8 af[4], bfr[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        af[i] = *reinterpret_cast<const bf16x8*>(sa + sw128(wm * 64 + i * 16 + frow, 4 * ks + fch));
+        bfr[i] = *reinterpret_cast<const bf16x8*>(sb + sw128(wn * 64 + i * 16 + frow, 4 * ks + fch));
+      }
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[j], af[i], acc[i][j], 0, 0, 0);
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");           // this wave's LDS reads have returned ...
+    __builtin_amdgcn_s_barrier();                                // ... before any wave's next DMA overwrites the stage
+  }
+#undef NT_ISSUE
+  nt_epilogue<EPI, CT>(acc, C, ldc, M, N, m0, n0, wm, wn, lane, ep);
+}
+
+// ------------------------------------------------------------------------------------------------
+// NT kernel, 256x256 tile, direct-to-LDS staging (K % 64 == 0, large N)
+// ------------------------------------------------------------------------------------------------
+// The 128x128 kernel is bound by (bytes in flight) / (DMA latency): one 32 KiB stage per workgroup in flight against
+// ~1.5 us of loaded latency (measured: 3,170 cycles per K-step vs 512 cycles of MFMA per wave, MFMA pipe 32 % busy).
+// LDS is the in-flight buffer, so the lever is FLOPs per staged byte: a 256x256 tile does 2x the MFMA work of the
+// 128x128 tile per byte brought into LDS and per byte read out of it (per wave 128x64 = 8x4 MFMA tiles: 12 fragment
+// reads feed 32 MFMAs instead of 8 feeding 16).  8 waves (2 per SIMD, one workgroup per CU), 2 x 64 KiB stages.
+constexpr int BM2 = 256, BN2 = 256;
+constexpr int STAGE2_BYTES = (BM2 + BN2) * BK * 2;  // 64 KiB
+constexpr int SMEM2_BYTES = 2 * STAGE2_BYTES;       // 128 KiB
+
+template <int EPI, typename CT>
+__global__ __launch_bounds__(512, 2) void gemm_nt_glds256_kernel(const bf16_t* __restrict__ A, int lda,
+                                                                 const bf16_t* __restrict__ B, int ldb, CT* __restrict__ C,
+                                                                 int ldc, int M, int N, int K, int tiles_n, EpiArgs ep) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 2, wn = wave & 3;           // wave tile: rows [128 wm, +128), cols [64 wn, +64)
+  const int t = xcd_remap(blockIdx.x, gridDim.x);
+  const int m0 = (t / tiles_n) * BM2, n0 = (t % tiles_n) * BN2;
+
+  // wave w stages rows [32w, 32w+32) of both 256-row tiles: 4 + 4 wave-instructions per K-step
+  const bf16_t* pa[4];
+  const bf16_t* pb[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int row = 32 * wave + 8 * i + (lane >> 3);
+    const int ch = (lane & 7) ^ (((row >> 1) & 3) << 1);
+    const int ar = m0 + row < M ? m0 + row : M - 1, br = n0 + row < N ? n0 + row : N - 1;
+    pa[i] = A + (long)ar * lda + ch * 8;
+    pb[i] = B + (long)br * ldb + ch * 8;
+  }
+  char* const wave_lds = smem + 32 * wave * 128;
+#define NT2_ISSUE(stage_, kt_)                                                         \
+  {                                                                                    \
+    char* la_ = wave_lds + (stage_) * STAGE2_BYTES;                                    \
+    char* lb_ = la_ + BM2 * BK * 2;                                                    \
+    const int ko_ = (kt_) * BK;                                                        \
+    glds16(pa[0] + ko_, la_);          glds16(pa[1] + ko_, la_ + 1024);                \
+    glds16(pa[2] + ko_, la_ + 2048);   glds16(pa[3] + ko_, la_ + 3072);                \
+    glds16(pb[0] + ko_, lb_);          glds16(pb[1] + ko_, lb_ + 1024);                \
+    glds16(pb[2] + ko_, lb_ + 2048);   glds16(pb[3] + ko_, lb_ + 3072);                \
+  }
+
+  f32x4 acc[8][4];
+#pragma unroll
+  for (int i = 0; i < 8; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  const int nk = K / BK;
+  const int frow = lane & 15, fch = lane >> 4;
+  NT2_ISSUE(0, 0)
+  for (int kt = 0; kt < nk; ++kt) {
+    const int cur = kt & 1;
+#if MV_ABLATE == 1
+    if (false) {
+#else
+    if (kt + 1 < nk) {
+#endif
+      NT2_ISSUE(cur ^ 1, kt + 1)
+      asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    } else {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    const char* sa = smem + cur * STAGE2_BYTES + wm * 128 * 128;
+    const char* sb = smem + cur * STAGE2_BYTES + BM2 * BK * 2 + wn * 64 * 128;
+#if MV_ABLATE != 2
+#pragma unroll
+#else
+#pragma unroll
+    for (int ks = 0; ks < 0; ++ks) {}
+    if (false)
+#endif
+    for (int ks = 0; ks < 2; ++ks) {
+      bf16x8 bfr[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) bfr[j] = *reinterpret_cast<const bf16x8*>(sb + sw128(j * 16 + frow, 4 * ks + fch));
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        const bf16x8 af = *reinterpret_cast<const bf16x8*>(sa + sw128(i * 16 + frow, 4 * ks + fch));
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[j], af, acc[i][j], 0, 0, 0);
+      }
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+  }
+#undef NT2_ISSUE
+  // epilogue in two 64-row halves of the wave tile (keeps the hoisted aux vectors within the register budget);
+  // nt_epilogue addresses a 128x128 region with a 2x2 wave grid, so present this wave as quadrant (h, wn & 1) of the
+  // region whose origin is (m0 + 128 wm, n0 + 128 (wn >> 1))
+#pragma unroll
+  for (int h = 0; h < 2; ++h)
+    nt_epilogue<EPI, CT>(*reinterpret_cast<f32x4(*)[4][4]>(&acc[4 * h]), C, ldc, M, N, m0 + 128 * wm, n0 + 128 * (wn >> 1), h,
+                         wn & 1, lane, ep);
+}
+
+// ------------------------------------------------------------------------------------------------
+// NT kernel, 256x256 tile, LDS RING of S stages of BK = 32 (K % 32 == 0)
+// ------------------------------------------------------------------------------------------------
+// Ablation of the 2-stage 256x256 kernel (K = 3072): compute alone 1130 TFLOP/s-equivalent, DMA alone 1206, both 782:
+// with ONE 64 KiB stage in flight the DMA side is latency-bound (64 KiB per ~2,700 cycles = 24 B/clk/CU) and overlaps
+// the MFMA side poorly.  Here the same LDS holds a ring of S stages of 32 KiB (A 256x32 + B 256x32): S-1 stages
+// (96-128 KiB) are in flight while one is consumed, retired by a counted s_waitcnt vmcnt(4 (S-2)), and ONE barrier per
+// stage both publishes stage t and frees stage t-1 for the next DMA.  Rows are 64 bytes here; the conflict-free
+// swizzle for ds_read_b128 fragment reads of 64-byte rows is chunk ^= ((row>>3)&1)<<1 (tools/lds_bank_sim.py).
+constexpr int BKR = 32;
+constexpr int RSTAGE_BYTES = (BM2 + BN2) * BKR * 2;  // 32 KiB
+
+template <int EPI, typename CT, int S>
+__global__ __launch_bounds__(512, 2) void gemm_nt_ring_kernel(const bf16_t* __restrict__ A, int lda,
+                                                              const bf16_t* __restrict__ B, int ldb, CT* __restrict__ C,
+                                                              int ldc, int M, int N, int K, int tiles_n, EpiArgs ep) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 2, wn = wave & 3;
+  const int t = xcd_remap(blockIdx.x, gridDim.x);
+  const int m0 = (t / tiles_n) * BM2, n0 = (t % tiles_n) * BN2;
+
+  // wave w stages rows [32w, 32w+32) of both tiles: 2 + 2 wave-instructions (16 rows x 64 B each) per stage
+  const bf16_t* pa[2];
+  const bf16_t* pb[2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int row = 32 * wave + 16 * i + (lane >> 2);
+    const int ch = (lane & 3) ^ (((row >> 3) & 1) << 1);
+    const int ar = m0 + row < M ? m0 + row : M - 1, br = n0 + row < N ? n0 + row : N - 1;
+    pa[i] = A + (long)ar * lda + ch * 8;
+    pb[i] = B + (long)br * ldb + ch * 8;
+  }
+  char* const wave_lds = smem + 32 * wave * 64;
+#define RING_ISSUE(slot_, kt_)                                                         \
+  {                                                                                    \
+    char* la_ = wave_lds + (slot_) * RSTAGE_BYTES;                                     \
+    char* lb_ = la_ + BM2 * BKR * 2;                                                   \
+    const int ko_ = (kt_) * BKR;                                                       \
+    glds16(pa[0] + ko_, la_);   glds16(pa[1] + ko_, la_ + 1024);                       \
+    glds16(pb[0] + ko_, lb_);   glds16(pb[1] + ko_, lb_ + 1024);                       \
+  }
+
+  f32x4 acc[8][4];
+#pragma unroll
+  for (int i = 0; i < 8; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  const int nk = K / BKR;
+  // fragment read offset of this lane inside a 16-row x 64-byte block (constant: the swizzle bit is (row>>3)&1)
+  const int frag_off = (lane & 15) * 64 + (((lane >> 4) ^ (((lane >> 3) & 1) << 1)) << 4);
+#pragma unroll
+  for (int s = 0; s < S - 1; ++s)
+    if (s < nk) RING_ISSUE(s, s)
+  int slot = 0, fill = S - 1;                  // slot of stage kt; slot that the next DMA goes to
+#define RING_SYNC(kt_)                                                                                     \
+  {                                                                                                        \
+    if ((kt_) + S - 2 < nk) {                                                                              \
+      asm volatile("s_waitcnt vmcnt(%0)" ::"n"(4 * (S - 2)) : "memory"); /* stage kt landed */            \
+    } else {                                                                                               \
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                                     \
+    }                                                                                                      \
+    __builtin_amdgcn_s_barrier(); /* stage kt visible to all; every wave is done READING stage kt-1 */     \
+    asm volatile("" ::: "memory");                                                                         \
+    if ((kt_) + S - 1 < nk) RING_ISSUE(fill, (kt_) + S - 1) /* refill the slot stage kt-1 lived in */      \
+  }
+#define RING_READ()                                                                                        \
+  {                                                                                                        \
+    const char* sa_ = smem + slot * RSTAGE_BYTES + wm * 128 * 64 + frag_off;                               \
+    const char* sb_ = smem + slot * RSTAGE_BYTES + BM2 * BKR * 2 + wn * 64 * 64 + frag_off;                \
+    _Pragma("unroll") for (int j = 0; j < 4; ++j) bfr[j] = *reinterpret_cast<const bf16x8*>(sb_ + j * 1024); \
+    _Pragma("unroll") for (int i = 0; i < 8; ++i) af[i] = *reinterpret_cast<const bf16x8*>(sa_ + i * 1024);  \
+  }
+#define RING_MFMA()                                                                                        \
+  {                                                                                                        \
+    _Pragma("unroll") for (int i = 0; i < 8; ++i)                                                          \
+      _Pragma("unroll") for (int j = 0; j < 4; ++j)                                                        \
+        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[j], af[i], acc[i][j], 0, 0, 0);            \
+  }
+#define RING_ADVANCE()                                                                                     \
+  {                                                                                                        \
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); /* this stage's reads returned before its slot is refilled */ \
+    slot = (slot + 1 == S) ? 0 : slot + 1;                                                                 \
+    fill = (fill + 1 == S) ? 0 : fill + 1;                                                                 \
+  }
+  bf16x8 af[8], bfr[4];
+  // The two waves that share a SIMD (w and w+4) would otherwise move in lockstep between barriers: both read LDS
+  // (matrix pipe idle), then both issue MFMAs.  Waves 4-7 therefore run ONE STAGE BEHIND in their MFMAs: inside
+  // barrier interval t they first issue the MFMAs of stage t-1 (fragments kept in registers across the barrier),
+  // then read stage t -- while waves 0-3 read stage t first and then issue its MFMAs.  Reads of one group overlap
+  // MFMAs of the other; results are unchanged (same products, same order per accumulator).
+  if (__builtin_amdgcn_readfirstlane(wave) < 4) {
+    for (int kt = 0; kt < nk; ++kt) {
+      RING_SYNC(kt)
+      RING_READ()
+      RING_MFMA()
+      RING_ADVANCE()
+    }
+  } else {
+    for (int kt = 0; kt < nk; ++kt) {
+      RING_SYNC(kt)
+      if (kt > 0) RING_MFMA()
+      RING_READ()
+      RING_ADVANCE()
+    }
+    if (nk > 0) RING_MFMA()
+  }
+#undef RING_SYNC
+#undef RING_READ
+#undef RING_MFMA
+#undef RING_ADVANCE
+#undef RING_ISSUE
+#pragma unroll
+  for (int h = 0; h < 2; ++h)
+    nt_epilogue<EPI, CT>(*reinterpret_cast<f32x4(*)[4][4]>(&acc[4 * h]), C, ldc, M, N, m0 + 128 * wm, n0 + 128 * (wn >> 1), h,
+                         wn & 1, lane, ep);
+}
+
+__device__ __forceinline__ void tn_store(f32x4 (&acc)[4][4], float* __restrict__ Cs, long ldc, int M, int N, int m0, int n0,
+                                         int wm, int wn, int lane) {
   const bool ldc_vec = (ldc & 3) == 0;
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
     const int m = m0 + wm * 64 + i * 16 + (lane & 15);
     if (m >= M) continue;
-    long crow = m;
-    int patch = 0;
-    if constexpr (EPI == MV_EPI_EMBED) {
-      const int img = m / ep.aux_i;
-      patch = m - img * ep.aux_i;
-      crow = (long)img * (ep.aux_i + 1) + 1 + patch;
-    }
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
       const int n = n0 + wn * 64 + j * 16 + 4 * (lane >> 4);
       if (n >= N) continue;
       const int nvalid = (N - n) >= 4 ? 4 : (N - n);
-      const bool vec = ldc_vec && nvalid == 4;
-      float v[4] = {acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]};
-      if (ep.bias) {
-#pragma unroll
-        for (int r = 0; r < 4; ++r)
-          if (r < nvalid) v[r] += ep.bias[n + r];
-      }
-      if constexpr (EPI == MV_EPI_GELU) {
-        if (ep.out2) store4(reinterpret_cast<bf16_t*>(ep.out2) + (long)m * ep.ld_out2 + n, v, vec && (ep.ld_out2 & 3) == 0, nvalid);
-#pragma unroll
-        for (int r = 0; r < 4; ++r) v[r] = gelu_f(v[r]);
-      } else if constexpr (EPI == MV_EPI_RESIDUAL) {
-        const float* ax = reinterpret_cast<const float*>(ep.aux) + (long)m * ep.ld_aux + n;
-#pragma unroll
-        for (int r = 0; r < 4; ++r)
-          if (r < nvalid) v[r] += ax[r];
-      } else if constexpr (EPI == MV_EPI_DGELU) {
-        const bf16_t* ax = reinterpret_cast<const bf16_t*>(ep.aux) + (long)m * ep.ld_aux + n;
-#pragma unroll
-        for (int r = 0; r < 4; ++r)
-          if (r < nvalid) v[r] *= dgelu_f((float)ax[r]);
-      } else if constexpr (EPI == MV_EPI_EMBED) {
-        const float* ax = reinterpret_cast<const float*>(ep.aux) + (long)(1 + patch) * ep.ld_aux + n;
-#pragma unroll
-        for (int r = 0; r < 4; ++r)
-          if (r < nvalid) v[r] += ax[r];
-      }
-      store4(C + crow * ldc + n, v, vec, nvalid);
+      const float v[4] = {acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]};
+      store4(Cs + (long)m * ldc + n, v, ldc_vec && nvalid == 4, nvalid);
     }
   }
 }
+
 
 // ------------------------------------------------------------------------------------------------
 // TN kernel: slab[s][M][N] = sum over this split's kc of A[kc][m] * B[kc][n]
@@ -324,20 +758,97 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_kernel(const bf16_t* __restric
 #undef TN_LOAD_TILE
 #undef TN_STORE_TILE
 
-  const bool ldc_vec = (ldc & 3) == 0;
+  tn_store(acc, Cs, ldc, M, N, m0, n0, wm, wn, lane);
+}
+
+// TN kernel, direct-to-LDS staging (Kc % 64 == 0): same product, tiles [64 kc][128 cols] = 256-byte rows; one
+// wave-instruction covers 4 rows.  Columns beyond the operand's width are clamped to chunk 0 (outputs never stored).
+__global__ __launch_bounds__(256, 2) void gemm_tn_glds_kernel(const bf16_t* __restrict__ A, int lda,
+                                                              const bf16_t* __restrict__ B, int ldb, float* __restrict__ C,
+                                                              long ldc, long slab_stride, int M, int N, int Kc, int tiles_n,
+                                                              int tiles_mn, int steps_per_split) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int t_all = xcd_remap(blockIdx.x, gridDim.x);
+  const int split = t_all / tiles_mn;
+  const int t = t_all - split * tiles_mn;
+  const int m0 = (t / tiles_n) * BM, n0 = (t % tiles_n) * BN;
+  const int nk_total = Kc / BK;
+  const int kt0 = split * steps_per_split;
+  int nk = nk_total - kt0;
+  if (nk > steps_per_split) nk = steps_per_split;
+  float* Cs = C + (long)split * slab_stride;
+
+  // wave w stages kc rows [16w, 16w+16) of both tiles: 4 wave-instructions of 4 rows x 256 B
+  const bf16_t* pa[4];
+  const bf16_t* pb[4];
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
-    const int m = m0 + wm * 64 + i * 16 + (lane & 15);
-    if (m >= M) continue;
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const int n = n0 + wn * 64 + j * 16 + 4 * (lane >> 4);
-      if (n >= N) continue;
-      const int nvalid = (N - n) >= 4 ? 4 : (N - n);
-      const float v[4] = {acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]};
-      store4(Cs + (long)m * ldc + n, v, ldc_vec && nvalid == 4, nvalid);
-    }
+    const int row = 16 * wave + 4 * i + (lane >> 4);
+    const int ch = (lane & 15) ^ (((row & 3) << 2) | ((row >> 2) & 3));
+    const int ca = (m0 + ch * 8 + 8 <= lda) ? m0 + ch * 8 : 0, cb = (n0 + ch * 8 + 8 <= ldb) ? n0 + ch * 8 : 0;
+    pa[i] = A + (long)(kt0 * BK + row) * lda + ca;
+    pb[i] = B + (long)(kt0 * BK + row) * ldb + cb;
   }
+  char* const wave_lds = smem + 16 * wave * 256;
+  const long astep = (long)BK * lda, bstep = (long)BK * ldb;
+#define TN_ISSUE(stage_, kt_)                                                          \
+  {                                                                                    \
+    char* la_ = wave_lds + (stage_) * STAGE_BYTES;                                     \
+    char* lb_ = la_ + BK * BM * 2;                                                     \
+    const long ao_ = (kt_) * astep, bo_ = (kt_) * bstep;                               \
+    glds16(pa[0] + ao_, la_);          glds16(pa[1] + ao_, la_ + 1024);                \
+    glds16(pa[2] + ao_, la_ + 2048);   glds16(pa[3] + ao_, la_ + 3072);                \
+    glds16(pb[0] + bo_, lb_);          glds16(pb[1] + bo_, lb_ + 1024);                \
+    glds16(pb[2] + bo_, lb_ + 2048);   glds16(pb[3] + bo_, lb_ + 3072);                \
+  }
+
+  f32x4 acc[4][4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  const int g = lane >> 4, q = (lane >> 2) & 3, p = lane & 3;
+  if (nk > 0) TN_ISSUE(0, 0)
+  for (int kt = 0; kt < nk; ++kt) {
+    const int cur = kt & 1;
+    if (kt + 1 < nk) {
+      TN_ISSUE(cur ^ 1, kt + 1)
+      asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    } else {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    const char* sa = smem + cur * STAGE_BYTES;
+    const char* sb = sa + BK * BM * 2;
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      bf16x8 af[4], bfr[4];
+      const int r0 = 32 * ks + 8 * g + q;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int ca = (wm * 64 + i * 16) >> 3, cb = (wn * 64 + i * 16) >> 3;
+        const bf16x4 a0 = __builtin_amdgcn_ds_read_tr16_b64_v4bf16(LDS_PTR(bf16x4, sa + sw256(r0, ca + (p >> 1)) + 8 * (p & 1)));
+        const bf16x4 a1 = __builtin_amdgcn_ds_read_tr16_b64_v4bf16(LDS_PTR(bf16x4, sa + sw256(r0 + 4, ca + (p >> 1)) + 8 * (p & 1)));
+        const bf16x4 b0 = __builtin_amdgcn_ds_read_tr16_b64_v4bf16(LDS_PTR(bf16x4, sb + sw256(r0, cb + (p >> 1)) + 8 * (p & 1)));
+        const bf16x4 b1 = __builtin_amdgcn_ds_read_tr16_b64_v4bf16(LDS_PTR(bf16x4, sb + sw256(r0 + 4, cb + (p >> 1)) + 8 * (p & 1)));
+        af[i] = __builtin_shufflevector(a0, a1, 0, 1, 2, 3, 4, 5, 6, 7);
+        bfr[i] = __builtin_shufflevector(b0, b1, 0, 1, 2, 3, 4, 5, 6, 7);
+      }
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[j], af[i], acc[i][j], 0, 0, 0);
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+  }
+#undef TN_ISSUE
+  tn_store(acc, Cs, ldc, M, N, m0, n0, wm, wn, lane);
 }
 
 // C[m][n] = (accumulate ? C : 0) + sum_s slab[s][m][n]   (fixed order: deterministic)
@@ -391,14 +902,6 @@ __global__ __launch_bounds__(256) void colsum_partial_kernel(const T* __restrict
   }
 }
 
-__global__ void colsum_finish_kernel(const float* __restrict__ partial, int nparts, int cols, float* out, int accumulate) {
-  const int c = blockIdx.x * blockDim.x + threadIdx.x;
-  if (c >= cols) return;
-  float s = 0.f;
-  for (int k = 0; k < nparts; ++k) s += partial[(long)k * cols + c];
-  out[c] = accumulate ? (out[c] + s) : s;
-}
-
 int colsum_parts(long rows) {
   long p = (rows + 255) / 256;
   if (p < 1) p = 1;
@@ -437,11 +940,34 @@ int set_smem(K kernel) {
 template <int EPI, typename CT>
 int launch_nt(const void* A, int lda, const void* B, int ldb, void* C, int ldc, int M, int N, int K, EpiArgs ep,
               hipStream_t s) {
-  static const int attr = set_smem(gemm_nt_kernel<EPI, CT>);
+  static const int attr = set_smem(gemm_nt_kernel<EPI, CT>) | set_smem(gemm_nt_glds_kernel<EPI, CT>) |
+                          (hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_nt_glds256_kernel<EPI, CT>),
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, SMEM2_BYTES) == hipSuccess ? 0 : -1);
   if (attr != 0) return MV_ERR_LAUNCH;
   const int tiles_m = mv_cdiv(M, BM), tiles_n = mv_cdiv(N, BN);
-  gemm_nt_kernel<EPI, CT><<<tiles_m * tiles_n, 256, SMEM_BYTES, s>>>((const bf16_t*)A, lda, (const bf16_t*)B, ldb,
-                                                                      (CT*)C, ldc, M, N, K, tiles_n, ep);
+  const int t2m = mv_cdiv(M, BM2), t2n = mv_cdiv(N, BN2);
+  // Kernel choice (measured on MI355X, tools/bench_gemm.py, M = 50432): the 256x256 ring kernel wins whenever its
+  // grid fills the chip for >= 4 rounds (N >= 1536) or K is long enough to amortise its fill/drain (K >= 2048);
+  // otherwise two 128x128 workgroups per CU overlap each other's epilogues better.  MV_GEMM_TILE = 128 | 256 | 2564
+  // forces a variant (tuning and tests).
+  static const int force = getenv("MV_GEMM_TILE") ? atoi(getenv("MV_GEMM_TILE")) : 0;
+  const bool ring_ok = K > 0 && K % BKR == 0;
+  const bool ring_pick = ring_ok && ((long)t2m * t2n >= 1024 || (K >= 2048 && (long)t2m * t2n >= 256));
+  if ((force == 2564 && ring_ok) || (force == 0 && ring_pick)) {
+    static const int a4 = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_nt_ring_kernel<EPI, CT, 4>),
+                                              hipFuncAttributeMaxDynamicSharedMemorySize, 4 * RSTAGE_BYTES) == hipSuccess ? 0 : -1;
+    if (a4) return MV_ERR_LAUNCH;
+    gemm_nt_ring_kernel<EPI, CT, 4><<<t2m * t2n, 512, 4 * RSTAGE_BYTES, s>>>((const bf16_t*)A, lda, (const bf16_t*)B, ldb,
+                                                                              (CT*)C, ldc, M, N, K, t2n, ep);
+  } else if (force == 256 && K > 0 && K % BK == 0)
+    gemm_nt_glds256_kernel<EPI, CT><<<t2m * t2n, 512, SMEM2_BYTES, s>>>((const bf16_t*)A, lda, (const bf16_t*)B, ldb,
+                                                                         (CT*)C, ldc, M, N, K, t2n, ep);
+  else if (K > 0 && K % BK == 0)
+    gemm_nt_glds_kernel<EPI, CT><<<tiles_m * tiles_n, 256, SMEM_BYTES, s>>>((const bf16_t*)A, lda, (const bf16_t*)B, ldb,
+                                                                             (CT*)C, ldc, M, N, K, tiles_n, ep);
+  else
+    gemm_nt_kernel<EPI, CT><<<tiles_m * tiles_n, 256, SMEM_BYTES, s>>>((const bf16_t*)A, lda, (const bf16_t*)B, ldb,
+                                                                        (CT*)C, ldc, M, N, K, tiles_n, ep);
   MV_CHECK_LAUNCH();
   return MV_OK;
 }
@@ -499,7 +1025,7 @@ extern "C" int mv_colsum(const void* x, int x_dtype, long ld, float* out, int ac
   else
     colsum_partial_kernel<bf16_t><<<grid, 256, 0, s>>>((const bf16_t*)x, ld, workspace, rows, cols, rpb < 1 ? 1 : rpb);
   MV_CHECK_LAUNCH();
-  colsum_finish_kernel<<<mv_cdiv(cols, 256), 256, 0, s>>>(workspace, parts, cols, out, accumulate);
+  mv_reduce_rows_kernel<<<mv_cdiv(cols, 64), 1024, 0, s>>>(workspace, parts, cols, (long)cols, out, out, cols, accumulate);
   MV_CHECK_LAUNCH();
   return MV_OK;
 }
@@ -511,16 +1037,21 @@ extern "C" int mv_gemm_tn_bf16(const void* A, int lda, const void* B, int ldb, f
   MV_REQUIRE(lda % 8 == 0 && ldb % 8 == 0 && lda >= ((M + 7) & ~7) && ldb >= ((N + 7) & ~7), MV_ERR_ALIGN);
   MV_REQUIRE(mv_aligned16(A) && mv_aligned16(B) && mv_aligned16(C) && mv_aligned16(workspace), MV_ERR_ALIGN);
   MV_REQUIRE(workspace_bytes >= mv_gemm_tn_workspace_bytes(M, N, Kc), MV_ERR_WORKSPACE);
-  static const int attr = set_smem(gemm_tn_kernel);
+  static const int attr = set_smem(gemm_tn_kernel) | set_smem(gemm_tn_glds_kernel);
   if (attr != 0) return MV_ERR_LAUNCH;
   hipStream_t s = (hipStream_t)stream;
   const TnPlan pl = tn_plan(M, N, Kc);
   const int tiles_mn = pl.tiles_m * pl.tiles_n;
   const bool direct = pl.splits == 1 && !accumulate;
   const long slab_stride = (long)M * N;
-  gemm_tn_kernel<<<tiles_mn * pl.splits, 256, SMEM_BYTES, s>>>(
-      (const bf16_t*)A, lda, (const bf16_t*)B, ldb, direct ? C : workspace, direct ? (long)ldc : (long)N,
-      direct ? 0 : slab_stride, M, N, Kc, pl.tiles_n, tiles_mn, pl.steps_per_split);
+  if (Kc > 0 && Kc % BK == 0)
+    gemm_tn_glds_kernel<<<tiles_mn * pl.splits, 256, SMEM_BYTES, s>>>(
+        (const bf16_t*)A, lda, (const bf16_t*)B, ldb, direct ? C : workspace, direct ? (long)ldc : (long)N,
+        direct ? 0 : slab_stride, M, N, Kc, pl.tiles_n, tiles_mn, pl.steps_per_split);
+  else
+    gemm_tn_kernel<<<tiles_mn * pl.splits, 256, SMEM_BYTES, s>>>(
+        (const bf16_t*)A, lda, (const bf16_t*)B, ldb, direct ? C : workspace, direct ? (long)ldc : (long)N,
+        direct ? 0 : slab_stride, M, N, Kc, pl.tiles_n, tiles_mn, pl.steps_per_split);
   MV_CHECK_LAUNCH();
   if (!direct) {
     int grid = mv_cdiv(slab_stride, 256);

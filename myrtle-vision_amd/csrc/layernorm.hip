@@ -151,16 +151,6 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const DT* __restrict__ dy, 
   }
 }
 
-__global__ void ln_bwd_finish(const float* __restrict__ partial, int nblocks, int dim, float* dgamma, float* dbeta,
-                              int accumulate) {
-  const int j = blockIdx.x * blockDim.x + threadIdx.x;  // 0 .. 2*dim-1
-  if (j >= 2 * dim) return;
-  float s = 0.f;
-  for (int b = 0; b < nblocks; ++b) s += partial[(long)b * 2 * dim + j];
-  float* out = (j < dim) ? (dgamma + j) : (dbeta + (j - dim));
-  *out = accumulate ? (*out + s) : s;
-}
-
 int ln_grid(int rows) {
   int g = mv_cdiv(rows, 4);
   return g < 1 ? 1 : (g > 1024 ? 1024 : g);
@@ -239,7 +229,8 @@ extern "C" int mv_layernorm_bwd(const void* dy, int dy_dtype, const float* x, lo
     }
     MV_CHECK_LAUNCH();
   }
-  ln_bwd_finish<<<mv_cdiv(2 * dim, 256), 256, 0, s>>>(workspace, rows > 0 ? grid : 0, dim, dgamma, dbeta, accumulate);
+  mv_reduce_rows_kernel<<<mv_cdiv(2 * dim, 64), 1024, 0, s>>>(workspace, rows > 0 ? grid : 0, 2 * dim, 2L * dim, dgamma, dbeta,
+                                                             dim, accumulate);
   MV_CHECK_LAUNCH();
   return MV_OK;
 }

@@ -69,3 +69,26 @@ __device__ __forceinline__ float dgelu_f(float x) {
   const float pdf = 0.39894228040143267794f * __expf(-0.5f * x * x);
   return cdf + x * pdf;
 }
+
+// out[c] (+)= sum over rows r of partial[r * ld + c]: the second stage of the deterministic two-stage reductions
+// (LayerNorm dgamma/dbeta, bias-gradient column sums).  One 1024-thread block per 64 columns: the 16 waves take
+// rows round-robin with coalesced 256-byte reads, then combine through LDS.  Columns >= split go to out1.
+static __global__ __launch_bounds__(1024) void mv_reduce_rows_kernel(const float* __restrict__ partial, int nrows,
+                                                                     int ncols, long ld, float* out0, float* out1,
+                                                                     int split, int accumulate) {
+  __shared__ float red[16][64];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int c = blockIdx.x * 64 + lane;
+  float s = 0.f;
+  if (c < ncols)
+    for (int r = wave; r < nrows; r += 16) s += partial[(long)r * ld + c];
+  red[wave][lane] = s;
+  __syncthreads();
+  if (wave == 0 && c < ncols) {
+    float t = 0.f;
+#pragma unroll
+    for (int w = 0; w < 16; ++w) t += red[w][lane];
+    float* o = (c < split) ? (out0 + c) : (out1 + (c - split));
+    *o = accumulate ? (*o + t) : t;
+  }
+}

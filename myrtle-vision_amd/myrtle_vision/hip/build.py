@@ -13,7 +13,7 @@ from concurrent.futures import ThreadPoolExecutor
 PKG_ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))  # myrtle-vision_amd/
 CSRC = os.path.join(PKG_ROOT, "csrc")
 LIB_DIR = os.path.join(PKG_ROOT, "lib")
-LIB_PATH = os.path.join(LIB_DIR, "libmyrtle_vision_hip.so")
+LIB_PATH = os.environ.get("MV_LIB_PATH") or os.path.join(LIB_DIR, "libmyrtle_vision_hip.so")   # MV_LIB_PATH: diagnostic builds
 INCLUDE = os.path.join(os.path.dirname(PKG_ROOT), "include")
 SOURCES = ["layernorm.hip", "gemm_bf16.hip", "gemm_f32.hip", "attention.hip", "elementwise.hip"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-fPIC", "-std=c++17", "-Wall", "-Wno-unused-function"]

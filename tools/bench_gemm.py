@@ -1,0 +1,53 @@
+#!/usr/bin/env python3
+"""Per-shape microbenchmark of the MFMA GEMM entry points on random data (GPU).  TFLOP/s per ViT-B layer shape."""
+import os, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "myrtle-vision_amd"))
+import torch
+from myrtle_vision.hip import ops
+
+M = int(os.environ.get("M", 50432))
+dev = "cuda"
+def rnd(*s, dt=torch.bfloat16): return (torch.randn(*s, device=dev) * 0.5).to(dt)
+
+def timeit(fn, iters=10):
+    for _ in range(3): fn()
+    torch.cuda.synchronize()
+    s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    s.record()
+    for _ in range(iters): fn()
+    e.record(); torch.cuda.synchronize()
+    return s.elapsed_time(e) / iters * 1e-3
+
+rows = []
+for name, N, K, epi in [("qkv fwd", 2304, 768, "none"), ("proj fwd +res", 768, 768, "res"), ("fc1 fwd +gelu", 3072, 768, "gelu"),
+                        ("fc2 fwd +res", 768, 3072, "res"), ("plain bf16 out N=3072", 3072, 768, "none"), ("plain K=3072", 768, 3072, "none")]:
+    x, w, b = rnd(M, K), torch.randn(N, K, device=dev) * K ** -0.5, torch.randn(N, device=dev)
+    if epi == "none":
+        out = torch.empty(M, N, device=dev, dtype=torch.bfloat16)
+        f = lambda: ops.linear_fwd(x, M, K, w, b, out, N)
+    elif epi == "res":
+        out, res = torch.empty(M, N, device=dev), torch.randn(M, N, device=dev)
+        f = lambda: ops.linear_fwd(x, M, K, w, b, out, N, epi=ops.EPI_RESIDUAL, aux=res, ld_aux=N)
+    else:
+        out, h = torch.empty(M, N, device=dev, dtype=torch.bfloat16), torch.empty(M, N, device=dev, dtype=torch.bfloat16)
+        f = lambda: ops.linear_fwd(x, M, K, w, b, out, N, epi=ops.EPI_GELU, out2=h, ld_out2=N)
+    t = timeit(f); rows.append((f"NT {name}", 2.0 * M * N * K / t / 1e12, t * 1e6))
+for name, N, K, epi in [("dX qkv (N=768,K=2304)", 2304, 768, "none"), ("dX fc2 +dgelu (->3072)", 768, 3072, "dgelu"), ("dX fc1 (K=3072)", 3072, 768, "none")]:
+    # linear_dx(dy[M,N], W[N,K]) -> [M,K]
+    dy, w = rnd(M, N), torch.randn(N, K, device=dev) * K ** -0.5
+    out = torch.empty(M, K, device=dev, dtype=torch.bfloat16)
+    if epi == "dgelu":
+        h = rnd(M, K)
+        f = lambda: ops.linear_dx(dy, M, N, w, out, K, epi=ops.EPI_DGELU, aux=h, ld_aux=K)
+    else:
+        f = lambda: ops.linear_dx(dy, M, N, w, out, K)
+    t = timeit(f); rows.append((f"NT {name}", 2.0 * M * N * K / t / 1e12, t * 1e6))
+for name, N, K in [("dW qkv", 2304, 768), ("dW proj", 768, 768), ("dW fc1", 3072, 768), ("dW fc2", 768, 3072)]:
+    dy, x = rnd(M, N), rnd(M, K)
+    f = lambda: ops.linear_dw(dy, x, M, N, K)
+    t = timeit(f); rows.append((f"TN {name} (+reduce+colsum)", 2.0 * M * N * K / t / 1e12, t * 1e6))
+    f = lambda: ops.linear_dw(dy, x, M, N, K, want_bias=False)
+    t = timeit(f); rows.append((f"TN {name} (+reduce)", 2.0 * M * N * K / t / 1e12, t * 1e6))
+for r in rows:
+    print(f"{r[0]:38s} {r[1]:8.1f} TFLOP/s  {r[2]:9.1f} us")
