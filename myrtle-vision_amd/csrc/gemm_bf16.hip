@@ -851,6 +851,127 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_glds_kernel(const bf16_t* __re
   tn_store(acc, Cs, ldc, M, N, m0, n0, wm, wn, lane);
 }
 
+// ------------------------------------------------------------------------------------------------
+// TN kernel, 256x256 tile, LDS ring of S stages of 32 contraction rows (Kc % 32 == 0), staggered wave groups
+// ------------------------------------------------------------------------------------------------
+// Same structure as gemm_nt_ring_kernel.  Each operand stage is two PANELS of [32 kc][128 cols] (256-byte rows, the
+// sw256 image, transposed fragment reads conflict-free); wave (wm, wn) reads A panel wm and half of B panel wn>>1.
+template <int S>
+__global__ __launch_bounds__(512, 2) void gemm_tn_ring_kernel(const bf16_t* __restrict__ A, int lda,
+                                                              const bf16_t* __restrict__ B, int ldb, float* __restrict__ C,
+                                                              long ldc, long slab_stride, int M, int N, int Kc, int tiles_n,
+                                                              int tiles_mn, int steps_per_split) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 2, wn = wave & 3;
+  const int t_all = xcd_remap(blockIdx.x, gridDim.x);
+  const int split = t_all / tiles_mn;
+  const int t = t_all - split * tiles_mn;
+  const int m0 = (t / tiles_n) * BM2, n0 = (t % tiles_n) * BN2;
+  const int nk_total = Kc / BKR;
+  const int kt0 = split * steps_per_split;
+  int nk = nk_total - kt0;
+  if (nk > steps_per_split) nk = steps_per_split;
+  float* Cs = C + (long)split * slab_stride;
+
+  // wave w stages rows [8 (w&3), +8) of panel (w>>2) of both operands: 2 + 2 wave-instructions of 4 rows x 256 B
+  const bf16_t* pa[2];
+  const bf16_t* pb[2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int row = 8 * (wave & 3) + 4 * i + (lane >> 4);
+    const int ch = (lane & 15) ^ (((row & 3) << 2) | ((row >> 2) & 3));
+    const int col = 128 * (wave >> 2) + ch * 8;
+    const int ca = (m0 + col + 8 <= lda) ? m0 + col : 0, cb = (n0 + col + 8 <= ldb) ? n0 + col : 0;
+    pa[i] = A + (long)(kt0 * BKR + row) * lda + ca;
+    pb[i] = B + (long)(kt0 * BKR + row) * ldb + cb;
+  }
+  char* const wave_lds = smem + (wave >> 2) * 8192 + 8 * (wave & 3) * 256;
+  const long astep = (long)BKR * lda, bstep = (long)BKR * ldb;
+#define TNR_ISSUE(slot_, kt_)                                                          \
+  {                                                                                    \
+    char* la_ = wave_lds + (slot_) * RSTAGE_BYTES;                                     \
+    char* lb_ = la_ + 16384;                                                           \
+    const long ao_ = (kt_) * astep, bo_ = (kt_) * bstep;                               \
+    glds16(pa[0] + ao_, la_);   glds16(pa[1] + ao_, la_ + 1024);                       \
+    glds16(pb[0] + bo_, lb_);   glds16(pb[1] + bo_, lb_ + 1024);                       \
+  }
+
+  f32x4 acc[8][4];
+#pragma unroll
+  for (int i = 0; i < 8; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  const int g = lane >> 4, q = (lane >> 2) & 3, p = lane & 3;
+  const int r0 = 8 * g + q;                    // fragment element e <-> kc row 8g + e of the stage
+#pragma unroll
+  for (int s = 0; s < S - 1; ++s)
+    if (s < nk) TNR_ISSUE(s, s)
+  int slot = 0, fill = S - 1;
+#define TNR_SYNC(kt_)                                                                                      \
+  {                                                                                                        \
+    if ((kt_) + S - 2 < nk) {                                                                              \
+      asm volatile("s_waitcnt vmcnt(%0)" ::"n"(4 * (S - 2)) : "memory");                                  \
+    } else {                                                                                               \
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                                     \
+    }                                                                                                      \
+    __builtin_amdgcn_s_barrier();                                                                          \
+    asm volatile("" ::: "memory");                                                                         \
+    if ((kt_) + S - 1 < nk) TNR_ISSUE(fill, (kt_) + S - 1)                                                 \
+  }
+#define TNR_FRAG(base_, ch_)                                                                               \
+  __builtin_shufflevector(                                                                                 \
+      __builtin_amdgcn_ds_read_tr16_b64_v4bf16(LDS_PTR(bf16x4, (base_) + sw256(r0, (ch_) + (p >> 1)) + 8 * (p & 1))),     \
+      __builtin_amdgcn_ds_read_tr16_b64_v4bf16(LDS_PTR(bf16x4, (base_) + sw256(r0 + 4, (ch_) + (p >> 1)) + 8 * (p & 1))), \
+      0, 1, 2, 3, 4, 5, 6, 7)
+#define TNR_READ()                                                                                         \
+  {                                                                                                        \
+    const char* sa_ = smem + slot * RSTAGE_BYTES + wm * 8192;                                              \
+    const char* sb_ = smem + slot * RSTAGE_BYTES + 16384 + (wn >> 1) * 8192;                               \
+    _Pragma("unroll") for (int j = 0; j < 4; ++j) bfr[j] = TNR_FRAG(sb_, ((wn & 1) * 64 + j * 16) >> 3);   \
+    _Pragma("unroll") for (int i = 0; i < 8; ++i) af[i] = TNR_FRAG(sa_, i * 2);                          \
+  }
+#define TNR_MFMA()                                                                                         \
+  {                                                                                                        \
+    _Pragma("unroll") for (int i = 0; i < 8; ++i)                                                          \
+      _Pragma("unroll") for (int j = 0; j < 4; ++j)                                                        \
+        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[j], af[i], acc[i][j], 0, 0, 0);            \
+  }
+#define TNR_ADVANCE()                                                                                      \
+  {                                                                                                        \
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                                     \
+    slot = (slot + 1 == S) ? 0 : slot + 1;                                                                 \
+    fill = (fill + 1 == S) ? 0 : fill + 1;                                                                 \
+  }
+  bf16x8 af[8], bfr[4];
+  if (__builtin_amdgcn_readfirstlane(wave) < 4) {       // waves 0-3: read stage t, then its MFMAs
+    for (int kt = 0; kt < nk; ++kt) {
+      TNR_SYNC(kt)
+      TNR_READ()
+      TNR_MFMA()
+      TNR_ADVANCE()
+    }
+  } else {                                              // waves 4-7 (SIMD partners): MFMAs one stage behind
+    for (int kt = 0; kt < nk; ++kt) {
+      TNR_SYNC(kt)
+      if (kt > 0) TNR_MFMA()
+      TNR_READ()
+      TNR_ADVANCE()
+    }
+    if (nk > 0) TNR_MFMA()
+  }
+#undef TNR_ISSUE
+#undef TNR_SYNC
+#undef TNR_FRAG
+#undef TNR_READ
+#undef TNR_MFMA
+#undef TNR_ADVANCE
+#pragma unroll
+  for (int h = 0; h < 2; ++h)
+    tn_store(*reinterpret_cast<f32x4(*)[4][4]>(&acc[4 * h]), Cs, ldc, M, N, m0 + 128 * wm, n0 + 128 * (wn >> 1), h, wn & 1, lane);
+}
+
 // C[m][n] = (accumulate ? C : 0) + sum_s slab[s][m][n]   (fixed order: deterministic)
 __global__ void splitk_reduce_kernel(const float* __restrict__ slabs, long slab_stride, int S, float* C, int ldc, int M,
                                      int N, int accumulate) {
@@ -929,6 +1050,28 @@ TnPlan tn_plan(int M, int N, int Kc) {
   return pl;
 }
 
+// 256x256 ring variant: one workgroup per CU, so the split count is chosen to land just under ONE round of the 256 CUs
+TnPlan tn_plan256(int M, int N, int Kc) {
+  TnPlan pl;
+  pl.tiles_m = mv_cdiv(M, BM2);
+  pl.tiles_n = mv_cdiv(N, BN2);
+  const int tiles = pl.tiles_m * pl.tiles_n;
+  const int nk = Kc / BKR;
+  int s = 256 / tiles;
+  const int max_s = mv_cdiv(nk, 16);    // at least 16 stages (512 contraction rows) per split
+  if (s > max_s) s = max_s;
+  if (s < 1) s = 1;
+  pl.steps_per_split = mv_cdiv(nk, s);
+  pl.splits = mv_cdiv(nk, pl.steps_per_split);
+  return pl;
+}
+bool tn_use_ring(int M, int N, int Kc) {
+  static const int force = getenv("MV_GEMM_TN") ? atoi(getenv("MV_GEMM_TN")) : 0;     // 128 | 256: tuning and tests
+  if (Kc <= 0 || Kc % BKR != 0 || force == 128) return false;
+  if (force == 256) return true;
+  return (long)M * N >= 256L * 256 * 4 && Kc >= 4096;   // >= 4 tiles and a contraction long enough to split over the chip
+}
+
 template <typename K>
 int set_smem(K kernel) {
   return hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -1005,7 +1148,7 @@ extern "C" int mv_gemm_nt_bf16(const void* A, int lda, const void* B, int ldb, v
 }
 
 extern "C" size_t mv_gemm_tn_workspace_bytes(int M, int N, int Kc) {
-  const TnPlan pl = tn_plan(M, N, Kc);
+  const TnPlan pl = tn_use_ring(M, N, Kc) ? tn_plan256(M, N, Kc) : tn_plan(M, N, Kc);
   const size_t slabs = (size_t)pl.splits * (size_t)M * (size_t)N * sizeof(float);
   const size_t cs = (size_t)colsum_parts(Kc) * (size_t)M * sizeof(float);
   return slabs + cs + 256;
@@ -1040,11 +1183,19 @@ extern "C" int mv_gemm_tn_bf16(const void* A, int lda, const void* B, int ldb, f
   static const int attr = set_smem(gemm_tn_kernel) | set_smem(gemm_tn_glds_kernel);
   if (attr != 0) return MV_ERR_LAUNCH;
   hipStream_t s = (hipStream_t)stream;
-  const TnPlan pl = tn_plan(M, N, Kc);
+  const bool ring = tn_use_ring(M, N, Kc);
+  const TnPlan pl = ring ? tn_plan256(M, N, Kc) : tn_plan(M, N, Kc);
   const int tiles_mn = pl.tiles_m * pl.tiles_n;
   const bool direct = pl.splits == 1 && !accumulate;
   const long slab_stride = (long)M * N;
-  if (Kc > 0 && Kc % BK == 0)
+  if (ring) {
+    static const int a4 = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_tn_ring_kernel<4>),
+                                              hipFuncAttributeMaxDynamicSharedMemorySize, 4 * RSTAGE_BYTES) == hipSuccess ? 0 : -1;
+    if (a4) return MV_ERR_LAUNCH;
+    gemm_tn_ring_kernel<4><<<tiles_mn * pl.splits, 512, 4 * RSTAGE_BYTES, s>>>(
+        (const bf16_t*)A, lda, (const bf16_t*)B, ldb, direct ? C : workspace, direct ? (long)ldc : (long)N,
+        direct ? 0 : slab_stride, M, N, Kc, pl.tiles_n, tiles_mn, pl.steps_per_split);
+  } else if (Kc > 0 && Kc % BK == 0)
     gemm_tn_glds_kernel<<<tiles_mn * pl.splits, 256, SMEM_BYTES, s>>>(
         (const bf16_t*)A, lda, (const bf16_t*)B, ldb, direct ? C : workspace, direct ? (long)ldc : (long)N,
         direct ? 0 : slab_stride, M, N, Kc, pl.tiles_n, tiles_mn, pl.steps_per_split);
@@ -1059,7 +1210,8 @@ extern "C" int mv_gemm_tn_bf16(const void* A, int lda, const void* B, int ldb, f
     splitk_reduce_kernel<<<grid, 256, 0, s>>>(workspace, slab_stride, pl.splits, C, ldc, M, N, accumulate);
     MV_CHECK_LAUNCH();
   }
-  if (colsum) {
+  if (colsum) {   // separate pass over dY (next step: produce these sums where dY is written; fusing them here as
+                  // ones-operand MFMAs pushed this 235-VGPR kernel into spills)
     float* cs_ws = workspace + (size_t)pl.splits * (size_t)slab_stride;
     const int rc = mv_colsum(A, MV_BF16, lda, colsum, accumulate, Kc, M, cs_ws,
                              (size_t)colsum_parts(Kc) * (size_t)M * sizeof(float), stream);

@@ -129,7 +129,7 @@ def test_gemm_nt_embed_epilogue(ops):
     assert (x[:, 0] == 7.0).all()                          # cls rows untouched
 
 
-TN_SHAPES = [(1576, 192, 576), (1576, 768, 192), (5000, 768, 768), (256, 48, 768), (100, 136, 200), (63, 8, 8),
+TN_SHAPES = [(1576, 192, 576), (1600, 192, 576), (4096, 200, 136), (1576, 768, 192), (5000, 768, 768), (256, 48, 768), (100, 136, 200), (63, 8, 8),
              (20000, 3072, 768)]
 
 
