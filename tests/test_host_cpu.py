@@ -1,0 +1,276 @@
+"""CPU tests (no GPU): the C ABI loads and exports every symbol the header declares, host logic mirrors the
+reference's semantics, checkpoints keep the reference wire format, quantiser plumbing renames keys like the
+reference, and the N > 1 gradient exchange is correct with world_size 2 over gloo."""
+import json
+import math
+import os
+import re
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from conftest import ROOT, load_golden
+
+HEADER = os.path.join(ROOT, "include", "myrtle_vision_hip.h")
+
+
+# ---------------------------------------------------------------- C ABI
+def _parse_header():
+    src = open(HEADER).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    decls = {}
+    for m in re.finditer(r"\b(int|size_t|const char\*)\s+(mv_\w+)\s*\(([^;]*?)\)\s*;", src, flags=re.S):
+        ret, name, args = m.group(1), m.group(2), m.group(3).strip()
+        kinds = ""
+        if args and args != "void":
+            for a in args.split(","):
+                a = " ".join(a.split())
+                if "*" in a or "mv_stream_t" in a:
+                    kinds += "p"
+                elif a.startswith("size_t"):
+                    kinds += "z"
+                elif a.startswith("long"):
+                    kinds += "l"
+                elif a.startswith("float"):
+                    kinds += "f"
+                elif a.startswith("int"):
+                    kinds += "i"
+                else:
+                    raise AssertionError(f"unparsed argument {a!r} in {name}")
+        decls[name] = (kinds, ret)
+    return decls
+
+
+def test_library_exports_every_declared_symbol_with_matching_signature():
+    from myrtle_vision.hip import lib
+    decls = _parse_header()
+    assert len(decls) >= 31
+    assert set(decls) == set(lib.SIGNATURES), set(decls) ^ set(lib.SIGNATURES)
+    for name, (kinds, _) in decls.items():
+        assert lib.SIGNATURES[name][0] == kinds, (name, kinds, lib.SIGNATURES[name][0])
+    handle = lib.lib()                      # loads the .so on a machine without a GPU; binds every symbol
+    assert handle.mv_version() >= 100
+    assert b"aligned" in handle.mv_error_string(-2)
+    assert handle.mv_gemm_tn_workspace_bytes(768, 768, 50432) > 0
+    assert handle.mv_layernorm_bwd_workspace_bytes(50432, 768) == 1024 * 2 * 768 * 4
+
+
+def test_missing_library_fails_loudly(tmp_path, monkeypatch):
+    from myrtle_vision.hip import lib
+    monkeypatch.setattr(lib, "_lib", None)
+    monkeypatch.setattr(lib, "LIB_PATH", str(tmp_path / "nope.so"))
+    with pytest.raises(lib.HipLibraryMissing, match="no CPU"):
+        lib.lib()
+
+
+def test_cpu_forward_fails_loudly():
+    from myrtle_vision.models.vit import ViT
+    vit = ViT(decoder="classification", image_size=224, patch_size=16, num_classes=5, dim=64, depth=1, heads=1, mlp_dim=64)
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        vit(torch.randn(1, 3, 224, 224))
+
+
+# ---------------------------------------------------------------- model class / state dict
+@pytest.mark.parametrize("name", ["micro_cls", "micro_seg", "base_cls"])
+def test_state_dict_matches_reference(name):
+    from myrtle_vision.models.vit import ViT
+    from oracle.vit_oracle import ViTConfig
+    _, meta = load_golden(name)
+    vit = ViT(patch_size=16, q_format="FP32", **meta["kwargs"])
+    sd = vit.state_dict()
+    assert {k: list(v.shape) for k, v in sd.items()} == meta["param_shapes"]
+    assert list(sd.keys()) == list(ViTConfig(patch_size=16, **meta["kwargs"]).param_shapes().keys())
+    assert set(vit.unused_parameter_names()) == set(meta["unused_params"])
+
+
+def test_constructor_asserts_like_reference():
+    from myrtle_vision.models.vit import ViT
+    base = dict(decoder="classification", image_size=224, patch_size=16, num_classes=5, dim=64, depth=1, heads=1, mlp_dim=64)
+    with pytest.raises(AssertionError, match="divisible by the patch size"):
+        ViT(**{**base, "image_size": 225})
+    with pytest.raises(AssertionError, match="way too small"):
+        ViT(**{**base, "image_size": 64})
+    with pytest.raises(AssertionError, match="decoder must be"):
+        ViT(**{**base, "decoder": "foo"})
+
+
+def test_quant_prepare_renames_keys_like_reference():
+    from myrtle_vision.models.vit import ViT
+    from myrtle_vision.utils.quantize import QFormat
+    _, meta = load_golden("micro_cls_fp16_32_conv")
+    vit = ViT(patch_size=16, q_format="FP32", **meta["kwargs"])
+    vit.quantizer.prepare_qat("FP16_32")
+    assert list(vit.state_dict().keys()) == meta["state_keys_after_convert"]
+    assert vit.precision == "fp32" and vit.quantizer.q_format == QFormat.FP16_32
+    with pytest.raises(ValueError, match="already quantized"):
+        vit.quantizer.prepare_qat("TF32")
+
+
+# ---------------------------------------------------------------- utils
+def test_get_batch_sizes_reference_semantics():
+    from myrtle_vision.utils.utils import get_batch_sizes
+    assert get_batch_sizes(32, 2, 64) == (32, 1)            # vit_base.json on 2 GPUs
+    assert get_batch_sizes(32, 1, 64) == (32, 2)
+    assert get_batch_sizes(32, 0, 64) == (32, 2)            # CPU: num_gpus 0 treated as one worker
+    assert get_batch_sizes(256, 8, 2048) == (256, 1)
+    assert get_batch_sizes(32, 8, 2048) == (32, 8)
+    assert get_batch_sizes(48, 2, 64) == (32, 1)            # falls back to the largest divisor below the target
+    assert get_batch_sizes(7, 2, 20) == (5, 2)
+    with pytest.raises(ValueError, match="not divisible by the number of GPUs"):
+        get_batch_sizes(32, 3, 64)
+
+
+def test_optimizer_args_and_schedule(tmp_path):
+    from myrtle_vision.utils.models import get_optimizer_args
+    from myrtle_vision.utils.optim import CosineLRScheduler
+    from oracle.optim_oracle import cosine_lr
+    cfg = json.load(open(os.path.join(ROOT, "classification", "train_configs", "vit_base.json")))["train_config"]
+    a = get_optimizer_args(cfg)
+    assert (a.opt, a.sched, a.lr, a.weight_decay, a.warmup_epochs, a.min_lr) == ("adamw", "cosine", 6.25e-5, 0.05, 5, 1e-5)
+
+    class FakeOpt:
+        param_groups = [{"lr": a.lr, "initial_lr": a.lr}, {"lr": a.lr, "initial_lr": a.lr}]
+    sched = CosineLRScheduler(FakeOpt, t_initial=a.epochs, lr_min=a.min_lr, warmup_t=a.warmup_epochs, warmup_lr_init=a.warmup_lr)
+    assert FakeOpt.param_groups[0]["lr"] == a.warmup_lr          # timm sets warmup_lr_init at construction
+    for epoch in [0, 1, 4, 5, 6, 100, 299, 300, 400]:
+        sched.step(epoch)
+        want = cosine_lr(epoch, base_lr=a.lr, t_initial=a.epochs, lr_min=a.min_lr, warmup_t=a.warmup_epochs, warmup_lr_init=a.warmup_lr)
+        assert math.isclose(FakeOpt.param_groups[1]["lr"], want, rel_tol=1e-12), epoch
+
+
+def test_param_arena_groups_and_views():
+    from myrtle_vision.models.vit import ViT
+    from myrtle_vision.utils.optim import ParamArena
+    from oracle.optim_oracle import timm_param_groups
+    vit = ViT(decoder="classification", image_size=224, patch_size=16, num_classes=5, dim=64, depth=2, heads=1, mlp_dim=128)
+    before = {k: v.clone() for k, v in vit.state_dict().items()}
+    arena = ParamArena(vit.named_parameters(), skip=vit.unused_parameter_names())
+    ref = timm_param_groups([(n, p) for n, p in vit.named_parameters() if n not in vit.unused_parameter_names()], 0.05)
+    n_no_decay = sum(p.numel() for p in ref[0]["params"])
+    n_decay = sum(p.numel() for p in ref[1]["params"])
+    assert arena.n_decay >= n_decay and arena.total - arena.n_decay >= n_no_decay
+    assert "pos_embedding" in arena.names[: len(ref[1]["params"])]         # ViT has no no_weight_decay(): pos/cls ARE decayed
+    assert "pos_embedding_det" not in arena.names and "det_tokens" not in arena.names
+    for k, v in vit.state_dict().items():
+        assert torch.equal(v, before[k])                                   # flattening preserved every value
+    for p, o in zip(arena.params, arena.offsets):
+        assert p.data_ptr() == arena.flat_param.data_ptr() + 4 * o and o % 4 == 0
+        assert p.grad.data_ptr() == arena.flat_grad.data_ptr() + 4 * o
+    arena.flat_grad.fill_(1.0)
+    arena.zero_grad()
+    assert float(arena.flat_grad.abs().sum()) == 0.0
+
+
+def test_checkpoint_wire_format_roundtrip(tmp_path):
+    from myrtle_vision.models.vit import ViT
+    from myrtle_vision.utils.models import load_checkpoint, save_checkpoint
+    from myrtle_vision.utils.optim import AdamW, CosineLRScheduler, ParamArena
+    kw = dict(decoder="classification", image_size=224, patch_size=16, num_classes=5, dim=64, depth=1, heads=1, mlp_dim=64)
+    vit = ViT(**kw)
+    opt = AdamW(ParamArena(vit.named_parameters(), skip=vit.unused_parameter_names()), lr=1e-3, weight_decay=0.05)
+    opt.exp_avg.normal_()
+    opt.step_count = 7
+    sched = CosineLRScheduler(opt, t_initial=10, lr_min=1e-5, warmup_t=2, warmup_lr_init=1e-6)
+    sched.step(3)
+    path = str(tmp_path / "vit_000123")
+    save_checkpoint(vit, opt, sched, 123, path)
+    ckpt = torch.load(path, map_location="cpu", weights_only=False)
+    assert set(ckpt) == {"model", "optimizer", "lr_scheduler", "iteration"}          # reference utils/models.py:120-126
+    assert list(ckpt["model"].keys()) == list(vit.state_dict().keys())
+    vit2 = ViT(**kw)
+    opt2 = AdamW(ParamArena(vit2.named_parameters(), skip=vit2.unused_parameter_names()), lr=1e-3, weight_decay=0.05)
+    sched2 = CosineLRScheduler(opt2, t_initial=10, lr_min=1e-5, warmup_t=2, warmup_lr_init=1e-6)
+    assert load_checkpoint(vit2, opt2, sched2, path) == 123
+    for (k, a), (_, b) in zip(vit.state_dict().items(), vit2.state_dict().items()):
+        assert torch.equal(a, b), k
+    s1, s2 = opt.state_dict()["state"], opt2.state_dict()["state"]
+    assert all(torch.equal(s1[k]["exp_avg"], s2[k]["exp_avg"]) for k in s1) and opt2.step_count == 7   # (arena padding is not state)
+    assert opt2.param_groups[0]["lr"] == opt.param_groups[0]["lr"]
+    # a reference-produced "model" dict (plain tensors under the same keys) loads unchanged
+    vit2.load_state_dict({k: v.clone() for k, v in ckpt["model"].items()})
+
+
+def test_rename_timm_state_dict_rules():
+    from myrtle_vision.utils.models import apply_rules, rename_timm_state_dict
+    D, depth = 32, 2
+    timm = {"cls_token": torch.zeros(1, 1, D), "pos_embed": torch.zeros(1, 197, D),
+            "patch_embed.proj.weight": torch.arange(D * 3 * 16 * 16, dtype=torch.float32).reshape(D, 3, 16, 16),
+            "patch_embed.proj.bias": torch.zeros(D), "norm.weight": torch.ones(D), "norm.bias": torch.zeros(D),
+            "head.weight": torch.zeros(10, D), "head.bias": torch.zeros(10)}
+    for i in range(depth):
+        for k, shape in [("norm1.weight", (D,)), ("norm1.bias", (D,)), ("attn.qkv.weight", (3 * D, D)), ("attn.qkv.bias", (3 * D,)),
+                         ("attn.proj.weight", (D, D)), ("attn.proj.bias", (D,)), ("norm2.weight", (D,)), ("norm2.bias", (D,)),
+                         ("mlp.fc1.weight", (4 * D, D)), ("mlp.fc1.bias", (4 * D,)), ("mlp.fc2.weight", (D, 4 * D)), ("mlp.fc2.bias", (D,))]:
+            timm[f"blocks.{i}.{k}"] = torch.zeros(shape)
+    out = rename_timm_state_dict(timm, {"embed_dim": D, "patch_size": 16}, 10)
+    assert "head.weight" not in out and "norm.weight" not in out and "decoder.norm.weight" not in out
+    assert out["patch_to_embedding.weight"].shape == (D, 768)
+    w = timm["patch_embed.proj.weight"]
+    assert out["patch_to_embedding.weight"][3, (5 * 16 + 7) * 3 + 2] == w[3, 2, 5, 7]      # (O,I,H,W) -> (O,(H,W,I))
+    assert "transformer.layers.1.0.fn.fn.to_out.0.weight" in out and "transformer.layers.0.1.fn.fn.net.3.bias" in out
+    assert apply_rules("pos_embed", [(r"pos_embed", r"pos_embedding")]) == "pos_embedding"
+    with pytest.raises(FileNotFoundError, match="cannot be downloaded"):
+        rename_timm_state_dict("vit_base_patch16_224", {"embed_dim": D, "patch_size": 16}, 10)
+
+
+def test_get_models_reads_reference_config_schema(tmp_path):
+    from myrtle_vision.utils.models import get_models
+    cfg = json.load(open(os.path.join(ROOT, "classification", "train_configs", "vit_tiny.json")))
+    cfg["data_config_path"] = os.path.join(ROOT, "classification", cfg["data_config_path"])
+    vit, distiller = get_models(cfg)
+    assert distiller is None and sum(p.numel() for p in vit.parameters()) == 5571501       # SURVEY 8a (a1), Tiny, 45 classes
+
+
+# ---------------------------------------------------------------- N > 1: gradient exchange over gloo
+def _ddp_worker(rank, world, port, tmpdir):
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from myrtle_vision.utils.ddp import GradAllReducer, broadcast_parameters
+    from myrtle_vision.utils.optim import ParamArena
+    torch.manual_seed(100 + rank)                                   # deliberately different initial weights per rank
+    model = torch.nn.Sequential(torch.nn.Linear(12, 40), torch.nn.Tanh(), torch.nn.Linear(40, 24), torch.nn.Tanh(), torch.nn.Linear(24, 3))
+    unused = torch.nn.Parameter(torch.randn(5))                     # a parameter that never gets a gradient
+    named = list(model.named_parameters()) + [("unused", unused)]
+    arena = ParamArena(named)
+    broadcast_parameters(arena, src=0)                              # DDP's constructor broadcast
+    red = GradAllReducer(arena, bucket_bytes=2048)                  # several buckets
+    assert len(red.ranges) > 2
+    g = torch.Generator().manual_seed(7)
+    X, Y = torch.randn(8, 12, generator=g), torch.randn(8, 3, generator=g)
+    xs, ys = X[rank::world], Y[rank::world]                         # DistributedSampler-style shard
+    for step in range(3):
+        arena.zero_grad()
+        loss = ((model(xs) - ys) ** 2).mean()
+        loss.backward()
+        red.finish()
+        if step == 0:
+            torch.save({"grad": arena.flat_grad.clone() * red.grad_scale, "param": arena.flat_param.clone()},
+                       os.path.join(tmpdir, f"r{rank}.pt"))
+        with torch.no_grad():
+            arena.flat_param -= 0.1 * red.grad_scale * arena.flat_grad
+    torch.save(arena.flat_param.clone(), os.path.join(tmpdir, f"final{rank}.pt"))
+    dist.destroy_process_group()
+
+
+def test_gradient_allreduce_world2_gloo(tmp_path):
+    port = 29500 + (os.getpid() % 2000)
+    mp.spawn(_ddp_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    r0, r1 = torch.load(tmp_path / "r0.pt"), torch.load(tmp_path / "r1.pt")
+    assert torch.equal(r0["param"], r1["param"])                     # broadcast made the ranks identical
+    assert torch.allclose(r0["grad"], r1["grad"], atol=0, rtol=0)    # all-reduce: same gradient everywhere
+    # single-process gradient of the mean loss over the CONCATENATED batch equals the averaged rank gradients
+    from myrtle_vision.utils.optim import ParamArena
+    torch.manual_seed(100)
+    model = torch.nn.Sequential(torch.nn.Linear(12, 40), torch.nn.Tanh(), torch.nn.Linear(40, 24), torch.nn.Tanh(), torch.nn.Linear(24, 3))
+    unused = torch.nn.Parameter(torch.randn(5))
+    arena = ParamArena(list(model.named_parameters()) + [("unused", unused)])
+    g = torch.Generator().manual_seed(7)
+    X, Y = torch.randn(8, 12, generator=g), torch.randn(8, 3, generator=g)
+    ((model(X) - Y) ** 2).mean().backward()
+    assert torch.allclose(arena.flat_grad, r0["grad"], atol=1e-6, rtol=1e-5)
+    f0, f1 = torch.load(tmp_path / "final0.pt"), torch.load(tmp_path / "final1.pt")
+    assert torch.equal(f0, f1)                                       # identical parameters on all ranks after K steps
