@@ -1,0 +1,254 @@
+"""Training / evaluation loops shared by ``classification/`` and ``segmentation/`` scripts.
+
+Loop semantics follow the reference scripts (classification/train.py:55-313, segmentation/train.py, */test.py):
+seeding, batch-size solver, one process per GPU, rank-0 checkpoints every ``iters_per_checkpoint`` iterations named
+``vit_{iteration:06}``, rank-0 validation every ``iters_per_val``, gradient accumulation without dividing the loss,
+``lr_scheduler.step(epoch)`` at epoch end.  Differences, all deliberate:
+
+* compute runs on the HIP kernels (model, loss, optimizer); no CPU fallback;
+* gradients are exchanged by ``utils.ddp.GradAllReducer`` over RCCL, and only on the LAST micro-batch of an
+  accumulation window (the reference's DDP all-reduces every micro-batch; the result is identical);
+* the two detection-only parameters are left out of the optimizer/all-reduce (the reference's DDP dies on them);
+* ``GradScaler`` is dropped (a numerical no-op without autocast);
+* ``pretrained_backbone`` must be a local timm-format state dict (no network); a bare timm model NAME that is not a
+  file means "random init" with a warning.
+"""
+import os
+import random
+import time
+
+import torch
+import torch.distributed as dist
+from torch.utils.data import DataLoader, Sampler
+
+from myrtle_vision.hip.functional import CrossEntropyLoss
+from myrtle_vision.hip import ops
+from myrtle_vision.utils.ddp import GradAllReducer, broadcast_parameters
+from myrtle_vision.utils.miou import MIoU
+from myrtle_vision.utils.models import (get_models, get_optimizer_args, prepare_model_and_load_ckpt,
+                                        rename_timm_state_dict, save_checkpoint)
+from myrtle_vision.utils.optim import create_optimizer, create_scheduler
+from myrtle_vision.utils.utils import (cleanup_distributed, get_batch_sizes, init_distributed, parse_config,
+                                       seed_everything)
+
+
+class ShardSampler(Sampler):
+    """torch DistributedSampler semantics (classification/train.py:116,200): per-epoch seeded permutation, padded
+    to a multiple of the world size, rank r takes indices[r::world]."""
+
+    def __init__(self, n, rank, world, seed=0):
+        self.n, self.rank, self.world, self.seed, self.epoch = n, rank, world, seed, 0
+        self.num_samples = (n + world - 1) // world
+
+    def set_epoch(self, epoch):
+        self.epoch = epoch
+
+    def __iter__(self):
+        g = torch.Generator().manual_seed(self.seed + self.epoch)
+        idx = torch.randperm(self.n, generator=g).tolist()
+        idx += idx[: self.num_samples * self.world - len(idx)]
+        return iter(idx[self.rank::self.world])
+
+    def __len__(self):
+        return self.num_samples
+
+
+def _datasets(task, data_config):
+    if task == "classification":
+        from myrtle_vision.datasets.resisc45 import Resisc45 as DS
+        collate = None
+    else:
+        from myrtle_vision.datasets.dlrsd import Dlrsd as DS, collate_both as collate
+    mk = lambda mode, files, ops_: DS(mode=mode, dataset_path=data_config["dataset_path"], imagepaths=data_config[files],
+                                      label_map_path=data_config["label_map"], transform_config=data_config[ops_])
+    return mk, collate
+
+
+@torch.no_grad()
+def validation(val_loader, device, criterion, vit, task, num_classes):
+    total_loss, total_acc, n = 0.0, 0.0, max(len(val_loader), 1)
+    miou = MIoU(num_classes, "cpu") if task == "segmentation" else None
+    vit.eval()
+    for imgs, labels in val_loader:
+        imgs, labels = imgs.to(device), labels.to(device)
+        outputs = vit(imgs)
+        total_loss += float(criterion(outputs, labels)) / n
+        pred = outputs.argmax(dim=1)
+        total_acc += float((pred == labels).float().mean()) / n
+        if miou is not None:
+            miou.add_img(pred.cpu(), labels.cpu())
+    vit.train()
+    return total_loss, total_acc, (miou.get_miou() if miou is not None else None)
+
+
+def train_worker(rank, num_gpus, config, task="classification"):
+    train_config, dist_config, vit_config = config["train_config"], config["dist_config"], config["vit_config"]
+    data_config = parse_config(config["data_config_path"])
+    if not torch.cuda.is_available():
+        raise RuntimeError("training needs an MI355X: the myrtle_vision HIP path has no CPU fallback")
+    device = torch.device("cuda", rank)
+    torch.cuda.set_device(device)
+    seed_everything(train_config["seed"])
+    world = max(num_gpus, 1)
+    batch_size, n_batch_accum = get_batch_sizes(train_config["local_batch_size"], num_gpus,
+                                                train_config["global_batch_size"], verbose=(rank == 0))
+    train_config["local_batch_size"] = batch_size
+    train_config["global_batch_size"] = batch_size * n_batch_accum * world
+    train_config["n_batch_accum"] = n_batch_accum
+    if num_gpus > 1:
+        init_distributed(rank, num_gpus, **dist_config)
+    out_dir = train_config["output_directory"]
+    if rank == 0:
+        os.makedirs(out_dir, exist_ok=True)
+        print("output directory:", out_dir)
+
+    mk, collate = _datasets(task, data_config)
+    trainset = mk("train", "train_files", "transform_ops_train")
+    valset = mk("eval", "valid_files", "transform_ops_val")
+    sampler = ShardSampler(len(trainset), rank, world, seed=train_config["seed"]) if num_gpus > 1 else None
+    train_loader = DataLoader(trainset, num_workers=1, shuffle=(sampler is None), sampler=sampler, batch_size=batch_size,
+                              pin_memory=True, drop_last=train_config["drop_last_batch"], collate_fn=collate)
+    val_loader = DataLoader(valset, num_workers=1, batch_size=batch_size, pin_memory=True,
+                            drop_last=train_config["drop_last_batch"], collate_fn=collate)
+
+    vit, _ = get_models(config)
+    backbone = train_config.get("pretrained_backbone")
+    if backbone is not None:
+        if isinstance(backbone, str) and os.path.exists(backbone):
+            missing = vit.load_state_dict(rename_timm_state_dict(backbone, vit_config, data_config["number_of_classes"]),
+                                          strict=False)
+            assert missing.unexpected_keys == []
+        elif rank == 0:
+            print(f"WARNING: pretrained_backbone={backbone!r} is not a local file (no network): training from random init")
+    vit = vit.to(device)
+
+    optimizer_args = get_optimizer_args(train_config)
+    optimizer = create_optimizer(optimizer_args, vit)
+    lr_scheduler, _ = create_scheduler(optimizer_args, optimizer)
+    criterion = CrossEntropyLoss()
+    iteration = prepare_model_and_load_ckpt(train_config=train_config, model=vit, optimizer=optimizer,
+                                            lr_scheduler=lr_scheduler)
+    optimizer.arena.bump_versions()
+    reducer = GradAllReducer(optimizer.arena)
+    broadcast_parameters(optimizer.arena)
+    optimizer.grad_scale = reducer.grad_scale
+    if optimizer_args.clip_grad is not None:
+        raise NotImplementedError("clip_grad is null in every reference config; gradient clipping is not implemented")
+
+    vit.train()
+    epoch_offset = max(0, int(batch_size * world * iteration / max(len(trainset), 1)))
+    if num_gpus > 1:
+        dist.barrier()
+    n_accum, last_val = 0, (0.0, 0.0, None)
+    num_classes = data_config["number_of_classes"]
+    for epoch in range(epoch_offset, train_config["epochs"]):
+        epoch_loss = epoch_acc = 0.0
+        if sampler is not None:
+            sampler.set_epoch(epoch)
+        for imgs, labels in train_loader:
+            if iteration % train_config["iters_per_checkpoint"] == 0 and n_accum == 0 and rank == 0:
+                save_checkpoint(model=vit, optimizer=optimizer, lr_scheduler=lr_scheduler, iteration=iteration,
+                                filepath=f"{out_dir}/vit_{iteration:06}")
+            if iteration % train_config["iters_per_val"] == 0 and n_accum == 0 and rank == 0:
+                last_val = validation(val_loader, device, criterion, vit, task, num_classes)
+            if n_accum == 0:
+                optimizer.zero_grad()
+            imgs, labels = imgs.to(device, non_blocking=True), labels.to(device, non_blocking=True)
+            reducer.enabled = reducer.world > 1 and (n_accum == n_batch_accum - 1)
+            outputs = vit(imgs)
+            loss = criterion(outputs, labels)
+            loss.backward()
+            n_accum += 1
+            if n_accum == n_batch_accum:
+                n_accum = 0
+                reducer.finish()
+                optimizer.step()
+                iteration += 1
+                if rank == 0:
+                    acc = float((outputs.argmax(dim=1) == labels).float().mean())
+                    epoch_loss += float(loss.detach()) / len(train_loader)
+                    epoch_acc += acc / len(train_loader)
+                    print(f"Iteration {iteration}:\tloss={float(loss.detach()):.4f}\tacc={acc:.4f}")
+        lr_scheduler.step(epoch)
+        if rank == 0:
+            extra = f" - val_miou: {last_val[2]:.4f}" if last_val[2] is not None else ""
+            print(f"Epoch : {epoch + 1} - loss : {epoch_loss:.4f} - acc: {epoch_acc:.4f} - "
+                  f"val_loss : {last_val[0]:.4f} - val_acc: {last_val[1]:.4f}{extra}\n")
+    if num_gpus > 1:
+        cleanup_distributed()
+    return iteration
+
+
+def launch_training(config, task):
+    """``__main__`` of the reference train scripts: timestamped output dir, one process per visible GPU."""
+    from datetime import datetime
+    import torch.multiprocessing as mp
+    config["train_config"]["output_directory"] += datetime.now().strftime("_%m_%d_%Y_%H_%M_%S")
+    num_gpus = torch.cuda.device_count()
+    if config["train_config"]["distributed"]:
+        if num_gpus <= 1:
+            print(f"WARNING: tried to enable distributed training but only found {num_gpus} GPU(s)")
+    elif num_gpus > 1:
+        print("INFO: you have multiple GPUs available but did not enable distributed training")
+        num_gpus = 1
+    try:
+        if num_gpus > 1:
+            mp.spawn(train_worker, args=(num_gpus, config, task), nprocs=num_gpus, join=True)
+        else:
+            train_worker(0, num_gpus, config, task)
+    except KeyboardInterrupt:
+        print("Ctrl-c pressed; cleaning up and ending training early...")
+
+
+@torch.no_grad()
+def evaluate(config, task, quantize=False, calib_steps=0, quantized_ckpt=False):
+    """classification/test.py, segmentation/test.py and classification/test_quantize.py in one function."""
+    from myrtle_vision.utils.models import load_checkpoint
+    from myrtle_vision.utils.quantize import QFormat
+    train_config, vit_config = config["train_config"], config["vit_config"]
+    data_config = parse_config(config["data_config_path"])
+    vit_config["dropout"], vit_config["emb_dropout"] = 0.0, 0.0            # classification/test.py:47-48
+    if train_config["checkpoint_path"] == "":
+        raise ValueError("a checkpoint is required for evaluation (train_config.checkpoint_path)")
+    q_format = vit_config["q_format"]
+    if quantize and not quantized_ckpt:
+        vit_config["q_format"] = "FP32"                                    # test_quantize.py:90-94: build FP32, load, then prepare
+    vit, _ = get_models(config)
+    vit = vit.to("cuda")
+    load_checkpoint(model=vit, optimizer=None, lr_scheduler=None, filepath=train_config["checkpoint_path"])
+    mk, collate = _datasets(task, data_config)
+    if quantize:
+        if not quantized_ckpt:
+            vit.quantizer.prepare_qat(q_format)
+        calib = DataLoader(mk("eval", "valid_files", "transform_ops_val"), batch_size=train_config["local_batch_size"],
+                           collate_fn=collate)
+        vit.train()
+        for step, (imgs, _) in enumerate(calib):                           # test_quantize.py:26-34
+            if step >= calib_steps:
+                break
+            vit(imgs.to("cuda"))
+        vit.convert()
+    testset = mk("eval" if task == "classification" else "test", "test_files", "transform_ops_val")
+    loader = DataLoader(testset, batch_size=train_config["local_batch_size"], collate_fn=collate)
+    vit.eval()
+    preds, gts = [], []
+    miou = MIoU(data_config["number_of_classes"], "cpu") if task == "segmentation" else None
+    for imgs, labels in loader:
+        out = vit(imgs.to("cuda")).argmax(dim=1).cpu()
+        preds.append(out.reshape(-1))
+        gts.append(labels.reshape(-1))
+        if miou is not None:
+            miou.add_img(out, labels)
+    preds, gts = torch.cat(preds), torch.cat(gts)
+    acc = float((preds == gts).float().mean())
+    result = {"accuracy": acc}
+    if miou is not None:
+        result["miou"] = miou.get_miou()
+        print(f"pixel accuracy: {acc:.4f}  mIoU: {result['miou']:.4f}")
+    else:
+        try:
+            from sklearn.metrics import classification_report
+            print(classification_report(gts.numpy(), preds.numpy(), digits=4, zero_division=0))
+        except ImportError:
+            print(f"accuracy: {acc:.4f}")
+    return result
