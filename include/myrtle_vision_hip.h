@@ -43,7 +43,8 @@ enum {
   MV_EPI_NONE = 0,     /* C = acc (+ bias) */
   MV_EPI_GELU = 1,     /* out2 = acc + bias (pre-activation, optional); C = gelu_erf(acc + bias) */
   MV_EPI_RESIDUAL = 2, /* C = acc + bias + aux              (aux: fp32 [M, ld_aux]) */
-  MV_EPI_DGELU = 3,    /* C = acc * gelu_erf'(aux)          (aux: pre-activation, dtype of A) */
+  MV_EPI_DGELU = 3,    /* C = acc * gelu_erf'(aux)          (aux: pre-activation, dtype of A); bf16 kernel only: out2 (optional)
+                          = fp32 [ceil(M/64), ld_out2] per-64-row column sums of C (bias-gradient partials) */
   MV_EPI_EMBED = 4     /* patch-embedding: row m of the GEMM is patch (m % aux_i) of image (m / aux_i);
                           C row = img*(aux_i+1) + 1 + patch;  C = acc + bias + aux[1 + patch]  (aux: fp32 [aux_i+1, N]) */
 };
@@ -60,11 +61,14 @@ size_t mv_layernorm_bwd_workspace_bytes(int rows, int dim);
 int mv_layernorm_fwd(const float* x, long ldx, const float* gamma, const float* beta, void* y, int y_dtype,
                      float* mean, float* rstd, int rows, int dim, float eps, mv_stream_t stream);
 /* dx[rows, dim] (fp32, row stride lddx) = dLN(dy) (+ dx_add if non-null, same layout as dx; may alias dx);
- * dgamma/dbeta: fp32 [dim], overwritten (accumulate=0) or added to (accumulate=1). */
+ * dgamma/dbeta: fp32 [dim], overwritten (accumulate=0) or added to (accumulate=1).
+ * Optional fused by-products for the consumer of dx in the backward chain (both may be NULL):
+ *   dx_bf16  : bf16 [rows, dim] dense copy of dx (the MFMA operand of the next block's dX/dW products);
+ *   dx_colsum: fp32 [dim] = sum over rows of dx (that block's output-projection bias gradient), overwritten. */
 int mv_layernorm_bwd(const void* dy, int dy_dtype, const float* x, long ldx, const float* gamma,
                      const float* mean, const float* rstd, const float* dx_add, float* dx, long lddx,
                      float* dgamma, float* dbeta, int accumulate, float* workspace, size_t workspace_bytes,
-                     int rows, int dim, mv_stream_t stream);
+                     int rows, int dim, void* dx_bf16, float* dx_colsum, mv_stream_t stream);
 
 /* ---- dense contractions on MFMA (bf16 in, fp32 accumulate) ----
  * nn.Linear forward  y = x W^T + b : patch_to_embedding :278, to_qkv :86, to_out :98, net.0/net.3 :48-51,

@@ -76,6 +76,33 @@ __device__ __forceinline__ void store4(CT* p, const float v[4], bool vec, int nv
   }
 }
 
+// Column sums of one wave's 64x64 quadrant (bias-gradient partials): cs[j][r] holds this lane's sum over its 4 rows
+// per MFMA tile; the 16 lanes with equal lane>>4 hold the other rows of the same columns -> xor-shuffle reduce, then
+// lane&15 == 0 writes partial[row_block][n .. n+3] for j = 0..3 (each (row_block, column) has exactly one writer).
+__device__ __forceinline__ void nt_colsum_flush(float (&cs)[4][4], float* __restrict__ partial, int ld, int row_block, int nb,
+                                                int N, int lane) {
+#pragma unroll
+  for (int j = 0; j < 4; ++j)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      float v = cs[j][r];
+      v += __shfl_xor(v, 1, 64);
+      v += __shfl_xor(v, 2, 64);
+      v += __shfl_xor(v, 4, 64);
+      v += __shfl_xor(v, 8, 64);
+      cs[j][r] = v;
+    }
+  if ((lane & 15) == 0) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int n = nb + j * 16 + r;
+        if (n < N) partial[(long)row_block * ld + n] = cs[j][r];
+      }
+  }
+}
+
 // ---- shared epilogue of the NT kernels.  Lane holds, for MFMA tile (i,j): row m = .. + (lane&15), 4 consecutive
 // columns n = .. + 4*(lane>>4) + 0..3 (the MFMA was issued transposed), so bias/aux/out are 8-/16-byte vectors.
 // erf to |err| <= 1.5e-7 (Abramowitz-Stegun 7.1.26) on v_rcp_f32 / v_exp_f32: ~13 VALU ops instead of libm erff's
@@ -150,6 +177,11 @@ __device__ __forceinline__ void nt_epilogue(f32x4 (&acc)[4][4], CT* __restrict__
           ax[i][j] = make_float4((float)h[0], (float)h[1], (float)h[2], (float)h[3]);
         }
     }
+    float cs[4][4];                                   // DGELU: column sums of this wave's 64x64 quadrant
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) cs[j][r] = 0.f;
 #pragma unroll
     for (int i = 0; i < 4; ++i)
 #pragma unroll
@@ -165,13 +197,22 @@ __device__ __forceinline__ void nt_epilogue(f32x4 (&acc)[4][4], CT* __restrict__
         } else if constexpr (EPI == MV_EPI_DGELU) {
           v[0] *= dgelu_fast(ax[i][j].x); v[1] *= dgelu_fast(ax[i][j].y);
           v[2] *= dgelu_fast(ax[i][j].z); v[3] *= dgelu_fast(ax[i][j].w);
+          cs[j][0] += v[0]; cs[j][1] += v[1]; cs[j][2] += v[2]; cs[j][3] += v[3];
         }
         store4(C + crow[i] * ldc + n, v, true, 4);
       }
+    if constexpr (EPI == MV_EPI_DGELU) {
+      if (ep.out2) nt_colsum_flush(cs, reinterpret_cast<float*>(ep.out2), ep.ld_out2, (m0 + wm * 64) >> 6, nb, N, lane);
+    }
     return;
   }
   // ---- edge tiles: bounds-checked, element-wise where needed
   const bool ldc_vec = (ldc & 3) == 0;
+  float cs[4][4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) cs[j][r] = 0.f;
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
     const int m = m0 + wm * 64 + i * 16 + (lane & 15);
@@ -208,7 +249,10 @@ __device__ __forceinline__ void nt_epilogue(f32x4 (&acc)[4][4], CT* __restrict__
         const bf16_t* ax = reinterpret_cast<const bf16_t*>(ep.aux) + (long)m * ep.ld_aux + n;
 #pragma unroll
         for (int r = 0; r < 4; ++r)
-          if (r < nvalid) v[r] *= dgelu_fast((float)ax[r]);
+          if (r < nvalid) {
+            v[r] *= dgelu_fast((float)ax[r]);
+            cs[j][r] += v[r];
+          }
       } else if constexpr (EPI == MV_EPI_EMBED) {
         const float* ax = reinterpret_cast<const float*>(ep.aux) + (long)(1 + patch) * ep.ld_aux + n;
 #pragma unroll
@@ -217,6 +261,10 @@ __device__ __forceinline__ void nt_epilogue(f32x4 (&acc)[4][4], CT* __restrict__
       }
       store4(C + crow * ldc + n, v, vec, nvalid);
     }
+  }
+  if constexpr (EPI == MV_EPI_DGELU) {
+    if (ep.out2 && m0 + wm * 64 < M)
+      nt_colsum_flush(cs, reinterpret_cast<float*>(ep.out2), ep.ld_out2, (m0 + wm * 64) >> 6, n0 + wn * 64 + 4 * (lane >> 4), N, lane);
   }
 }
 

@@ -68,23 +68,28 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const float* __restrict__ x
 // Per-lane partial dgamma/dbeta are kept in registers across the rows a wave visits (a lane owns the
 // same columns for every row), reduced across the block's 4 waves through LDS, and written as one
 // partial row per block; ln_bwd_finish sums the partial rows (deterministic, no atomics).
+// Optional extras for the fused transformer blocks (backward order: this dx IS the next consumer's incoming gradient):
+//   dx16  : bf16 copy of dx (the MFMA operand of that consumer's dX / dW products) -- replaces a separate cast pass;
+//   colsum: third group of per-column partial sums, sum_rows dx = the consumer's output-projection bias gradient.
 template <int VPL, typename DT>
 __global__ __launch_bounds__(256) void ln_bwd_kernel(const DT* __restrict__ dy, const float* __restrict__ x, long ldx,
                                                      const float* __restrict__ gamma, const float* __restrict__ mean,
                                                      const float* __restrict__ rstd, const float* dx_add, float* dx,
-                                                     long lddx, float* __restrict__ partial, int rows, int dim) {
+                                                     long lddx, float* __restrict__ partial, int rows, int dim,
+                                                     bf16_t* __restrict__ dx16, int want_colsum) {
   __shared__ float red[4][VPL * 64 * 4 * 2];
   const int lane = threadIdx.x & 63;
   const int wave = threadIdx.x >> 6;
   const int nvec = dim >> 2;
   const float inv_dim = 1.0f / (float)dim;
-  float4 g4[VPL], dg[VPL], db[VPL];
+  float4 g4[VPL], dg[VPL], db[VPL], dc[VPL];
 #pragma unroll
   for (int i = 0; i < VPL; ++i) {
     const int c = lane + 64 * i;
     g4[i] = (c < nvec) ? reinterpret_cast<const float4*>(gamma)[c] : make_float4(0.f, 0.f, 0.f, 0.f);
     dg[i] = make_float4(0.f, 0.f, 0.f, 0.f);
     db[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+    dc[i] = make_float4(0.f, 0.f, 0.f, 0.f);
   }
   for (long row = (long)blockIdx.x * 4 + wave; row < rows; row += (long)gridDim.x * 4) {
     const float4* xr = reinterpret_cast<const float4*>(x + row * ldx);
@@ -127,6 +132,11 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const DT* __restrict__ dy, 
           o.x += a.x; o.y += a.y; o.z += a.z; o.w += a.w;
         }
         dxr[c] = o;
+        if (dx16) {
+          bf16x4 o16 = {(bf16_t)o.x, (bf16_t)o.y, (bf16_t)o.z, (bf16_t)o.w};
+          reinterpret_cast<bf16x4*>(dx16 + row * (long)dim)[c] = o16;
+        }
+        dc[i].x += o.x; dc[i].y += o.y; dc[i].z += o.z; dc[i].w += o.w;
       }
     }
   }
@@ -138,7 +148,8 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const DT* __restrict__ dy, 
     r[4] = db[i].x; r[5] = db[i].y; r[6] = db[i].z; r[7] = db[i].w;
   }
   __syncthreads();
-  float* prow = partial + (long)blockIdx.x * 2 * dim;
+  const int groups = want_colsum ? 3 : 2;
+  float* prow = partial + (long)blockIdx.x * groups * dim;
   for (int idx = threadIdx.x; idx < VPL * 64 * 8; idx += 256) {
     const int vec = idx >> 3, e = idx & 7;       // vec = i*64 + lane -> column block c = lane + 64*i
     const int i = vec >> 6, l = vec & 63;
@@ -147,6 +158,21 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const DT* __restrict__ dy, 
       const float s = (red[0][idx] + red[1][idx]) + (red[2][idx] + red[3][idx]);
       const int col = c * 4 + (e & 3);
       prow[(e >> 2) * dim + col] = s;
+    }
+  }
+  if (want_colsum) {                             // third group through the same LDS buffer
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < VPL; ++i) {
+      float* r = &red[wave][(i * 64 + lane) * 8];
+      r[0] = dc[i].x; r[1] = dc[i].y; r[2] = dc[i].z; r[3] = dc[i].w;
+    }
+    __syncthreads();
+    for (int idx = threadIdx.x; idx < VPL * 64 * 8; idx += 256) {
+      const int vec = idx >> 3, e = idx & 7;
+      const int i = vec >> 6, l = vec & 63;
+      const int c = l + 64 * i;
+      if (c < nvec && e < 4) prow[2 * dim + c * 4 + e] = (red[0][idx] + red[1][idx]) + (red[2][idx] + red[3][idx]);
     }
   }
 }
@@ -159,7 +185,7 @@ int ln_grid(int rows) {
 }  // namespace
 
 extern "C" size_t mv_layernorm_bwd_workspace_bytes(int rows, int dim) {
-  return (size_t)ln_grid(rows) * 2 * (size_t)dim * sizeof(float);
+  return (size_t)ln_grid(rows) * 3 * (size_t)dim * sizeof(float);
 }
 
 #define LN_FWD_CASE(V)                                                                                      \
@@ -201,15 +227,15 @@ extern "C" int mv_layernorm_fwd(const float* x, long ldx, const float* gamma, co
 #define LN_BWD_LAUNCH(V)                                                                                     \
   if (dy_dtype == MV_F32)                                                                                    \
     ln_bwd_kernel<V, float><<<grid, 256, 0, s>>>((const float*)dy, x, ldx, gamma, mean, rstd, dx_add, dx, lddx, \
-                                                 workspace, rows, dim);                                      \
+                                                 workspace, rows, dim, (bf16_t*)dx_bf16, dx_colsum != nullptr); \
   else                                                                                                       \
     ln_bwd_kernel<V, bf16_t><<<grid, 256, 0, s>>>((const bf16_t*)dy, x, ldx, gamma, mean, rstd, dx_add, dx, lddx, \
-                                                  workspace, rows, dim);
+                                                  workspace, rows, dim, (bf16_t*)dx_bf16, dx_colsum != nullptr);
 
 extern "C" int mv_layernorm_bwd(const void* dy, int dy_dtype, const float* x, long ldx, const float* gamma,
                                 const float* mean, const float* rstd, const float* dx_add, float* dx, long lddx,
                                 float* dgamma, float* dbeta, int accumulate, float* workspace, size_t workspace_bytes,
-                                int rows, int dim, mv_stream_t stream) {
+                                int rows, int dim, void* dx_bf16, float* dx_colsum, mv_stream_t stream) {
   MV_REQUIRE(rows >= 0 && dim > 0 && dim % 4 == 0 && dim <= 2048 && ldx % 4 == 0 && lddx % 4 == 0, MV_ERR_SHAPE);
   MV_REQUIRE(dy_dtype == MV_F32 || dy_dtype == MV_BF16, MV_ERR_UNSUPPORTED);
   MV_REQUIRE(mv_aligned16(x) && mv_aligned16(gamma) && mv_aligned16(dy) && mv_aligned16(dx) &&
@@ -229,8 +255,14 @@ extern "C" int mv_layernorm_bwd(const void* dy, int dy_dtype, const float* x, lo
     }
     MV_CHECK_LAUNCH();
   }
-  mv_reduce_rows_kernel<<<mv_cdiv(2 * dim, 64), 1024, 0, s>>>(workspace, rows > 0 ? grid : 0, 2 * dim, 2L * dim, dgamma, dbeta,
-                                                             dim, accumulate);
+  const int groups = dx_colsum ? 3 : 2;
+  mv_reduce_rows_kernel<<<mv_cdiv(2 * dim, 64), 1024, 0, s>>>(workspace, rows > 0 ? grid : 0, 2 * dim, (long)groups * dim, dgamma,
+                                                             dbeta, dim, accumulate);
+  if (dx_colsum) {
+    MV_CHECK_LAUNCH();
+    mv_reduce_rows_kernel<<<mv_cdiv(dim, 64), 1024, 0, s>>>(workspace + 2 * dim, rows > 0 ? grid : 0, dim, (long)groups * dim,
+                                                           dx_colsum, dx_colsum, dim, 0);
+  }
   MV_CHECK_LAUNCH();
   return MV_OK;
 }

@@ -302,6 +302,37 @@ def patch_embed(img, weight, bias, cls_token, pos, patch, prec):
 # ------------------------------------------------------------------------------------------------------------
 # fused transformer blocks
 # ------------------------------------------------------------------------------------------------------------
+# One-slot side channel along the backward chain: the LayerNorm-backward kernel that produces a block's input
+# gradient dx can also emit (a) dx in bf16 and (b) its column sums -- exactly what the NEXT block function to run
+# (the one whose output gradient is this dx) needs as MFMA operand and as output-projection bias gradient.  Keeping
+# a strong reference to dx pins its address, so a pointer match identifies the tensor unambiguously.
+_side = {}
+
+
+def _publish_side(dx, dx16, colsum):
+    _side.clear()
+    _side[dx.data_ptr()] = (dx, dx16, colsum)
+
+
+def _take_side(dout, rows, dim):
+    ent = _side.pop(dout.data_ptr(), None)
+    _side.clear()
+    if ent is None or ent[0].shape != dout.shape or ent[1].shape != (rows, dim):
+        return None, None
+    return ent[1], ent[2]
+
+
+def _ln_bwd_with_side(dy, x, D, g, mean, rstd, dout, M, adt):
+    """LayerNorm backward + residual gradient; in bf16 mode also publishes the bf16 copy and column sums of dx."""
+    dx = torch.empty_like(x)
+    if adt == torch.bfloat16:
+        dx16 = torch.empty(M, D, dtype=torch.bfloat16, device=x.device)
+        cs = torch.empty(D, dtype=torch.float32, device=x.device)
+        dg, db = ops.layernorm_bwd(dy, x, D, g, mean, rstd, dout, dx, D, M, D, dx16=dx16, dx_colsum=cs)
+        _publish_side(dx, dx16, cs)
+    else:
+        dg, db = ops.layernorm_bwd(dy, x, D, g, mean, rstd, dout, dx, D, M, D)
+    return dx, dg, db
 class _AttnBlock(Function):
     """x + to_out(attention(to_qkv(LN(x))))  ==  Residual(PreNorm(dim, Attention)) (vit.py:131-141, 84-99)."""
 
@@ -341,8 +372,11 @@ class _AttnBlock(Function):
         inner = inner3 // 3
         adt = y.dtype
         dout = _c(dout)
-        d_act = ops.cast(dout, adt).view(M, D)                    # dY of the projection, activation dtype
-        dwo, dbo = ops.linear_dw(d_act, o.view(M, inner), M, D, inner)
+        d_act, dbo = _take_side(dout, M, D) if adt == torch.bfloat16 else (None, None)
+        if d_act is None:
+            d_act = ops.cast(dout, adt).view(M, D)                # dY of the projection, activation dtype
+        dwo, dbo2 = ops.linear_dw(d_act, o.view(M, inner), M, D, inner, want_bias=dbo is None)
+        dbo = dbo if dbo is not None else dbo2
         do = torch.empty(B, T, inner, dtype=adt, device=x.device)
         ops.linear_dx(d_act, M, D, wo, do, inner)
         if fused:
@@ -353,8 +387,7 @@ class _AttnBlock(Function):
         dwqkv, dbqkv = ops.linear_dw(dqkv.view(M, inner3), y, M, inner3, D)
         dy = torch.empty(M, D, dtype=adt, device=x.device)
         ops.linear_dx(dqkv.view(M, inner3), M, inner3, wqkv, dy, D)
-        dx = torch.empty_like(x)
-        dg, db = ops.layernorm_bwd(dy, x, D, g, mean, rstd, dout, dx, D, M, D)   # + residual gradient
+        dx, dg, db = _ln_bwd_with_side(dy, x, D, g, mean, rstd, dout, M, adt)   # + residual gradient
         return dx, dg, db, dwqkv, dbqkv, dwo, dbo, None, None, None
 
 
@@ -389,15 +422,24 @@ class _MlpBlock(Function):
         Hd = w1.shape[0]
         adt = y.dtype
         dout = _c(dout)
-        d_act = ops.cast(dout, adt).view(M, D)
-        dw2, db2 = ops.linear_dw(d_act, a, M, D, Hd)
+        d_act, db2 = _take_side(dout, M, D) if adt == torch.bfloat16 else (None, None)
+        if d_act is None:
+            d_act = ops.cast(dout, adt).view(M, D)
+        dw2, db2b = ops.linear_dw(d_act, a, M, D, Hd, want_bias=db2 is None)
+        db2 = db2 if db2 is not None else db2b
         dh = torch.empty(M, Hd, dtype=adt, device=x.device)
-        ops.linear_dx(d_act, M, D, w2, dh, Hd, epi=EPI_DGELU, aux=h, ld_aux=Hd)    # (dY W2) * gelu'(h)
-        dw1, db1 = ops.linear_dw(dh, y, M, Hd, D)
+        if adt == torch.bfloat16:
+            # (dY W2) * gelu'(h); the epilogue also leaves per-64-row column sums of dh = fc1's bias-gradient partials
+            part = torch.empty((M + 63) // 64, Hd, dtype=torch.float32, device=x.device)
+            ops.linear_dx(d_act, M, D, w2, dh, Hd, epi=EPI_DGELU, aux=h, ld_aux=Hd, colsum_partial=part)
+            db1 = ops.colsum(part, part.shape[0], Hd, Hd, torch.empty(Hd, dtype=torch.float32, device=x.device))
+            dw1, _ = ops.linear_dw(dh, y, M, Hd, D, want_bias=False)
+        else:
+            ops.linear_dx(d_act, M, D, w2, dh, Hd, epi=EPI_DGELU, aux=h, ld_aux=Hd)
+            dw1, db1 = ops.linear_dw(dh, y, M, Hd, D)
         dy = torch.empty(M, D, dtype=adt, device=x.device)
         ops.linear_dx(dh, M, Hd, w1, dy, D)
-        dx = torch.empty_like(x)
-        dg, db = ops.layernorm_bwd(dy, x, D, g, mean, rstd, dout, dx, D, M, D)
+        dx, dg, db = _ln_bwd_with_side(dy, x, D, g, mean, rstd, dout, M, adt)
         return dx, dg, db, dw1, db1, dw2, db2, None
 
 

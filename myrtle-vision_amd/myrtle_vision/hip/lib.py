@@ -25,7 +25,7 @@ SIGNATURES = {
     "mv_gemm_tn_workspace_bytes": ("iii", _Z),
     "mv_layernorm_bwd_workspace_bytes": ("ii", _Z),
     "mv_layernorm_fwd": ("plpppipp" "iifp", _I),
-    "mv_layernorm_bwd": ("pi" "plp" "pp" "ppl" "ppi" "pz" "iip", _I),
+    "mv_layernorm_bwd": ("pi" "plp" "pp" "ppl" "ppi" "pz" "ii" "pp" "p", _I),
     "mv_gemm_nt_bf16": ("pipipii" "iii" "pi" "pii" "pi" "p", _I),
     "mv_gemm_tn_bf16": ("pipipi" "iii" "i" "p" "pz" "p", _I),
     "mv_gemm_f32": ("pllll" "pllll" "pllll" "iii" "ii" "fi" "pi" "pli" "pl" "p", _I),

@@ -150,15 +150,16 @@ def layernorm_fwd(x, ldx, rows, dim, gamma, beta, out_dtype, eps=1e-5):
     return y, mean, rstd
 
 
-def layernorm_bwd(dy, x, ldx, gamma, mean, rstd, dx_add, dx, lddx, rows, dim):
-    """Writes dx (fp32 rows ``lddx`` apart; ``dx_add`` added if given, same layout) -> (dgamma, dbeta)."""
+def layernorm_bwd(dy, x, ldx, gamma, mean, rstd, dx_add, dx, lddx, rows, dim, dx16=None, dx_colsum=None):
+    """Writes dx (fp32 rows ``lddx`` apart; ``dx_add`` added if given, same layout) -> (dgamma, dbeta).
+    Optional fused by-products: ``dx16`` (bf16 [rows, dim] copy of dx) and ``dx_colsum`` (fp32 [dim] column sums)."""
     require_cuda(dy, x, dx)
     dgamma = torch.empty(dim, dtype=torch.float32, device=x.device)
     dbeta = torch.empty(dim, dtype=torch.float32, device=x.device)
     nbytes = lib().mv_layernorm_bwd_workspace_bytes(rows, dim)
     ws = workspace(nbytes, x.device)
     check(lib().mv_layernorm_bwd(_p(dy), _DT[dy.dtype], _p(x), ldx, _p(gamma), _p(mean), _p(rstd), _p(dx_add), _p(dx),
-                                 lddx, _p(dgamma), _p(dbeta), 0, _p(ws), ws.numel(), rows, dim, _s()),
+                                 lddx, _p(dgamma), _p(dbeta), 0, _p(ws), ws.numel(), rows, dim, _p(dx16), _p(dx_colsum), _s()),
           "layernorm_bwd", rows=rows, dim=dim)
     return dgamma, dbeta
 
@@ -187,15 +188,17 @@ def linear_fwd(x, M, K, weight, bias, out, ldc, *, lda=None, epi=EPI_NONE, aux=N
     return out
 
 
-def linear_dx(dy, M, N, weight, out, ldc, *, ld_dy=None, epi=EPI_NONE, aux=None, ld_aux=0):
-    """out[M, K] = dy[M, N] @ weight[N, K]  (optionally * gelu'(aux))."""
+def linear_dx(dy, M, N, weight, out, ldc, *, ld_dy=None, epi=EPI_NONE, aux=None, ld_aux=0, colsum_partial=None):
+    """out[M, K] = dy[M, N] @ weight[N, K]  (optionally * gelu'(aux)).  ``colsum_partial`` (bf16 path, EPI_DGELU only):
+    fp32 [ceil(M/64), K] receiving per-64-row column sums of ``out`` (bias-gradient partials)."""
     K = weight.shape[1]
     ld_dy = N if ld_dy is None else ld_dy
     if dy.dtype == torch.bfloat16:
         pw = prepared_weight(weight)
         t0 = _timer.begin() if _timer is not None else None
         check(lib().mv_gemm_nt_bf16(_p(dy), ld_dy, _p(pw.wt), pw.ldt, _p(out), ldc, _DT[out.dtype], M, K, N, None, epi,
-                                    _p(aux), ld_aux, 0, None, 0, _s()), "gemm_nt_bf16(dx)", M=M, N=K, K=N, epi=epi)
+                                    _p(aux), ld_aux, 0, _p(colsum_partial), K if colsum_partial is not None else 0, _s()),
+              "gemm_nt_bf16(dx)", M=M, N=K, K=N, epi=epi)
         if t0 is not None:
             _timer.end("gemm_nt_bf16", t0, 2.0 * M * N * K)
     else:

@@ -56,7 +56,7 @@ def test_library_exports_every_declared_symbol_with_matching_signature():
     assert handle.mv_version() >= 100
     assert b"aligned" in handle.mv_error_string(-2)
     assert handle.mv_gemm_tn_workspace_bytes(768, 768, 50432) > 0
-    assert handle.mv_layernorm_bwd_workspace_bytes(50432, 768) == 1024 * 2 * 768 * 4
+    assert handle.mv_layernorm_bwd_workspace_bytes(50432, 768) == 1024 * 3 * 768 * 4
 
 
 def test_missing_library_fails_loudly(tmp_path, monkeypatch):
