@@ -624,6 +624,9 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_ring_kernel(const bf16_t* __re
     }                                                                                                      \
     __builtin_amdgcn_s_barrier(); /* stage kt visible to all; every wave is done READING stage kt-1 */     \
     asm volatile("" ::: "memory");                                                                         \
+  }
+#define RING_REFILL(kt_)                                                                                   \
+  {                                                                                                        \
     if ((kt_) + S - 1 < nk) RING_ISSUE(fill, (kt_) + S - 1) /* refill the slot stage kt-1 lived in */      \
   }
 #define RING_READ()                                                                                        \
@@ -654,6 +657,7 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_ring_kernel(const bf16_t* __re
   if (__builtin_amdgcn_readfirstlane(wave) < 4) {
     for (int kt = 0; kt < nk; ++kt) {
       RING_SYNC(kt)
+      RING_REFILL(kt)              // DMA issue (~60-185 cycles per piece of in-order issue time) overlaps the partners' MFMAs
       RING_READ()
       RING_MFMA()
       RING_ADVANCE()
@@ -661,12 +665,14 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_ring_kernel(const bf16_t* __re
   } else {
     for (int kt = 0; kt < nk; ++kt) {
       RING_SYNC(kt)
-      if (kt > 0) RING_MFMA()
-      RING_READ()
+      if (kt > 0) RING_MFMA()      // matrix work first: starts right at the barrier, while waves 0-3 issue DMA and read
+      RING_REFILL(kt)              // ... and this group's DMA issue lands in waves 0-3's MFMA phase
+      RING_READ()                  // (measured: NT prefers DMA-then-read, TN read-then-DMA; +8-20 % over issuing DMA first in both groups)
       RING_ADVANCE()
     }
     if (nk > 0) RING_MFMA()
   }
+#undef RING_REFILL
 #undef RING_SYNC
 #undef RING_READ
 #undef RING_MFMA
@@ -966,6 +972,9 @@ __global__ __launch_bounds__(512, 2) void gemm_tn_ring_kernel(const bf16_t* __re
     }                                                                                                      \
     __builtin_amdgcn_s_barrier();                                                                          \
     asm volatile("" ::: "memory");                                                                         \
+  }
+#define TNR_REFILL(kt_)                                                                                    \
+  {                                                                                                        \
     if ((kt_) + S - 1 < nk) TNR_ISSUE(fill, (kt_) + S - 1)                                                 \
   }
 #define TNR_FRAG(base_, ch_)                                                                               \
@@ -996,7 +1005,8 @@ __global__ __launch_bounds__(512, 2) void gemm_tn_ring_kernel(const bf16_t* __re
   if (__builtin_amdgcn_readfirstlane(wave) < 4) {       // waves 0-3: read stage t, then its MFMAs
     for (int kt = 0; kt < nk; ++kt) {
       TNR_SYNC(kt)
-      TNR_READ()
+      TNR_READ()                   // 24 transposed LDS reads first: their latency hides under this wave's DMA issue
+      TNR_REFILL(kt)               // (measured +20 % over DMA-first; the NT kernel prefers the opposite order)
       TNR_MFMA()
       TNR_ADVANCE()
     }
@@ -1005,12 +1015,14 @@ __global__ __launch_bounds__(512, 2) void gemm_tn_ring_kernel(const bf16_t* __re
       TNR_SYNC(kt)
       if (kt > 0) TNR_MFMA()
       TNR_READ()
+      TNR_REFILL(kt)
       TNR_ADVANCE()
     }
     if (nk > 0) TNR_MFMA()
   }
 #undef TNR_ISSUE
 #undef TNR_SYNC
+#undef TNR_REFILL
 #undef TNR_FRAG
 #undef TNR_READ
 #undef TNR_MFMA
