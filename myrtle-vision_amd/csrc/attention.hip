@@ -39,16 +39,34 @@ __device__ __forceinline__ bf16x4 pack4(f32x4 a) {
   bf16x4 r = {(bf16_t)a[0], (bf16_t)a[1], (bf16_t)a[2], (bf16_t)a[3]};
   return r;
 }
-// transposed fragment: column (lane&15) of the 16 columns starting at col0 (elements), k slots 8g+e <-> rows
-// row_base + 4g + e (e<4) and row_base + 16 + 4g + (e-4); tile has 128-byte rows in the sw128 image
-__device__ __forceinline__ bf16x8 tr_frag128(const char* tile, int row_base, int col0, int lane) {
+// Per-lane LDS offsets of the fragment reads.  Every tile base used below is a multiple of 16 rows, so the swizzle
+// term of sw128 -- a function of (row>>1)&3 -- depends on the LANE only, and every fragment address is
+// "tile + row_base*128 + lane constant (+ 2048 for the second half of a transposed fragment)".  Computing sw128() per
+// read instead cost ~150 VALU instructions per (query pair, key tile) against 16 MFMAs: the kernels were issue-bound.
+struct LaneOff {
+  int rf[2];   // row fragment, k-step 0 / 1: row (lane&15), chunk (4 ks + lane>>4) ^ swz
+  int tr[4];   // transposed fragment for d-tile 0..3: row 4g+q, chunk (2 dt + p>>1) ^ swz, + 8 (p&1)
+};
+__device__ __forceinline__ LaneOff make_lane_off(int lane) {
+  LaneOff L;
   const int g = lane >> 4, q = (lane >> 2) & 3, p = lane & 3;
-  const int r = row_base + 4 * g + q, ch = (col0 >> 3) + (p >> 1), b = 8 * (p & 1);
-  return cat8(tr_read(tile + sw128(r, ch) + b), tr_read(tile + sw128(r + 16, ch) + b));
+  const int fr = (((lane & 15) >> 1) & 3) << 1;
+#pragma unroll
+  for (int ks = 0; ks < 2; ++ks) L.rf[ks] = (lane & 15) * 128 + (((4 * ks + g) ^ fr) << 4);
+  const int rt = 4 * g + q, ft = ((rt >> 1) & 3) << 1;
+#pragma unroll
+  for (int dt = 0; dt < 4; ++dt) L.tr[dt] = rt * 128 + (((2 * dt + (p >> 1)) ^ ft) << 4) + 8 * (p & 1);
+  return L;
 }
-// row fragment: 8 consecutive k (k-step ks of 32) of row (row_base + lane&15)
-__device__ __forceinline__ bf16x8 row_frag128(const char* tile, int row_base, int ks, int lane) {
-  return *reinterpret_cast<const bf16x8*>(tile + sw128(row_base + (lane & 15), 4 * ks + (lane >> 4)));
+// transposed fragment of d-tile dt (pass L.tr[dt]): column (lane&15) of its 16 columns; k slots 8g+e <-> rows
+// row_base + 4g + e (e<4) and row_base + 16 + 4g + (e-4); row_base % 16 == 0
+__device__ __forceinline__ bf16x8 tr_frag128(const char* tile, int row_base, int tr_off) {
+  const char* p0 = tile + row_base * 128 + tr_off;
+  return cat8(tr_read(p0), tr_read(p0 + 2048));
+}
+// row fragment: 8 consecutive k (k-step ks of 32) of row (row_base + lane&15); row_base % 16 == 0
+__device__ __forceinline__ bf16x8 row_frag128(const char* tile, int row_base, int rf_off) {
+  return *reinterpret_cast<const bf16x8*>(tile + row_base * 128 + rf_off);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -62,6 +80,7 @@ __global__ __launch_bounds__(256, (NKT <= 14 ? 2 : 1)) void attn_fwd_kernel(cons
   char* sK = smem;
   char* sV = smem + NP * 128;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 4;
+  const LaneOff L = make_lane_off(lane);
   const int b = blockIdx.x / H, h = blockIdx.x % H;
   const long D = (long)H * 64;
   const bf16_t* base = qkv + (long)b * N * 3 * D + h * 64;
@@ -95,7 +114,7 @@ __global__ __launch_bounds__(256, (NKT <= 14 ? 2 : 1)) void attn_fwd_kernel(cons
       f32x4 acc = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
       for (int ks = 0; ks < 2; ++ks)
-        acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(row_frag128(sK, kt * 16, ks, lane), qf[ks], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(row_frag128(sK, kt * 16, L.rf[ks]), qf[ks], acc, 0, 0, 0);
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const int key = kt * 16 + 4 * g + r;
@@ -127,7 +146,7 @@ __global__ __launch_bounds__(256, (NKT <= 14 ? 2 : 1)) void attn_fwd_kernel(cons
       const bf16x8 pf = pack8(st[2 * u], st[2 * u + 1]);
 #pragma unroll
       for (int dt = 0; dt < 4; ++dt)
-        o[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(tr_frag128(sV, 32 * u, dt * 16, lane), pf, o[dt], 0, 0, 0);
+        o[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(tr_frag128(sV, 32 * u, L.tr[dt]), pf, o[dt], 0, 0, 0);
     }
     if (qrow < N) {
       const float inv = 1.0f / sum;
@@ -159,6 +178,7 @@ __global__ __launch_bounds__(512, 1) void attn_bwd_kernel(const bf16_t* __restri
   float* sDelta = sLse + NP;                                  // [NP] rowsum(dO * O)
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 4;
+  const LaneOff L = make_lane_off(lane);
   const int b = blockIdx.x / H, h = blockIdx.x % H;
   const long D = (long)H * 64;
   const bf16_t* base = qkv + (long)b * N * 3 * D + h * 64;
@@ -245,10 +265,10 @@ __global__ __launch_bounds__(512, 1) void attn_bwd_kernel(const bf16_t* __restri
           dp[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
           for (int ks = 0; ks < 2; ++ks) {
-            s[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(row_frag128(sQ, t * 16, ks, lane),
-                                                           row_frag128(sK, kt * 16, ks, lane), s[t], 0, 0, 0);
-            dp[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(row_frag128(sDO, t * 16, ks, lane),
-                                                            row_frag128(sV, kt * 16, ks, lane), dp[t], 0, 0, 0);
+            s[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(row_frag128(sQ, t * 16, L.rf[ks]),
+                                                           row_frag128(sK, kt * 16, L.rf[ks]), s[t], 0, 0, 0);
+            dp[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(row_frag128(sDO, t * 16, L.rf[ks]),
+                                                            row_frag128(sV, kt * 16, L.rf[ks]), dp[t], 0, 0, 0);
           }
         }
         // P = exp2(S*c2 - lse2[q]),  dS = P * (dP - delta[q]) * scale ; q = 32u + 16t + 4g + r, key on the lane
@@ -267,8 +287,8 @@ __global__ __launch_bounds__(512, 1) void attn_bwd_kernel(const bf16_t* __restri
         const bf16x8 dsf = pack8(ds[0], ds[1]);
 #pragma unroll
         for (int dt = 0; dt < 4; ++dt) {
-          adv[i][dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(tr_frag128(sDO, 0, dt * 16, lane), pf, adv[i][dt], 0, 0, 0);
-          adk[i][dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(tr_frag128(sQ, 0, dt * 16, lane), dsf, adk[i][dt], 0, 0, 0);
+          adv[i][dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(tr_frag128(sDO, 0, L.tr[dt]), pf, adv[i][dt], 0, 0, 0);
+          adk[i][dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(tr_frag128(sQ, 0, L.tr[dt]), dsf, adk[i][dt], 0, 0, 0);
         }
         // dS^T -> LDS: row = key, 4 consecutive queries per lane per q-tile
 #pragma unroll
@@ -281,13 +301,15 @@ __global__ __launch_bounds__(512, 1) void attn_bwd_kernel(const bf16_t* __restri
     // dQ^T[d][q] = sum_key K^T[d][key] dS^T[key][q] : 2 q-tiles x 4 d-tiles = 8 output tiles, one per wave
     if (32 * u < N) {
       const int t = wave >> 2, dt = wave & 3;
+      const int trk = dt == 0 ? L.tr[0] : dt == 1 ? L.tr[1] : dt == 2 ? L.tr[2] : L.tr[3];   // static indices (no scratch)
+      const int dsoff = (4 * g + ((lane >> 2) & 3)) * 64 + ((t ^ (g & 1)) << 5) + 8 * (lane & 3);
       f32x4 dq = {0.f, 0.f, 0.f, 0.f};
       const int q4 = (lane >> 2) & 3, p = lane & 3;
       for (int v = 0; v < NQP; ++v) {
         if (32 * v >= N) break;
-        const int r = 32 * v + 4 * g + q4;
-        const bf16x8 dsf = cat8(tr_read(sds + swds(r, t) + 8 * p), tr_read(sds + swds(r + 16, t) + 8 * p));
-        dq = __builtin_amdgcn_mfma_f32_16x16x32_bf16(tr_frag128(sK, 32 * v, dt * 16, lane), dsf, dq, 0, 0, 0);
+        const char* dsp = sds + 2048 * v + dsoff;               // swds(32 v + 4g + q4, t) + 8 p ; the +16-row block is +1024
+        const bf16x8 dsf = cat8(tr_read(dsp), tr_read(dsp + 1024));
+        dq = __builtin_amdgcn_mfma_f32_16x16x32_bf16(tr_frag128(sK, 32 * v, trk), dsf, dq, 0, 0, 0);
       }
       const int q = 32 * u + 16 * t + (lane & 15);
       if (q < N) *reinterpret_cast<bf16x4*>(dbase + (long)q * 3 * D + dt * 16 + 4 * g) = pack4(dq);
@@ -299,6 +321,187 @@ __global__ __launch_bounds__(512, 1) void attn_bwd_kernel(const bf16_t* __restri
     const int kt = wave + 8 * i;
     const int key = kt * 16 + (lane & 15);
     if (kt < nkt_valid && key < N) {
+#pragma unroll
+      for (int dt = 0; dt < 4; ++dt) {
+        *reinterpret_cast<bf16x4*>(dbase + (long)key * 3 * D + D + dt * 16 + 4 * g) = pack4(adk[i][dt]);
+        *reinterpret_cast<bf16x4*>(dbase + (long)key * 3 * D + 2 * D + dt * 16 + 4 * g) = pack4(adv[i][dt]);
+      }
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// backward, N <= 208: one 256-thread workgroup per (image, head), TWO workgroups per CU
+// ------------------------------------------------------------------------------------------------
+// The 8-wave kernel below needs 104 KB of LDS (one workgroup per CU) and measured 313 us per ViT-B layer: its short
+// phases between barriers have nothing to overlap with.  This variant keeps the same mathematics and fragment maps but
+// fits two workgroups on a CU: single-buffered Q/dO pair and dS^T (two barriers per query pair instead of one), V
+// trimmed to the 13 real key tiles -> 79,616 B.  Wave w owns key tiles w, w+4, w+8, w+12 (128 accumulator VGPRs).
+__global__ __launch_bounds__(256, 2) void attn_bwd4_kernel(const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ out,
+                                                           const bf16_t* __restrict__ dout, const float* __restrict__ lse,
+                                                           bf16_t* __restrict__ dqkv, int N, int H, float scale) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  constexpr int NKT = 13, NPK = 224, NPV = 208, NQP = 7, KPW = 4;
+  char* sK = smem;                           // [224][64] bf16 (rows >= N zero; rows 208..223 exist for the key-pair reads)
+  char* sV = sK + NPK * 128;                 // [208][64]
+  char* sPair = sV + NPV * 128;              // Q[32][64], dO[32][64]
+  char* sDS = sPair + 8192;                  // [224 keys][32 queries] bf16 (dS^T), swds
+  float* sLse = reinterpret_cast<float*>(sDS + NPK * 64);
+  float* sDelta = sLse + NPK;
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 4;
+  const LaneOff L = make_lane_off(lane);
+  const int b = blockIdx.x / H, h = blockIdx.x % H;
+  const long D = (long)H * 64;
+  const bf16_t* base = qkv + (long)b * N * 3 * D + h * 64;
+  const bf16_t* dobase = dout + (long)b * N * D + h * 64;
+  const bf16_t* obase = out + (long)b * N * D + h * 64;
+  bf16_t* dbase = dqkv + (long)b * N * 3 * D + h * 64;
+  const u32x4 zero4 = {0u, 0u, 0u, 0u};
+  const float c2 = scale * LOG2E;
+
+  for (int idx = tid; idx < NPK * 8; idx += 256) {
+    const int row = idx >> 3, ch = idx & 7;
+    const long rr = row < N ? row : N - 1;
+    u32x4 kv = *reinterpret_cast<const u32x4*>(base + rr * 3 * D + D + ch * 8);
+    u32x4 vv = *reinterpret_cast<const u32x4*>(base + rr * 3 * D + 2 * D + ch * 8);
+    kv = row < N ? kv : zero4;
+    vv = row < N ? vv : zero4;
+    *reinterpret_cast<u32x4*>(sK + sw128(row, ch)) = kv;
+    if (row < NPV) *reinterpret_cast<u32x4*>(sV + sw128(row, ch)) = vv;
+  }
+  for (int idx = tid; idx < NPK * 4; idx += 256) reinterpret_cast<u32x4*>(sDS)[idx] = zero4;   // padding key rows stay 0
+  if (tid < NPK) {
+    const int row = tid;
+    float dl = 0.f, l2 = INFINITY;
+    if (row < N) {
+      l2 = lse[((long)b * H + h) * N + row] * LOG2E;
+#pragma unroll
+      for (int c = 0; c < 8; ++c) {
+        const u32x4 a = *reinterpret_cast<const u32x4*>(dobase + (long)row * D + c * 8);
+        const u32x4 o = *reinterpret_cast<const u32x4*>(obase + (long)row * D + c * 8);
+        const bf16x8 av = __builtin_bit_cast(bf16x8, a), ov = __builtin_bit_cast(bf16x8, o);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) dl += (float)av[e] * (float)ov[e];
+      }
+    }
+    sLse[row] = l2;
+    sDelta[row] = dl;
+  }
+
+  // pair staging: 2 tiles x 32 rows x 8 chunks = 512 chunks, two per thread
+  auto load_pair = [&](int u, int e) -> u32x4 {
+    const int idx = tid + 256 * e;
+    const int which = idx >> 8, row = (idx >> 3) & 31, ch = idx & 7;
+    const int q = 32 * u + row;
+    const bf16_t* src = which == 0 ? base + ch * 8 : dobase + ch * 8;
+    const long ld = which == 0 ? 3 * D : D;
+    const u32x4 v = *reinterpret_cast<const u32x4*>(src + (long)(q < N ? q : N - 1) * ld);
+    return q < N ? v : zero4;
+  };
+  auto store_pair = [&](int e, u32x4 v) {
+    const int idx = tid + 256 * e;
+    const int which = idx >> 8, row = (idx >> 3) & 31, ch = idx & 7;
+    *reinterpret_cast<u32x4*>(sPair + which * 4096 + sw128(row, ch)) = v;
+  };
+
+  f32x4 adk[KPW][4], adv[KPW][4];
+#pragma unroll
+  for (int i = 0; i < KPW; ++i)
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt) {
+      adk[i][dt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+      adv[i][dt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    }
+
+  store_pair(0, load_pair(0, 0));
+  store_pair(1, load_pair(0, 1));
+  __syncthreads();
+
+  const char* sQ = sPair;
+  const char* sDO = sPair + 4096;
+  const int nkt_valid = (N + 15) >> 4;
+  for (int u = 0; u < NQP; ++u) {
+    u32x4 nx0 = zero4, nx1 = zero4;
+    if (u + 1 < NQP) {
+      nx0 = load_pair(u + 1, 0);
+      nx1 = load_pair(u + 1, 1);
+    }
+    if (32 * u < N) {
+#pragma unroll
+      for (int i = 0; i < KPW; ++i) {
+        const int kt = wave + 4 * i;
+        if (kt >= nkt_valid || kt >= NKT) continue;
+        const int key = kt * 16 + (lane & 15);
+        f32x4 s[2], dp[2];
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+          s[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+          dp[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+          for (int ks = 0; ks < 2; ++ks) {
+            s[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(row_frag128(sQ, t * 16, L.rf[ks]),
+                                                           row_frag128(sK, kt * 16, L.rf[ks]), s[t], 0, 0, 0);
+            dp[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(row_frag128(sDO, t * 16, L.rf[ks]),
+                                                            row_frag128(sV, kt * 16, L.rf[ks]), dp[t], 0, 0, 0);
+          }
+        }
+        f32x4 pp[2], ds[2];
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const int ql = 32 * u + 16 * t + 4 * g + r;
+            float p = __builtin_amdgcn_exp2f(s[t][r] * c2 - sLse[ql]);
+            p = key < N ? p : 0.f;
+            pp[t][r] = p;
+            ds[t][r] = p * (dp[t][r] - sDelta[ql]) * scale;
+          }
+        const bf16x8 pf = pack8(pp[0], pp[1]);
+        const bf16x8 dsf = pack8(ds[0], ds[1]);
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt) {
+          adv[i][dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(tr_frag128(sDO, 0, L.tr[dt]), pf, adv[i][dt], 0, 0, 0);
+          adk[i][dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(tr_frag128(sQ, 0, L.tr[dt]), dsf, adk[i][dt], 0, 0, 0);
+        }
+#pragma unroll
+        for (int t = 0; t < 2; ++t) *reinterpret_cast<bf16x4*>(sDS + swds(key, t) + 8 * g) = pack4(ds[t]);
+      }
+    }
+    __syncthreads();                                   // S-phase done everywhere: dS^T complete, Q/dO pair no longer read
+    if (u + 1 < NQP) {
+      store_pair(0, nx0);
+      store_pair(1, nx1);
+    }
+    // dQ^T[d][q] = sum_key K^T[d][key] dS^T[key][q]: 2 q-tiles x 4 d-tiles = 8 output tiles, two per wave
+    if (32 * u < N) {
+      const int t = wave >> 1;
+      const int trk0 = (wave & 1) ? L.tr[2] : L.tr[0], trk1 = (wave & 1) ? L.tr[3] : L.tr[1];
+      const int dsoff = (4 * g + ((lane >> 2) & 3)) * 64 + ((t ^ (g & 1)) << 5) + 8 * (lane & 3);
+      f32x4 dq0 = {0.f, 0.f, 0.f, 0.f}, dq1 = {0.f, 0.f, 0.f, 0.f};
+      const int q4 = (lane >> 2) & 3, p = lane & 3;
+      for (int v = 0; v < NQP; ++v) {
+        if (32 * v >= N) break;
+        const char* dsp = sDS + 2048 * v + dsoff;
+        const bf16x8 dsf = cat8(tr_read(dsp), tr_read(dsp + 1024));
+        dq0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(tr_frag128(sK, 32 * v, trk0), dsf, dq0, 0, 0, 0);
+        dq1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(tr_frag128(sK, 32 * v, trk1), dsf, dq1, 0, 0, 0);
+      }
+      const int q = 32 * u + 16 * t + (lane & 15);
+      if (q < N) {
+        bf16_t* dst = dbase + (long)q * 3 * D + (2 * (wave & 1)) * 16 + 4 * g;
+        *reinterpret_cast<bf16x4*>(dst) = pack4(dq0);
+        *reinterpret_cast<bf16x4*>(dst + 16) = pack4(dq1);
+      }
+    }
+    __syncthreads();                                   // dS^T reads done; next Q/dO pair visible
+  }
+
+#pragma unroll
+  for (int i = 0; i < KPW; ++i) {
+    const int kt = wave + 4 * i;
+    const int key = kt * 16 + (lane & 15);
+    if (kt < nkt_valid && kt < NKT && key < N) {
 #pragma unroll
       for (int dt = 0; dt < 4; ++dt) {
         *reinterpret_cast<bf16x4*>(dbase + (long)key * 3 * D + D + dt * 16 + 4 * g) = pack4(adk[i][dt]);
@@ -347,7 +550,14 @@ extern "C" int mv_attention_bwd(const void* qkv, const void* out, const void* do
   MV_REQUIRE(mv_aligned16(qkv) && mv_aligned16(out) && mv_aligned16(dout) && mv_aligned16(dqkv), MV_ERR_ALIGN);
   if (B == 0) return MV_OK;
   hipStream_t s = (hipStream_t)stream;
-  if (N <= 224) {
+  static const int force8 = getenv("MV_ATTN_BWD8") ? 1 : 0;      // tests: force the 8-wave kernel
+  if (N <= 208 && !force8) {
+    constexpr int smem4 = 224 * 128 + 208 * 128 + 8192 + 224 * 64 + 2 * 224 * 4;   // 79,616 B: two workgroups per CU
+    static const int a = set_smem(attn_bwd4_kernel, smem4);
+    if (a) return MV_ERR_LAUNCH;
+    attn_bwd4_kernel<<<B * H, 256, smem4, s>>>((const bf16_t*)qkv, (const bf16_t*)out, (const bf16_t*)dout, lse,
+                                              (bf16_t*)dqkv, N, H, scale);
+  } else if (N <= 224) {
     static const int a = set_smem(attn_bwd_kernel<14, 2>, bwd_smem(14));
     if (a) return MV_ERR_LAUNCH;
     attn_bwd_kernel<14, 2><<<B * H, 512, bwd_smem(14), s>>>((const bf16_t*)qkv, (const bf16_t*)out, (const bf16_t*)dout,
