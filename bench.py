@@ -29,6 +29,16 @@ import torch.distributed as dist  # noqa: E402
 
 TRAIN_GFLOP_PER_IMG = 105.38        # fwd 35.13 GFLOP x 3
 BF16_DENSE_PEAK_TFLOPS = 2500.0     # MI355X_MICROARCH.md: ~2.5 PF dense bf16
+METRIC = {"cls": "images/sec (train fwd+bwd) ViT-B/16 224^2 bf16",
+          "seg": "images/sec (train fwd+bwd) ViT-B/16 segmentation 224^2",
+          "seg256": "images/sec (train fwd+bwd) ViT-B/16 segmentation 256^2",
+          "infer-int8": "images/sec (inference fwd) ViT-B/16 224^2 affine-int8 fake-quant"}
+WORKLOAD = {"cls": "ViT-B/16 224^2 classification training step: zero_grad + fwd + CE + bwd + grad all-reduce + AdamW; "
+                   "1000 classes; random-init weights; batch resident in HBM",
+            "seg": "ViT-B/16 224^2 segmentation training step (17 classes, per-pixel CE over the bilinear-upsampled "
+                   "14x14 map): zero_grad + fwd + CE + bwd + grad all-reduce + AdamW; batch resident in HBM",
+            "seg256": "ViT-B/16 256^2 segmentation training step (17 classes, N=257 tokens, bicubic pos-emb resize)",
+            "infer-int8": "ViT-B/16 224^2 forward only, min/max-calibrated per-tensor affine fake-quant (Q8 sites)"}
 VIT_B = dict(decoder="classification", image_size=224, patch_size=16, num_classes=1000, dim=768, depth=12, heads=12,
              mlp_dim=3072, dropout=0.0, emb_dropout=0.0)
 
@@ -83,6 +93,12 @@ def main():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--batch", type=int, default=256, help="per-GPU batch")
     ap.add_argument("--precision", default="bf16")
+    ap.add_argument("--workload", default="cls", choices=["cls", "seg", "seg256", "infer-int8"],
+                    help="cls = the headline (SURVEY section 8d config 2/3); seg/seg256 = config 4 (segmentation "
+                         "decoder, 17 classes, 224^2 / 256^2); infer-int8 = config 5 (forward only, per-tensor "
+                         "affine fake-quant at the Q8 sites after a 10-batch min/max calibration)")
+    ap.add_argument("--seg-unfused", action="store_true", help="seg: vit(img) + cross_entropy instead of the fused tail")
+    ap.add_argument("--no-optimizer", action="store_true", help="fwd+bwd only (section 8d: report with and without)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timer", action="store_true")
     args = ap.parse_args()
@@ -115,7 +131,13 @@ def main():
     from myrtle_vision.utils.utils import seed_everything
 
     seed_everything(1234)                                   # same initial weights on every rank
-    vit = ViT(precision=args.precision, q_format="FP32", **VIT_B).to(dev)
+    cfg = dict(VIT_B)
+    size = 224
+    if args.workload in ("seg", "seg256"):
+        size = 256 if args.workload == "seg256" else 224
+        cfg.update(decoder="segmentation", num_classes=17, image_size=size)
+    q_format = "PyTorchINT8" if args.workload == "infer-int8" else "FP32"
+    vit = ViT(precision=args.precision, q_format=q_format, **cfg).to(dev)
     arena = ParamArena(vit.named_parameters(), skip=vit.unused_parameter_names())
     opt = AdamW(arena, lr=6.25e-5, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.05)      # vit_base.json
     reducer = GradAllReducer(arena)
@@ -123,18 +145,35 @@ def main():
     opt.grad_scale = reducer.grad_scale
 
     g = torch.Generator().manual_seed(1234 + rank)          # per-rank shard of the synthetic global batch
-    img = torch.randn(args.batch, 3, 224, 224, generator=g).to(dev)
-    labels = torch.randint(0, 1000, (args.batch,), generator=g).to(dev)
+    img = torch.randn(args.batch, 3, size, size, generator=g).to(dev)
+    if args.workload in ("seg", "seg256"):
+        labels = torch.randint(0, 17, (args.batch, size, size), generator=g).to(dev)
+    else:
+        labels = torch.randint(0, 1000, (args.batch,), generator=g).to(dev)
     vit.train()
 
-    def step():
-        opt.zero_grad()
-        logits = vit(img)
-        loss = cross_entropy(logits, labels)
-        loss.backward()
-        reducer.finish()
-        opt.step()
-        return loss
+    if args.workload == "infer-int8":
+        vit.eval()
+        with torch.no_grad():
+            for i in range(10):                                  # min/max calibration (test_quantize.py:26-34)
+                vit(torch.randn(64, 3, size, size, generator=g).to(dev))
+        vit.convert()
+
+        def step():
+            with torch.no_grad():
+                return vit(img).float().mean()
+    else:
+        def step():
+            opt.zero_grad()
+            if args.workload in ("seg", "seg256") and not args.seg_unfused:
+                loss = vit.segmentation_loss(img, labels)[0]     # what segmentation/train.py runs here (engine.py)
+            else:
+                loss = cross_entropy(vit(img), labels)
+            loss.backward()
+            reducer.finish()
+            if not args.no_optimizer:
+                opt.step()
+            return loss
 
     for _ in range(args.warmup):
         loss = step()
@@ -160,16 +199,16 @@ def main():
     if rank == 0:
         img_s = args.batch * world * args.steps / elapsed
         out = {
-            "metric": "images/sec (train fwd+bwd) ViT-B/16 224^2 bf16",
+            "metric": METRIC[args.workload],
             "value": round(img_s, 2), "unit": "images/sec", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(1e3 * elapsed / args.steps, 3), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": args.precision, "data": "synthetic",
-            "config": {"workload": "ViT-B/16 224^2 classification training step: zero_grad + fwd + CE + bwd + "
-                                   "grad all-reduce + AdamW; 1000 classes; random-init weights; batch resident in HBM",
+            "config": {"workload": WORKLOAD[args.workload] + ("" if not args.no_optimizer else " [optimizer step OFF]"),
                        "per_gpu_batch": args.batch, "global_batch": args.batch * world,
                        "parallelism": f"dp{world}", "final_loss": round(final_loss, 4)},
-            "step_mfma_frac": round(img_s / world * TRAIN_GFLOP_PER_IMG * 1e9 / (BF16_DENSE_PEAK_TFLOPS * 1e12), 4),
         }
+        if args.workload == "cls":
+            out["step_mfma_frac"] = round(img_s / world * TRAIN_GFLOP_PER_IMG * 1e9 / (BF16_DENSE_PEAK_TFLOPS * 1e12), 4)
         if timer is not None:
             summ = timer.summary()
             k = summ.get("gemm_nt_bf16")
@@ -181,7 +220,7 @@ def main():
                                    "gflop_per_launch": round(k["flops_per_launch"] / 1e9, 2)}
             out["kernels"] = {n: {"launches": v["launches"], "avg_us": round(v["avg_us"], 1), "tflops": round(v["tflops"], 1),
                                   "ms_per_step": round(v["total_ms"] / args.steps, 3)} for n, v in summ.items()}
-        if world == 1 and not args.no_cpu_baseline:
+        if world == 1 and not args.no_cpu_baseline and args.workload == "cls":
             out["cpu_baseline"] = cpu_baseline()
         print(json.dumps(out))
     if world > 1:

@@ -160,6 +160,21 @@ int mv_upsample_bilinear_fwd(const float* small, long sb, long sc, long sp, floa
 int mv_upsample_bilinear_bwd(const float* dbig, float* dsmall, long sb, long sc, long sp, int B, int C, int h, int w,
                              int H, int W, mv_stream_t stream);
 
+/* ---- fused segmentation tail: CrossEntropyLoss()(Upsample(size=(H,W),'bilinear')(small), labels) ----
+ * replaces vit.py:355,371 (SegmentationDecoder.upsample) + segmentation/train.py:188,261-265 (criterion, argmax, accuracy)
+ * in one pass that never materialises the [B, C, H, W] logits.
+ * small: fp32 [B, h*w, C] (the decoder GEMM output, consumed in place); labels: int64 [B, H, W] in [0, C).
+ * fwd: lse fp32 [B,H,W] (log-sum-exp per pixel, kept for the backward), pred uint8 [B,H,W] (first-index arg-max),
+ *      partials fp32 [2 * mv_seg_ce_partials(B,H,W)] scratch, stats[0] = mean loss, stats[1] = pixel accuracy.
+ * bwd: dsmall (ds_dtype, [B*h*w, ld_ds], columns [C, ld_ds) zeroed) = d(mean loss)/d(small) * grad_scale; gather form,
+ *      deterministic.  MV_ERR_UNSUPPORTED when C > 32 (bwd) or the per-image map does not fit 64 KB of LDS: compose
+ *      mv_upsample_bilinear_* with mv_cross_entropy instead. */
+long mv_seg_ce_partials(int B, int H, int W);
+int mv_seg_ce_fwd(const float* small, const int64_t* labels, float* lse, uint8_t* pred, float* partials, float* stats,
+                  int B, int C, int h, int w, int H, int W, mv_stream_t stream);
+int mv_seg_ce_bwd(const float* small, const int64_t* labels, const float* lse, void* dsmall, int ds_dtype, int ld_ds,
+                  float grad_scale, int B, int C, int h, int w, int H, int W, mv_stream_t stream);
+
 /* ---- optimizer: AdamW step (timm create_optimizer 'adamw' -> torch.optim.AdamW), classification/train.py:161-166,274-277 ----
  * flat fp32 arrays of n elements; decoupled weight decay; bias corrections passed in (host computes from step) */
 int mv_adamw(float* p, const float* g, float* m, float* v, long n, float lr, float beta1, float beta2, float eps,

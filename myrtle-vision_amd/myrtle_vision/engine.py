@@ -64,6 +64,13 @@ def _datasets(task, data_config):
     return mk, collate
 
 
+def _fused_seg_tail(task, criterion):
+    """The segmentation loops may replace ``criterion(vit(x), y)`` + ``argmax`` by ``vit.segmentation_loss`` only when
+    the criterion is the plain mean cross entropy the reference uses (segmentation/train.py:188)."""
+    from myrtle_vision.hip.functional import CrossEntropyLoss
+    return task == "segmentation" and type(criterion) is CrossEntropyLoss
+
+
 @torch.no_grad()
 def validation(val_loader, device, criterion, vit, task, num_classes):
     total_loss, total_acc, n = 0.0, 0.0, max(len(val_loader), 1)
@@ -71,10 +78,15 @@ def validation(val_loader, device, criterion, vit, task, num_classes):
     vit.eval()
     for imgs, labels in val_loader:
         imgs, labels = imgs.to(device), labels.to(device)
-        outputs = vit(imgs)
-        total_loss += float(criterion(outputs, labels)) / n
-        pred = outputs.argmax(dim=1)
-        total_acc += float((pred == labels).float().mean()) / n
+        if _fused_seg_tail(task, criterion):
+            loss, acc, pred = vit.segmentation_loss(imgs, labels)        # no [B,C,H,W] logits
+            total_loss += float(loss) / n
+            total_acc += float(acc) / n
+        else:
+            outputs = vit(imgs)
+            total_loss += float(criterion(outputs, labels)) / n
+            pred = outputs.argmax(dim=1)
+            total_acc += float((pred == labels).float().mean()) / n
         if miou is not None:
             miou.add_img(pred.cpu(), labels.cpu())
     vit.train()
@@ -155,8 +167,12 @@ def train_worker(rank, num_gpus, config, task="classification"):
                 optimizer.zero_grad()
             imgs, labels = imgs.to(device, non_blocking=True), labels.to(device, non_blocking=True)
             reducer.enabled = reducer.world > 1 and (n_accum == n_batch_accum - 1)
-            outputs = vit(imgs)
-            loss = criterion(outputs, labels)
+            if _fused_seg_tail(task, criterion):
+                loss, acc_t, _ = vit.segmentation_loss(imgs, labels)
+            else:
+                outputs = vit(imgs)
+                loss = criterion(outputs, labels)
+                acc_t = None
             loss.backward()
             n_accum += 1
             if n_accum == n_batch_accum:
@@ -165,7 +181,7 @@ def train_worker(rank, num_gpus, config, task="classification"):
                 optimizer.step()
                 iteration += 1
                 if rank == 0:
-                    acc = float((outputs.argmax(dim=1) == labels).float().mean())
+                    acc = float(acc_t) if acc_t is not None else float((outputs.argmax(dim=1) == labels).float().mean())
                     epoch_loss += float(loss.detach()) / len(train_loader)
                     epoch_acc += acc / len(train_loader)
                     print(f"Iteration {iteration}:\tloss={float(loss.detach()):.4f}\tacc={acc:.4f}")

@@ -486,33 +486,60 @@ def cls_head(x, g, b, w, bias, prec):
     return _ClsHead.apply(x, g, b, w, bias, prec)
 
 
+def _seg_small_fwd(x, g, b, w, bias, prec):
+    """x[:, 1:] -> LayerNorm -> Linear(D, C): the [B*h*w, C] fp32 class map before upsampling (vit.py:359-366)."""
+    adt = ops.act_dtype(prec)
+    B, T, D = x.shape
+    C = w.shape[0]
+    npatch = T - 1
+    x = _c(x)
+    xp = ops.gather_patch_rows(x, B, T, D, torch.float32)                # x[:, 1:] as dense rows
+    M = B * npatch
+    y, mean, rstd = ops.layernorm_fwd(xp, D, M, D, g, b, adt)
+    small = torch.empty(M, C, dtype=torch.float32, device=x.device)      # [B, h*w, C]
+    ops.linear_fwd(y, M, D, w, bias, small, C)
+    return small, (xp, g, mean, rstd, y, w)
+
+
+def _seg_small_bwd(saved, dims, dl, ld):
+    """Backward of _seg_small_fwd from d(small) given as [M, ld] in the activation dtype (columns >= C zero)."""
+    xp, g, mean, rstd, y, w = saved
+    B, T, D, C = dims
+    npatch = T - 1
+    M = B * npatch
+    adt = y.dtype
+    dw, dbias = ops.linear_dw(dl, y, M, C, D, ld_dy=ld)
+    dy = torch.empty(M, D, dtype=adt, device=dl.device)
+    ops.linear_dx(dl, M, C, w, dy, D, ld_dy=ld)
+    dx = torch.zeros(B, T, D, dtype=torch.float32, device=dl.device)
+    # rows of image b start at dx[b, 1]: the patch rows of one image are contiguous, images are T*D apart
+    dxp = torch.empty(M, D, dtype=torch.float32, device=dl.device)
+    dg, db = ops.layernorm_bwd(dy, xp, D, g, mean, rstd, None, dxp, D, M, D)
+    dx[:, 1:, :] = dxp.view(B, npatch, D)
+    return dx, dg, db, dw, dbias
+
+
 class _SegHead(Function):
     """SegmentationDecoder: upsample(rearrange(linear(norm(x[:, 1:])))) (vit.py:359-374) -> fp32 [B, C, S, S]."""
 
     @staticmethod
     def forward(ctx, x, g, b, w, bias, grid, size, prec):
-        adt = ops.act_dtype(prec)
         B, T, D = x.shape
         C = w.shape[0]
         npatch = T - 1
-        x = _c(x)
-        xp = ops.gather_patch_rows(x, B, T, D, torch.float32)                # x[:, 1:] as dense rows
-        M = B * npatch
-        y, mean, rstd = ops.layernorm_fwd(xp, D, M, D, g, b, adt)
-        small = torch.empty(M, C, dtype=torch.float32, device=x.device)      # [B, h*w, C]
-        ops.linear_fwd(y, M, D, w, bias, small, C)
+        small, saved = _seg_small_fwd(x, g, b, w, bias, prec)
         big = ops.upsample_bilinear_fwd(small, npatch * C, 1, C, B, C, grid, grid, size, size)
-        ctx.save_for_backward(xp, g, mean, rstd, y, w)
+        ctx.save_for_backward(*saved)
         ctx.dims = (B, T, D, C, grid, size)
         return big
 
     @staticmethod
     def backward(ctx, dbig):
-        xp, g, mean, rstd, y, w = ctx.saved_tensors
+        saved = ctx.saved_tensors
         B, T, D, C, grid, size = ctx.dims
         npatch = T - 1
         M = B * npatch
-        adt = y.dtype
+        adt = saved[4].dtype
         dbig = _c(dbig.float())
         dsmall = torch.empty(M, C, dtype=torch.float32, device=dbig.device)
         ops.upsample_bilinear_bwd(dbig, dsmall, npatch * C, 1, C, B, C, grid, grid, size, size)
@@ -522,15 +549,40 @@ class _SegHead(Function):
             dl[:, :C] = dsmall                                                # (B*196 x 17) pad+cast: cold glue
         else:
             dl = dsmall
-        dw, dbias = ops.linear_dw(dl, y, M, C, D, ld_dy=ld)
-        dy = torch.empty(M, D, dtype=adt, device=dbig.device)
-        ops.linear_dx(dl, M, C, w, dy, D, ld_dy=ld)
-        dx = torch.zeros(B, T, D, dtype=torch.float32, device=dbig.device)
-        # rows of image b start at dx[b, 1]: the patch rows of one image are contiguous, images are T*D apart
-        dxp = torch.empty(M, D, dtype=torch.float32, device=dbig.device)
-        dg, db = ops.layernorm_bwd(dy, xp, D, g, mean, rstd, None, dxp, D, M, D)
-        dx[:, 1:, :] = dxp.view(B, npatch, D)
-        return dx, dg, db, dw, dbias, None, None, None
+        return (*_seg_small_bwd(saved, (B, T, D, C), dl, ld), None, None, None)
+
+
+class _SegHeadLoss(Function):
+    """SegmentationDecoder + CrossEntropyLoss() + argmax in one fused tail (mv_seg_ce_*): the [B, C, S, S] logits are
+    never written (vit.py:355-374 + segmentation/train.py:188,261-265).  -> (loss, pixel accuracy, pred uint8 [B,S,S])."""
+
+    @staticmethod
+    def forward(ctx, x, g, b, w, bias, labels, grid, size, prec):
+        B, T, D = x.shape
+        C = w.shape[0]
+        small, saved = _seg_small_fwd(x, g, b, w, bias, prec)
+        stats, lse, pred, labels = ops.seg_ce_fwd(small, labels, B, C, grid, grid, size, size)
+        adt = ops.act_dtype(prec)
+        ctx.needs = any(ctx.needs_input_grad[:5])
+        if ctx.needs:
+            ld = ops.pad8(C) if adt == torch.bfloat16 else C
+            # the gradient of the mean loss, produced now (labels and lse are hot), scaled by the incoming g in backward
+            dl = ops.seg_ce_bwd(small, labels, lse, B, C, grid, grid, size, size, grad_dtype=adt, ld=ld)
+            ctx.save_for_backward(dl, *saved)
+            ctx.dims = (B, T, D, C, ld)
+        ctx.mark_non_differentiable(pred)
+        return stats[0], stats[1].detach(), pred
+
+    @staticmethod
+    def backward(ctx, gloss, _gacc, _gpred):
+        dl, *saved = ctx.saved_tensors
+        B, T, D, C, ld = ctx.dims
+        dl = dl * gloss.to(dl.dtype)                                          # [B*h*w, ld]: tiny
+        return (*_seg_small_bwd(saved, (B, T, D, C), dl, ld), None, None, None, None)
+
+
+def seg_head_loss(x, g, b, w, bias, labels, grid, size, prec):
+    return _SegHeadLoss.apply(x, g, b, w, bias, labels, grid, size, prec)
 
 
 def seg_head(x, g, b, w, bias, grid, size, prec):

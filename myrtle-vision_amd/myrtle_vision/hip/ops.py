@@ -450,6 +450,40 @@ def upsample_bilinear_bwd(dbig, dsmall, sb, sc, sp, B, C, h, w, H, W):
     return dsmall
 
 
+SEG_CE_MAX_CLASSES = 32
+SEG_CE_LDS_LIMIT = 64 * 1024
+
+
+def seg_ce_supported(C, h, w, W):
+    """Shapes the fused segmentation tail covers (mv_seg_ce_* return MV_ERR_UNSUPPORTED outside them)."""
+    return C <= SEG_CE_MAX_CLASSES and (h * w * C + W * C) * 4 <= SEG_CE_LDS_LIMIT
+
+
+def seg_ce_fwd(small, labels, B, C, h, w, H, W):
+    """small fp32 [B*h*w, C], labels int64 [B,H,W] -> (stats[2] = mean loss, pixel accuracy; lse [B,H,W]; pred u8)."""
+    require_cuda(small, labels)
+    labels = labels.contiguous()
+    if labels.dtype != torch.int64:
+        labels = labels.long()
+    dev = small.device
+    lse = torch.empty(B, H, W, dtype=torch.float32, device=dev)
+    pred = torch.empty(B, H, W, dtype=torch.uint8, device=dev)
+    nblk = lib().mv_seg_ce_partials(B, H, W)
+    partials = torch.empty(max(2 * nblk, 2), dtype=torch.float32, device=dev)
+    stats = torch.empty(2, dtype=torch.float32, device=dev)
+    check(lib().mv_seg_ce_fwd(_p(small), _p(labels), _p(lse), _p(pred), _p(partials), _p(stats), B, C, h, w, H, W, _s()),
+          "seg_ce_fwd", B=B, C=C, h=h, w=w, H=H, W=W)
+    return stats, lse, pred, labels
+
+
+def seg_ce_bwd(small, labels, lse, B, C, h, w, H, W, *, grad_dtype=torch.float32, ld=None, grad_scale=1.0):
+    ld = C if ld is None else ld
+    ds = torch.empty(B * h * w, ld, dtype=grad_dtype, device=small.device)
+    check(lib().mv_seg_ce_bwd(_p(small), _p(labels), _p(lse), _p(ds), _DT[grad_dtype], ld, grad_scale, B, C, h, w, H, W,
+                              _s()), "seg_ce_bwd", B=B, C=C, h=h, w=w, H=H, W=W, ld=ld)
+    return ds
+
+
 def adamw_step(p, g, m, v, *, lr, beta1, beta2, eps, weight_decay, step, grad_scale=1.0):
     """In-place AdamW on flat fp32 tensors (torch.optim.AdamW semantics)."""
     require_cuda(p, g, m, v)

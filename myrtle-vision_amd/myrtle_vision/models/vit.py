@@ -296,7 +296,9 @@ class ViT(nn.Module):
         ops.act_dtype(precision)  # validates
         self.precision = precision
         for m in self.modules():
-            if isinstance(m, _HipModule):
+            # quantised leaves (QATLinear, QLinear, QLayerNorm ...) were re-classed by ModelQuantizer and are no longer
+            # _HipModule instances, but they carry the same attribute and must follow the model
+            if isinstance(m, _HipModule) or hasattr(m, "precision"):
                 m.precision = precision
         return self
 
@@ -325,6 +327,29 @@ class ViT(nn.Module):
                 and self.pos_embedding_cat.plain())
 
     def forward(self, img: torch.Tensor):
+        x = self._backbone(img)
+        with self.cm_mlp_head:
+            output = self.decoder(x)
+        output = self.dequant_output(output)
+        return output
+
+    def segmentation_loss(self, img: torch.Tensor, labels: torch.Tensor):
+        """Extension: what segmentation/train.py:260-265 computes from ``vit(img)`` --
+        ``CrossEntropyLoss()(outputs, labels)``, ``outputs.argmax(dim=1)`` and the pixel accuracy -- in one fused tail
+        that never writes the [B, C, H, W] logits.  -> (loss, accuracy, pred uint8 [B, H, W]).  Falls back to the
+        separate HIP kernels (same numbers, more HBM traffic) for shapes the fused kernels do not cover."""
+        if not isinstance(self.decoder, SegmentationDecoder):
+            raise ValueError("segmentation_loss needs decoder='segmentation'")
+        x = self._backbone(img)
+        with self.cm_mlp_head:
+            if self.decoder.loss_fusable(labels):
+                return self.decoder.loss(x, labels)
+            logits = self.dequant_output(self.decoder(x))
+        loss = F.cross_entropy(logits, labels)
+        pred = logits.detach().argmax(dim=1)
+        return loss, (pred == labels).float().mean(), pred.to(torch.uint8)
+
+    def _backbone(self, img: torch.Tensor):
         ops.require_cuda(img, self.pos_embedding)
         b_dim, c_dim, h_dim, w_dim = img.shape
         p = self.patch_size
@@ -340,11 +365,7 @@ class ViT(nn.Module):
 
         with self.cm_transformer:
             x = self.transformer(x)
-
-        with self.cm_mlp_head:
-            output = self.decoder(x)
-        output = self.dequant_output(output)
-        return output
+        return x
 
     def _embed_unfused(self, img, gh, gw):
         """reference vit.py:271-311 module by module (used when quantisers sit between the steps)."""
@@ -401,6 +422,22 @@ class SegmentationDecoder(nn.Module):
         ops.require_cuda(x)
         return F.seg_head(x.float(), self.norm.weight, self.norm.bias, self.linear.weight, self.linear.bias, g,
                           self.image_size, self.norm.precision)
+
+    def loss_fusable(self, labels) -> bool:
+        g = self.image_size_in_patches
+        return (_plain(self.norm, LayerNorm) and _plain(self.linear, Linear) and not self._forward_hooks
+                and not self.upsample._forward_hooks and isinstance(self.image_size, int)
+                and tuple(labels.shape[1:]) == (self.image_size, self.image_size)
+                and ops.seg_ce_supported(self.linear.out_features, g, g, self.image_size))
+
+    def loss(self, x: torch.Tensor, labels: torch.Tensor):
+        """Fused decoder + mean cross entropy + argmax: (loss, pixel accuracy, pred uint8 [B, S, S])."""
+        g = self.image_size_in_patches
+        if x.shape[1] - 1 != g * g:
+            raise ValueError(f"expected {g * g} patch tokens for image_size {self.image_size}, got {x.shape[1] - 1}")
+        ops.require_cuda(x, labels)
+        return F.seg_head_loss(x.float(), self.norm.weight, self.norm.bias, self.linear.weight, self.linear.bias, labels,
+                               g, self.image_size, self.norm.precision)
 
 
 # ---- reference vit.py:376-396 (detection is out of scope for the HIP path: SURVEY section 2 row 16) --------

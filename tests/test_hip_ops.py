@@ -329,6 +329,54 @@ def test_upsample_bilinear(ops, g_in, size):
     assert relerr(dsmall, ref.grad.reshape(B, C, -1).transpose(1, 2)) < 5e-6
 
 
+@pytest.mark.parametrize("B,C,g_in,size", [(3, 17, 14, 224), (2, 5, 4, 50), (1, 32, 16, 256), (2, 17, 7, 20)])
+def test_seg_ce_fused_tail(ops, B, C, g_in, size):
+    """mv_seg_ce_fwd/bwd == CrossEntropyLoss()(interpolate(small, bilinear), labels) + argmax, without the big logits
+    (vit.py:355,371 + segmentation/train.py:188,261-265); also against the unfused HIP composition."""
+    small = torch.randn(B, g_in * g_in, C, generator=g(1)) * 2             # decoder GEMM layout [B, h*w, C]
+    labels = torch.randint(0, C, (B, size, size), generator=g(2))
+    ref = small.double().transpose(1, 2).reshape(B, C, g_in, g_in).requires_grad_(True)
+    big = torch.nn.functional.interpolate(ref, size=(size, size), mode="bilinear", align_corners=False)
+    l = torch.nn.functional.cross_entropy(big, labels)
+    l.backward()
+    want_grad = ref.grad.reshape(B, C, -1).transpose(1, 2).reshape(B * g_in * g_in, C)
+    assert ops.seg_ce_supported(C, g_in, g_in, size)
+    sm = small.cuda().view(B * g_in * g_in, C)
+    stats, lse, pred, lab = ops.seg_ce_fwd(sm, labels.cuda(), B, C, g_in, g_in, size, size)
+    assert abs(float(stats[0]) - float(l)) < 2e-6 * max(1.0, abs(float(l)))
+    want_pred = big.argmax(1)
+    # arg-max may differ from the fp64 reference only where the top-2 margin is at fp32 rounding level
+    top2 = big.detach().topk(2, dim=1).values
+    safe = (top2[:, 0] - top2[:, 1]) > 1e-5
+    assert torch.equal(pred.cpu().long()[safe], want_pred[safe])
+    assert abs(float(stats[1]) - float((want_pred == labels).double().mean())) < 1e-4
+    assert relerr(lse, torch.logsumexp(big.detach(), dim=1)) < 2e-6
+    ds = ops.seg_ce_bwd(sm, lab, lse, B, C, g_in, g_in, size, size)
+    assert relerr(ds, want_grad) < 1e-5
+    # zero-padded bf16 layout read by the decoder's dW / dX GEMMs, and the grad_scale argument
+    ld = (C + 7) & ~7
+    dsp = ops.seg_ce_bwd(sm, lab, lse, B, C, g_in, g_in, size, size, grad_dtype=torch.bfloat16, ld=ld, grad_scale=2.0)
+    assert dsp.shape == (B * g_in * g_in, ld) and (dsp[:, C:] == 0).all()
+    assert relerr(dsp[:, :C].float(), 2.0 * want_grad) < 2.0 ** -8
+    # unfused HIP composition: same loss, same class map
+    bigh = ops.upsample_bilinear_fwd(sm, g_in * g_in * C, 1, C, B, C, g_in, g_in, size, size)
+    loss_u, dl_u, am_u = ops.cross_entropy(bigh, labels.cuda(), want_grad=True, want_argmax=True)
+    assert abs(float(loss_u) - float(stats[0])) < 2e-6 * max(1.0, abs(float(l)))
+    assert (am_u.cpu() != pred.cpu().long()).float().mean() < 1e-4
+    # deterministic: a second launch is bit-identical
+    ds2 = ops.seg_ce_bwd(sm, lab, lse, B, C, g_in, g_in, size, size)
+    assert torch.equal(ds, ds2)
+
+
+def test_seg_ce_unsupported_shapes_are_rejected(ops):
+    assert not ops.seg_ce_supported(33, 14, 14, 224)
+    assert not ops.seg_ce_supported(17, 32, 32, 512)
+    small = torch.zeros(40 * 40, 17, device="cuda")
+    labels = torch.zeros(1, 640, 640, dtype=torch.int64, device="cuda")
+    with pytest.raises(RuntimeError):
+        ops.seg_ce_fwd(small, labels, 1, 17, 40, 40, 640, 640)          # 40*40*17*4 B > 64 KB of LDS
+
+
 def test_adamw_matches_torch(ops):
     n = 100003
     p0, gr = torch.randn(n, generator=g(1)), torch.randn(n, generator=g(2))

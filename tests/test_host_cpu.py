@@ -23,7 +23,7 @@ def _parse_header():
     src = open(HEADER).read()
     src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
     decls = {}
-    for m in re.finditer(r"\b(int|size_t|const char\*)\s+(mv_\w+)\s*\(([^;]*?)\)\s*;", src, flags=re.S):
+    for m in re.finditer(r"\b(int|long|size_t|const char\*)\s+(mv_\w+)\s*\(([^;]*?)\)\s*;", src, flags=re.S):
         ret, name, args = m.group(1), m.group(2), m.group(3).strip()
         kinds = ""
         if args and args != "void":
@@ -48,12 +48,13 @@ def _parse_header():
 def test_library_exports_every_declared_symbol_with_matching_signature():
     from myrtle_vision.hip import lib
     decls = _parse_header()
-    assert len(decls) >= 31
+    assert len(decls) >= 34
     assert set(decls) == set(lib.SIGNATURES), set(decls) ^ set(lib.SIGNATURES)
     for name, (kinds, _) in decls.items():
         assert lib.SIGNATURES[name][0] == kinds, (name, kinds, lib.SIGNATURES[name][0])
     handle = lib.lib()                      # loads the .so on a machine without a GPU; binds every symbol
     assert handle.mv_version() >= 100
+    assert handle.mv_seg_ce_partials(256, 224, 224) == 256 * 49 and handle.mv_seg_ce_partials(0, 224, 224) == 0
     assert b"aligned" in handle.mv_error_string(-2)
     assert handle.mv_gemm_tn_workspace_bytes(768, 768, 50432) > 0
     assert handle.mv_layernorm_bwd_workspace_bytes(50432, 768) == 1024 * 3 * 768 * 4
@@ -274,3 +275,19 @@ def test_gradient_allreduce_world2_gloo(tmp_path):
     assert torch.allclose(arena.flat_grad, r0["grad"], atol=1e-6, rtol=1e-5)
     f0, f1 = torch.load(tmp_path / "final0.pt"), torch.load(tmp_path / "final1.pt")
     assert torch.equal(f0, f1)                                       # identical parameters on all ranks after K steps
+
+
+@pytest.mark.parametrize("q_format", ["FP16_32", "TF32", "FP16_16", "PyTorchINT8"])
+def test_quantised_formats_force_fp32_on_every_leaf(q_format):
+    """Fake-quantised values are fp32 by definition (reference utils/quantize.py:84): a model built with the default
+    bf16 precision must switch EVERY leaf, including the Linear/LayerNorm modules ModelQuantizer re-classes."""
+    from myrtle_vision.models.vit import ViT
+    v = ViT(precision="bf16", q_format=q_format, decoder="classification", image_size=80, patch_size=16, num_classes=10,
+            dim=128, depth=1, heads=2, mlp_dim=128, dropout=0.0, emb_dropout=0.0)
+    precs = {n: m.precision for n, m in v.named_modules() if hasattr(m, "precision")}
+    assert len(precs) > 8 and set(precs.values()) == {"fp32"}, precs
+    if q_format == "PyTorchINT8":
+        return                                   # its convert() runs the min/max kernel on the weights: GPU only
+    v.convert()
+    precs = {n: m.precision for n, m in v.named_modules() if hasattr(m, "precision")}
+    assert set(precs.values()) == {"fp32"}, precs

@@ -102,6 +102,53 @@ def check_case(name, precision, tol_logits, tol_grad, q_format=None):
     return worst
 
 
+@pytest.mark.parametrize("precision,tol,tol_grad", [("fp32", 1e-3, 1e-3), ("bf16", 3e-2, 6e-2)])
+def test_fused_segmentation_tail_matches_reference(precision, tol, tol_grad):
+    """``vit.segmentation_loss`` (decoder + bilinear upsample + CE + argmax without the [B,C,H,W] logits) against the
+    reference's loss / arg-max / gradients for micro_seg, and against ``cross_entropy(vit(img))`` on the same model."""
+    from myrtle_vision.hip.functional import cross_entropy
+    vit, img, labels, arrays, meta = build("micro_seg", precision)
+    vit.train()
+    loss, acc, pred = vit.segmentation_loss(img, labels)
+    assert pred.dtype == torch.uint8 and pred.shape == labels.shape and not pred.requires_grad
+    loss.backward()
+    torch.cuda.synchronize()
+    assert abs(float(loss) - float(arrays["loss"])) < tol * max(1.0, abs(float(arrays["loss"])))
+    if precision == "fp32":
+        assert (pred[:, ::7, ::7].cpu().numpy() == arrays["argmax_sub"]).all()
+    fused = {}
+    for pname, p in vit.named_parameters():
+        if p.grad is None:
+            continue
+        c = canonical(pname)
+        w = arrays[f"gsum:{c}"]
+        got = summarize(p.grad.float().cpu()).numpy()
+        if precision == "fp32":
+            e = max(np.abs(got[:4] - w[:4]).max() / max(w[1], 1e-30), np.abs(got[4:] - w[4:]).max() / max(w[2], 1e-30))
+        else:
+            e = max(abs(got[1] - w[1]) / max(w[1], 1e-30), abs(got[2] - w[2]) / max(w[2], 1e-30),
+                    np.abs(got[4:] - w[4:]).max() / max(w[2], 1e-30))
+        assert e < tol_grad, (c, e)
+        fused[pname] = p.grad.clone()
+        p.grad = None
+    # the drop-in path on the same weights: same loss, same accuracy, same gradients
+    logits = vit(img)
+    loss_u = cross_entropy(logits, labels)
+    loss_u.backward()
+    same = 1e-5 if precision == "fp32" else 2e-2
+    assert abs(float(loss_u) - float(loss)) < same * max(1.0, abs(float(loss_u)))
+    assert abs(float(acc) - float((logits.argmax(1) == labels).float().mean())) < 1e-3
+    for pname, p in vit.named_parameters():
+        if p.grad is None:
+            continue
+        d = (p.grad - fused[pname]).float().norm() / p.grad.float().norm().clamp_min(1e-30)
+        assert float(d) < same, (pname, float(d))
+    # evaluation: no graph, no backward kernel
+    with torch.no_grad():
+        l2, a2, p2 = vit.segmentation_loss(img, labels)
+    assert float(l2) == float(loss) and torch.equal(p2, pred)
+
+
 @pytest.mark.parametrize("name", CASES)
 def test_fp32_matches_reference(name):
     check_case(name, "fp32", 1e-3, 1e-3)
