@@ -30,6 +30,8 @@
 // sharing one A row-panel run on one XCD and hit its L2.
 #include "mv_common.h"
 
+#include <atomic>
+
 #ifndef MV_ABLATE
 #define MV_ABLATE 0   // diagnostic builds only (tools/ablate_gemm.sh); 0 in the product
 #endif
@@ -684,6 +686,191 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_ring_kernel(const bf16_t* __re
                          wn & 1, lane, ep);
 }
 
+// ------------------------------------------------------------------------------------------------
+// NT kernel, 256x256 tile, BK = 64, EIGHT PHASES per two K-tiles (K % 128 == 0)
+// ------------------------------------------------------------------------------------------------
+// Structure after the "256^2 8-phase template" of cdna_hip_programming.md section 5 (its example source is not part of
+// this image; the schedule below is derived from the description and checked hazard by hazard):
+//  * 8 waves = 2 (M) x 4 (N), 128x64 outputs per wave, as the ring kernel -> same epilogue.
+//  * a phase = 16 MFMAs = one 64x32 quadrant of the wave's outputs over one K-tile of 64.  Quadrant order per K-tile:
+//    (qm0,qn0) (qm0,qn1) (qm1,qn1) (qm1,qn0): phase 1 reads B_q0 + A_q0 fragments, phase 2 B_q1, phase 3 A_q1, phase 4
+//    nothing (B_q0 is still in registers).
+//  * LDS = 2 buffers x 4 slots of 16 KiB.  A slot is organised BY USE, not by wave: A_qm holds, for both wave rows, the
+//    64 rows of quadrant-row qm (128 rows x 64 k); B_qn holds the 32 columns of quadrant-column qn of all four wave
+//    columns.  Every slot is therefore read in exactly ONE phase and can be restaged 2 phases later (1 phase later for
+//    B_q0, whose reads are retired by lgkmcnt(8) before that phase's first barrier).
+//  * every phase all 512 threads stage ONE slot (2 global_load_lds_dwordx4 each; rows are whole 128-byte lines):
+//      phase: 1        2        3        4        5        6        7        8
+//      slot : A_q1[t+1] B_q0[t+2] A_q0[t+2] B_q1[t+2] A_q1[t+2] B_q0[t+3] A_q0[t+3] B_q1[t+3]
+//    and waits only twice: vmcnt(6) in phase 4 (everything up to phase 1 landed = K-tile t+1 complete, read in phases
+//    5-7) and in phase 8 (K-tile t+2 complete).  Three slots (48 KiB) stay in flight across those waits.
+//  * a phase is  [ds_reads | stage | (waits) | barrier | lgkmcnt(0) | 16 MFMA | barrier];  waves 4-7 run ONE BARRIER
+//    behind waves 0-3, so the reads + DMA issue of one group overlap the MFMAs of the other on every SIMD.
+//    RAW: a vmcnt wait sits before a phase's first barrier and the data is read in the NEXT phase, so both groups have
+//    waited and met a barrier before either reads.  WAR: restaging 2 phases after the last read leaves >= 3 barrier
+//    intervals between the lagging group's lgkmcnt(0) and the leading group's DMA issue.
+//  * the last iteration is peeled: it stages only K-tile nk-1's last slot and waits vmcnt(0), so nothing is fetched
+//    beyond K and nothing is outstanding at the epilogue.
+constexpr int P8_SLOT = 128 * 64 * 2;   // 16 KiB
+constexpr int P8_SMEM = 8 * P8_SLOT;    // 128 KiB
+constexpr int P8_BQ0 = 0, P8_AQ0 = 1, P8_BQ1 = 2, P8_AQ1 = 3;   // slot order in a buffer = staging order
+
+template <int EPI, typename CT>
+__global__ __launch_bounds__(512, 2) void gemm_nt_8phase_kernel(const bf16_t* __restrict__ A, int lda,
+                                                                const bf16_t* __restrict__ B, int ldb, CT* __restrict__ C,
+                                                                int ldc, int M, int N, int K, int tiles_n, EpiArgs ep) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 2, wn = wave & 3;
+  const int t = xcd_remap(blockIdx.x, gridDim.x);
+  const int m0 = (t / tiles_n) * BM2, n0 = (t % tiles_n) * BN2;
+
+  // staging: wave w moves pieces 2w and 2w+1 of a slot (1 KiB = 8 slot rows of 128 B each); lane l -> row l>>3, 16-byte
+  // chunk l&7 of the LDS image, i.e. logical chunk (l&7) ^ swz(row) of the source row (swizzle on the SOURCE side)
+  unsigned ps[4][2];                          // element offsets from A / B (dispatch guarantees they fit 32 bits)
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int rloc = 16 * wave + 8 * i + (lane >> 3);
+    const int ch = (lane & 7) ^ (((rloc >> 1) & 3) << 1);
+    const int ra = m0 + 128 * (wave >> 2) + 16 * (wave & 3) + 8 * i + (lane >> 3);     // + 64 qm
+    const int rb = n0 + 64 * (wave >> 1) + 16 * (wave & 1) + 8 * i + (lane >> 3);      // + 32 qn
+    const int ra0 = ra < M ? ra : M - 1, ra1 = ra + 64 < M ? ra + 64 : M - 1;
+    const int rb0 = rb < N ? rb : N - 1, rb1 = rb + 32 < N ? rb + 32 : N - 1;
+    ps[P8_AQ0][i] = (unsigned)ra0 * (unsigned)lda + ch * 8;
+    ps[P8_AQ1][i] = (unsigned)ra1 * (unsigned)lda + ch * 8;
+    ps[P8_BQ0][i] = (unsigned)rb0 * (unsigned)ldb + ch * 8;
+    ps[P8_BQ1][i] = (unsigned)rb1 * (unsigned)ldb + ch * 8;
+  }
+  char* const wave_lds = smem + wave * 2048;
+#define P8_STAGE(buf_, slot_, kt_)                                                      \
+  {                                                                                     \
+    char* l_ = wave_lds + ((buf_) * 4 + (slot_)) * P8_SLOT;                             \
+    const bf16_t* g_ = (((slot_) == P8_AQ0 || (slot_) == P8_AQ1) ? A : B) + (kt_) * 64; \
+    glds16(g_ + ps[slot_][0], l_);                                                      \
+    glds16(g_ + ps[slot_][1], l_ + 1024);                                               \
+  }
+
+  f32x4 acc[8][4];
+#pragma unroll
+  for (int i = 0; i < 8; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  // fragment reads: slot rows 64 wm + 16 mt + (lane&15) (A) / 32 wn + 16 nt + (lane&15) (B); all bases are multiples
+  // of 16 rows, so the sw128 term depends on the lane only
+  const int fr = (((lane & 15) >> 1) & 3) << 1;
+  const int rf0 = (lane & 15) * 128 + (((lane >> 4) ^ fr) << 4);
+  const int rf1 = (lane & 15) * 128 + (((4 + (lane >> 4)) ^ fr) << 4);
+  const char* const a_rd = smem + 64 * wm * 128;
+  const char* const b_rd = smem + 32 * wn * 128;
+  bf16x8 af[4][2], bf0[2][2], bf1[2][2];
+#define P8_READ_A(buf_, slot_)                                                                               \
+  {                                                                                                          \
+    const char* s_ = a_rd + ((buf_) * 4 + (slot_)) * P8_SLOT;                                                \
+    _Pragma("unroll") for (int i = 0; i < 4; ++i) {                                                          \
+      af[i][0] = *reinterpret_cast<const bf16x8*>(s_ + i * 2048 + rf0);                                      \
+      af[i][1] = *reinterpret_cast<const bf16x8*>(s_ + i * 2048 + rf1);                                      \
+    }                                                                                                        \
+  }
+#define P8_READ_B(dst_, buf_, slot_)                                                                         \
+  {                                                                                                          \
+    const char* s_ = b_rd + ((buf_) * 4 + (slot_)) * P8_SLOT;                                                \
+    _Pragma("unroll") for (int j = 0; j < 2; ++j) {                                                          \
+      dst_[j][0] = *reinterpret_cast<const bf16x8*>(s_ + j * 2048 + rf0);                                    \
+      dst_[j][1] = *reinterpret_cast<const bf16x8*>(s_ + j * 2048 + rf1);                                    \
+    }                                                                                                        \
+  }
+#define P8_MFMA(mb_, nb_, bfx_)                                                                              \
+  {                                                                                                          \
+    __builtin_amdgcn_s_setprio(1);                                                                           \
+    _Pragma("unroll") for (int ks = 0; ks < 2; ++ks)                                                         \
+      _Pragma("unroll") for (int i = 0; i < 4; ++i)                                                          \
+        _Pragma("unroll") for (int j = 0; j < 2; ++j)                                                        \
+          acc[(mb_) + i][(nb_) + j] =                                                                        \
+              __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfx_[j][ks], af[i][ks], acc[(mb_) + i][(nb_) + j], 0, 0, 0); \
+    __builtin_amdgcn_s_setprio(0);                                                                           \
+  }
+#define P8_BAR()                                  \
+  {                                               \
+    __builtin_amdgcn_sched_barrier(0);            \
+    __builtin_amdgcn_s_barrier();                 \
+    asm volatile("" ::: "memory");                \
+    __builtin_amdgcn_sched_barrier(0);            \
+  }
+#define P8_LGKM0()                                          \
+  {                                                         \
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      \
+    __builtin_amdgcn_sched_barrier(0);                      \
+  }
+// one K-tile (4 phases) out of buffer d_; ST_ = 1: stage per the schedule (k-tile indices t1_, t2_ for the two buffers'
+// next contents), ST_ = 0: the drained tail.  WAIT_: asm string of the phase-4/8 wait.
+#define P8_KTILE(d_, ST_, first_slot_buf_, first_slot_kt_, next_buf_, next_kt_, after_buf_, after_kt_, WAIT_, STAGE_FIRST_) \
+  {                                                                                                          \
+    /* phase 1/5 */                                                                                          \
+    P8_READ_B(bf0, d_, P8_BQ0)                                                                               \
+    __builtin_amdgcn_sched_barrier(0);                                                                       \
+    P8_READ_A(d_, P8_AQ0)                                                                                    \
+    __builtin_amdgcn_sched_barrier(0);                                                                       \
+    if (STAGE_FIRST_) P8_STAGE(first_slot_buf_, P8_AQ1, first_slot_kt_)                                      \
+    asm volatile("s_waitcnt lgkmcnt(8)" ::: "memory"); /* the 4 B_q0 reads (issued first) have returned */   \
+    P8_BAR()                                                                                                 \
+    P8_LGKM0()                                                                                               \
+    P8_MFMA(0, 0, bf0)                                                                                       \
+    P8_BAR()                                                                                                 \
+    /* phase 2/6 */                                                                                          \
+    P8_READ_B(bf1, d_, P8_BQ1)                                                                               \
+    __builtin_amdgcn_sched_barrier(0);                                                                       \
+    if (ST_) P8_STAGE(next_buf_, P8_BQ0, next_kt_)                                                           \
+    P8_BAR()                                                                                                 \
+    P8_LGKM0()                                                                                               \
+    P8_MFMA(0, 2, bf1)                                                                                       \
+    P8_BAR()                                                                                                 \
+    /* phase 3/7 */                                                                                          \
+    P8_READ_A(d_, P8_AQ1)                                                                                    \
+    __builtin_amdgcn_sched_barrier(0);                                                                       \
+    if (ST_) P8_STAGE(next_buf_, P8_AQ0, next_kt_)                                                           \
+    P8_BAR()                                                                                                 \
+    P8_LGKM0()                                                                                               \
+    P8_MFMA(4, 2, bf1)                                                                                       \
+    P8_BAR()                                                                                                 \
+    /* phase 4/8 */                                                                                          \
+    if (ST_) P8_STAGE(next_buf_, P8_BQ1, next_kt_)                                                           \
+    asm volatile(WAIT_ ::: "memory");                                                                        \
+    P8_BAR()                                                                                                 \
+    P8_MFMA(4, 0, bf0)                                                                                       \
+    P8_BAR()                                                                                                 \
+  }
+
+  const int nk = K >> 6;                        // even, >= 2 (dispatch)
+  P8_STAGE(0, P8_BQ0, 0) P8_STAGE(0, P8_AQ0, 0) P8_STAGE(0, P8_BQ1, 0) P8_STAGE(0, P8_AQ1, 0)
+  P8_STAGE(1, P8_BQ0, 1) P8_STAGE(1, P8_AQ0, 1) P8_STAGE(1, P8_BQ1, 1)
+  asm volatile("s_waitcnt vmcnt(6)" ::: "memory");     // K-tile 0 landed
+  P8_BAR()
+  if (__builtin_amdgcn_readfirstlane(wave) >= 4) P8_BAR()      // waves 4-7 run one barrier behind
+  int kt = 0;
+  for (; kt < nk - 2; kt += 2) {
+    // phases 1-4: compute buffer 0 (K-tile kt); stage A_q1[kt+1] -> buffer 1, then B_q0/A_q0/B_q1[kt+2] -> buffer 0
+    P8_KTILE(0, 1, 1, kt + 1, 0, kt + 2, 0, 0, "s_waitcnt vmcnt(6)", 1)
+    // phases 5-8: compute buffer 1 (K-tile kt+1); stage A_q1[kt+2] -> buffer 0, then B_q0/A_q0/B_q1[kt+3] -> buffer 1
+    P8_KTILE(1, 1, 0, kt + 2, 1, kt + 3, 0, 0, "s_waitcnt vmcnt(6)", 1)
+  }
+  // peeled last iteration: only K-tile nk-1's A_q1 is still to be staged
+  P8_KTILE(0, 0, 1, kt + 1, 0, 0, 0, 0, "s_waitcnt vmcnt(0)", 1)
+  P8_KTILE(1, 0, 0, 0, 0, 0, 0, 0, "", 0)
+  if (__builtin_amdgcn_readfirstlane(wave) < 4) P8_BAR()
+#undef P8_KTILE
+#undef P8_LGKM0
+#undef P8_BAR
+#undef P8_MFMA
+#undef P8_READ_A
+#undef P8_READ_B
+#undef P8_STAGE
+#pragma unroll
+  for (int h = 0; h < 2; ++h)
+    nt_epilogue<EPI, CT>(*reinterpret_cast<f32x4(*)[4][4]>(&acc[4 * h]), C, ldc, M, N, m0 + 128 * wm, n0 + 128 * (wn >> 1), h,
+                         wn & 1, lane, ep);
+}
+
 __device__ __forceinline__ void tn_store(f32x4 (&acc)[4][4], float* __restrict__ Cs, long ldc, int M, int N, int m0, int n0,
                                          int wm, int wn, int lane) {
   const bool ldc_vec = (ldc & 3) == 0;
@@ -1090,6 +1277,10 @@ int colsum_parts(long rows) {
   return (int)p;
 }
 
+// kernel-variant override (0 = automatic): initialised from MV_GEMM_TILE / MV_GEMM_TN, changed by mv_gemm_force_variant
+std::atomic<int> g_force_nt{getenv("MV_GEMM_TILE") ? atoi(getenv("MV_GEMM_TILE")) : 0};
+std::atomic<int> g_force_tn{getenv("MV_GEMM_TN") ? atoi(getenv("MV_GEMM_TN")) : 0};
+
 struct TnPlan {
   int tiles_m, tiles_n, splits, steps_per_split;
 };
@@ -1126,7 +1317,7 @@ TnPlan tn_plan256(int M, int N, int Kc) {
   return pl;
 }
 bool tn_use_ring(int M, int N, int Kc) {
-  static const int force = getenv("MV_GEMM_TN") ? atoi(getenv("MV_GEMM_TN")) : 0;     // 128 | 256: tuning and tests
+  const int force = g_force_tn.load(std::memory_order_relaxed);                        // 128 | 256: tuning and tests
   if (Kc <= 0 || Kc % BKR != 0 || force == 128) return false;
   if (force == 256) return true;
   return (long)M * N >= 256L * 256 * 4 && Kc >= 4096;   // >= 4 tiles and a contraction long enough to split over the chip
@@ -1151,11 +1342,22 @@ int launch_nt(const void* A, int lda, const void* B, int ldb, void* C, int ldc, 
   const int t2m = mv_cdiv(M, BM2), t2n = mv_cdiv(N, BN2);
   // Kernel choice (measured on MI355X, tools/bench_gemm.py, M = 50432): the 256x256 ring kernel wins whenever its
   // grid fills the chip for >= 4 rounds (N >= 1536) or K is long enough to amortise its fill/drain (K >= 2048);
-  // otherwise two 128x128 workgroups per CU overlap each other's epilogues better.  MV_GEMM_TILE = 128 | 256 | 2564
-  // forces a variant (tuning and tests).
-  static const int force = getenv("MV_GEMM_TILE") ? atoi(getenv("MV_GEMM_TILE")) : 0;
+  // otherwise two 128x128 workgroups per CU overlap each other's epilogues better.  Where the ring kernel would be
+  // picked and K % 128 == 0, the 8-phase kernel replaces it (+6-14 % on every ViT-B shape: whole 128-byte lines per
+  // DMA row, 16-MFMA phases).  MV_GEMM_TILE = 128 | 256 | 2564 (ring) | 2568 (8-phase) forces a variant (tuning, tests).
+  const int force = g_force_nt.load(std::memory_order_relaxed);
   const bool ring_ok = K > 0 && K % BKR == 0;
   const bool ring_pick = ring_ok && ((long)t2m * t2n >= 1024 || (K >= 2048 && (long)t2m * t2n >= 256));
+  const bool p8_ok = K >= 128 && K % 128 == 0 && (long)M * lda < (1L << 31) && (long)N * ldb < (1L << 31);
+  if ((force == 2568 && p8_ok) || (force == 0 && ring_pick && p8_ok)) {
+    static const int a8 = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_nt_8phase_kernel<EPI, CT>),
+                                              hipFuncAttributeMaxDynamicSharedMemorySize, P8_SMEM) == hipSuccess ? 0 : -1;
+    if (a8) return MV_ERR_LAUNCH;
+    gemm_nt_8phase_kernel<EPI, CT><<<t2m * t2n, 512, P8_SMEM, s>>>((const bf16_t*)A, lda, (const bf16_t*)B, ldb, (CT*)C, ldc,
+                                                                   M, N, K, t2n, ep);
+    MV_CHECK_LAUNCH();
+    return MV_OK;
+  }
   if ((force == 2564 && ring_ok) || (force == 0 && ring_pick)) {
     static const int a4 = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_nt_ring_kernel<EPI, CT, 4>),
                                               hipFuncAttributeMaxDynamicSharedMemorySize, 4 * RSTAGE_BYTES) == hipSuccess ? 0 : -1;
@@ -1205,6 +1407,15 @@ extern "C" int mv_gemm_nt_bf16(const void* A, int lda, const void* B, int ldb, v
     default:
       return MV_ERR_UNSUPPORTED;
   }
+}
+
+extern "C" int mv_gemm_force_variant(int nt_variant, int tn_variant) {
+  const bool nt_ok = nt_variant == 0 || nt_variant == 128 || nt_variant == 256 || nt_variant == 2564 || nt_variant == 2568;
+  const bool tn_ok = tn_variant == 0 || tn_variant == 128 || tn_variant == 256;
+  MV_REQUIRE(nt_ok && tn_ok, MV_ERR_UNSUPPORTED);
+  g_force_nt.store(nt_variant, std::memory_order_relaxed);
+  g_force_tn.store(tn_variant, std::memory_order_relaxed);
+  return MV_OK;
 }
 
 extern "C" size_t mv_gemm_tn_workspace_bytes(int M, int N, int Kc) {

@@ -50,6 +50,7 @@ SIGNATURES = {
     "mv_cross_entropy": ("ppp" "pii" "p" "lil" "f" "p", _I),
     "mv_upsample_bilinear_fwd": ("plll" "p" "iiiiii" "p", _I),
     "mv_upsample_bilinear_bwd": ("pplll" "iiiiii" "p", _I),
+    "mv_gemm_force_variant": ("ii", _I),
     "mv_seg_ce_partials": ("iii", _L),
     "mv_seg_ce_fwd": ("pppppp" "iiiiii" "p", _I),
     "mv_seg_ce_bwd": ("pppp" "ii" "f" "iiiiii" "p", _I),

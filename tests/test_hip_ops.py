@@ -93,6 +93,45 @@ def test_gemm_nt_bias_f32_out(ops, M, N, K):
     assert relerr(out16.float(), want) < 2.0 ** -8        # + one bf16 rounding
 
 
+# Every NT / TN kernel variant on shapes large enough to reach it (>= 2 tiles of 256, ragged M and N edges, K long
+# enough for the 8-phase pipeline), all epilogues.  The automatic dispatch only picks the 256^2 kernels for >= 256
+# tiles, which no unit-test shape has; mv_gemm_force_variant switches variants inside this one process.
+@pytest.mark.parametrize("variant", [128, 256, 2564, 2568])
+@pytest.mark.parametrize("M,N,K", [(520, 300, 256), (777, 1000, 768), (256, 256, 128), (1030, 520, 3072)])
+def test_gemm_nt_every_variant(ops, variant, M, N, K):
+    from myrtle_vision.hip.lib import lib, check
+    a, w, b = bf(torch.randn(M, K, generator=g(1))), bf(torch.randn(N, K, generator=g(2)) * K ** -0.5), torch.randn(N, generator=g(3)) * 0.1
+    pre = a.double() @ w.double().t() + b.double()
+    wp = w.float().cuda()
+    check(lib().mv_gemm_force_variant(variant, 0), "force_variant")
+    try:
+        out = torch.empty(M, N, device="cuda")
+        ops.linear_fwd(a.cuda(), M, K, wp, b.cuda(), out, N)
+        assert relerr(out, pre) < 3e-6
+        ldn = (N + 7) & ~7
+        act = torch.zeros(M, ldn, device="cuda", dtype=torch.bfloat16)
+        h = torch.zeros(M, ldn, device="cuda", dtype=torch.bfloat16)
+        ops.linear_fwd(a.cuda(), M, K, wp, b.cuda(), act, ldn, epi=ops.EPI_GELU, out2=h, ld_out2=ldn)
+        assert relerr(h[:, :N].float(), pre) < 2.0 ** -8 and relerr(act[:, :N].float(), gelu_erf(pre)) < 2.0 ** -8
+        res = torch.randn(M, N, generator=g(4))
+        ops.linear_fwd(a.cuda(), M, K, wp, b.cuda(), out, N, epi=ops.EPI_RESIDUAL, aux=res.cuda(), ld_aux=N)
+        assert relerr(out, pre + res.double()) < 3e-6
+        # dX entry point with DGELU (+ fc1 bias-gradient partial sums): contraction over N here
+        if N % 8 == 0:
+            dy, hh = bf(torch.randn(M, N, generator=g(5))), bf(torch.randn(M, K, generator=g(6)))
+            want = (dy.double() @ w.double()) * dgelu64(hh)
+            dx = torch.empty(M, K, device="cuda", dtype=torch.bfloat16)
+            ops.linear_dx(dy.cuda(), M, N, wp, dx, K, epi=ops.EPI_DGELU, aux=hh.cuda(), ld_aux=K)
+            assert relerr(dx.float(), want) < 2.0 ** -8
+        # a second launch is bit-identical (no race between DMA and fragment reads shows up as a flaky tile)
+        out2 = torch.empty(M, N, device="cuda")
+        for _ in range(3):
+            ops.linear_fwd(a.cuda(), M, K, wp, b.cuda(), out2, N, epi=ops.EPI_RESIDUAL, aux=res.cuda(), ld_aux=N)
+            assert torch.equal(out, out2)
+    finally:
+        check(lib().mv_gemm_force_variant(0, 0), "force_variant")
+
+
 def test_gemm_nt_epilogues(ops):
     M, N, K = 1576, 768, 192
     a, w, b = bf(torch.randn(M, K, generator=g(1))), bf(torch.randn(N, K, generator=g(2)) * K ** -0.5), torch.randn(N, generator=g(3)) * 0.1
@@ -140,6 +179,23 @@ def test_gemm_tn_dw_and_colsum(ops, Kc, M, N):
     dw, db = ops.linear_dw(dy.cuda(), x.cuda(), Kc, M, N)
     assert relerr(dw, want) < 3e-6
     assert relerr(db, dy.double().sum(0)) < 3e-6
+
+
+@pytest.mark.parametrize("variant", [128, 256])
+@pytest.mark.parametrize("Kc,M,N", [(4096, 520, 300 // 4 * 4 + 4), (6400, 768, 768), (2080, 264, 1000)])
+def test_gemm_tn_every_variant(ops, variant, Kc, M, N):
+    from myrtle_vision.hip.lib import lib, check
+    dy, x = bf(torch.randn(Kc, M, generator=g(1))), bf(torch.randn(Kc, N, generator=g(2)))
+    want = dy.double().t() @ x.double()
+    check(lib().mv_gemm_force_variant(0, variant), "force_variant")
+    try:
+        dw, db = ops.linear_dw(dy.cuda(), x.cuda(), Kc, M, N)
+        assert relerr(dw, want) < 3e-6
+        assert relerr(db, dy.double().sum(0)) < 3e-6
+        dw2, _ = ops.linear_dw(dy.cuda(), x.cuda(), Kc, M, N)
+        assert torch.equal(dw, dw2)                                   # deterministic split-K reduce
+    finally:
+        check(lib().mv_gemm_force_variant(0, 0), "force_variant")
 
 
 def test_misaligned_leading_dimension_is_rejected(ops):
