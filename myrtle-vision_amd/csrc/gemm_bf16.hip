@@ -135,6 +135,21 @@ __device__ __forceinline__ float dgelu_fast(float x) {
 // Interior tiles take the fast path: ALL bias/aux vectors are loaded before the first store.  (aux and C are
 // different buffers by contract, but the compiler cannot know, and interleaving "load aux, store C" serialises
 // sixteen HBM round trips per lane: the +residual GEMM measured 242 TFLOP/s that way.)
+// bf16 outputs: a lane holds 4 consecutive columns (8 bytes) of each 16-column MFMA tile.  For an adjacent tile pair
+// (j0, j1) v_permlane16_swap exchanges, per dword, tile j0's data in lanes with odd lane>>4 against tile j1's data in
+// lanes with even lane>>4 (l <-> l^16).  Afterwards lane g = lane>>4 owns 8 consecutive columns (16 bytes) of ONE tile:
+//   tile j0 + (g&1), columns 8 (g>>1) .. +7   ->   half as many, twice as wide stores (the store tail of a 256x256
+// bf16 tile is issue-bound: 32 dwordx2 per lane before, 16 dwordx4 now; cdna guide T21).
+__device__ __forceinline__ u32x4 pair_swap_bf16(const float (&va)[4], const float (&vb)[4]) {
+  const bf16x4 pa = {(bf16_t)va[0], (bf16_t)va[1], (bf16_t)va[2], (bf16_t)va[3]};
+  const bf16x4 pb = {(bf16_t)vb[0], (bf16_t)vb[1], (bf16_t)vb[2], (bf16_t)vb[3]};
+  typedef unsigned u32x2_t __attribute__((ext_vector_type(2)));
+  const u32x2_t a = __builtin_bit_cast(u32x2_t, pa), b = __builtin_bit_cast(u32x2_t, pb);
+  const u32x2_t r0 = __builtin_amdgcn_permlane16_swap(a[0], b[0], false, false);
+  const u32x2_t r1 = __builtin_amdgcn_permlane16_swap(a[1], b[1], false, false);
+  return (u32x4){r0[0], r1[0], r0[1], r1[1]};
+}
+
 template <int EPI, typename CT>
 __device__ __forceinline__ void nt_epilogue(f32x4 (&acc)[4][4], CT* __restrict__ C, int ldc, int M, int N, int m0, int n0,
                                             int wm, int wn, int lane, const EpiArgs& ep) {
@@ -169,21 +184,57 @@ __device__ __forceinline__ void nt_epilogue(f32x4 (&acc)[4][4], CT* __restrict__
           const long arow = (EPI == MV_EPI_EMBED) ? prow[i] : (mb + i * 16);
           ax[i][j] = *reinterpret_cast<const float4*>(reinterpret_cast<const float*>(ep.aux) + arow * ep.ld_aux + nb + j * 16);
         }
-    } else if constexpr (EPI == MV_EPI_DGELU) {
+    }
+    bf16x4 hx[4][4];                                   // DGELU: the saved pre-activation, kept packed (32 VGPRs, not 64)
+    if constexpr (EPI == MV_EPI_DGELU) {
 #pragma unroll
       for (int i = 0; i < 4; ++i)
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          const bf16x4 h = *reinterpret_cast<const bf16x4*>(reinterpret_cast<const bf16_t*>(ep.aux) +
-                                                             (long)(mb + i * 16) * ep.ld_aux + nb + j * 16);
-          ax[i][j] = make_float4((float)h[0], (float)h[1], (float)h[2], (float)h[3]);
-        }
+        for (int j = 0; j < 4; ++j)
+          hx[i][j] = *reinterpret_cast<const bf16x4*>(reinterpret_cast<const bf16_t*>(ep.aux) +
+                                                      (long)(mb + i * 16) * ep.ld_aux + nb + j * 16);
     }
     float cs[4][4];                                   // DGELU: column sums of this wave's 64x64 quadrant
 #pragma unroll
     for (int j = 0; j < 4; ++j)
 #pragma unroll
       for (int r = 0; r < 4; ++r) cs[j][r] = 0.f;
+    if constexpr (sizeof(CT) == 2 && (EPI == MV_EPI_NONE || EPI == MV_EPI_GELU || EPI == MV_EPI_DGELU)) {
+      if (((ldc & 7) == 0) && ((ep.ld_out2 & 7) == 0 || EPI != MV_EPI_GELU)) {
+        const int g = lane >> 4;
+        const int nw = n0 + wn * 64 + 16 * (g & 1) + 8 * (g >> 1);      // + 32 jp: first of this lane's 8 columns
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+          for (int jp = 0; jp < 2; ++jp) {
+            float v[2][4], hpre[2][4];
+#pragma unroll
+            for (int q = 0; q < 2; ++q) {
+              const int j = 2 * jp + q;
+              v[q][0] = acc[i][j][0] + bv[j].x; v[q][1] = acc[i][j][1] + bv[j].y;
+              v[q][2] = acc[i][j][2] + bv[j].z; v[q][3] = acc[i][j][3] + bv[j].w;
+              if constexpr (EPI == MV_EPI_GELU) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) { hpre[q][r] = v[q][r]; v[q][r] = gelu_fast(v[q][r]); }
+              } else if constexpr (EPI == MV_EPI_DGELU) {
+                v[q][0] *= dgelu_fast((float)hx[i][j][0]); v[q][1] *= dgelu_fast((float)hx[i][j][1]);
+                v[q][2] *= dgelu_fast((float)hx[i][j][2]); v[q][3] *= dgelu_fast((float)hx[i][j][3]);
+                cs[j][0] += v[q][0]; cs[j][1] += v[q][1]; cs[j][2] += v[q][2]; cs[j][3] += v[q][3];
+              }
+            }
+            if constexpr (EPI == MV_EPI_GELU) {
+              if (ep.out2)
+                *reinterpret_cast<u32x4*>(reinterpret_cast<bf16_t*>(ep.out2) + (long)(mb + i * 16) * ep.ld_out2 + nw + 32 * jp) =
+                    pair_swap_bf16(hpre[0], hpre[1]);
+            }
+            *reinterpret_cast<u32x4*>(C + crow[i] * ldc + nw + 32 * jp) = pair_swap_bf16(v[0], v[1]);
+          }
+        if constexpr (EPI == MV_EPI_DGELU) {
+          if (ep.out2) nt_colsum_flush(cs, reinterpret_cast<float*>(ep.out2), ep.ld_out2, (m0 + wm * 64) >> 6, nb, N, lane);
+        }
+        return;
+      }
+    }
 #pragma unroll
     for (int i = 0; i < 4; ++i)
 #pragma unroll
@@ -197,8 +248,8 @@ __device__ __forceinline__ void nt_epilogue(f32x4 (&acc)[4][4], CT* __restrict__
         } else if constexpr (EPI == MV_EPI_RESIDUAL || EPI == MV_EPI_EMBED) {
           v[0] += ax[i][j].x; v[1] += ax[i][j].y; v[2] += ax[i][j].z; v[3] += ax[i][j].w;
         } else if constexpr (EPI == MV_EPI_DGELU) {
-          v[0] *= dgelu_fast(ax[i][j].x); v[1] *= dgelu_fast(ax[i][j].y);
-          v[2] *= dgelu_fast(ax[i][j].z); v[3] *= dgelu_fast(ax[i][j].w);
+          v[0] *= dgelu_fast((float)hx[i][j][0]); v[1] *= dgelu_fast((float)hx[i][j][1]);
+          v[2] *= dgelu_fast((float)hx[i][j][2]); v[3] *= dgelu_fast((float)hx[i][j][3]);
           cs[j][0] += v[0]; cs[j][1] += v[1]; cs[j][2] += v[2]; cs[j][3] += v[3];
         }
         store4(C + crow[i] * ldc + n, v, true, 4);
@@ -718,12 +769,27 @@ constexpr int P8_BQ0 = 0, P8_AQ0 = 1, P8_BQ1 = 2, P8_AQ1 = 3;   // slot order in
 template <int EPI, typename CT>
 __global__ __launch_bounds__(512, 2) void gemm_nt_8phase_kernel(const bf16_t* __restrict__ A, int lda,
                                                                 const bf16_t* __restrict__ B, int ldb, CT* __restrict__ C,
-                                                                int ldc, int M, int N, int K, int tiles_n, EpiArgs ep) {
+                                                                int ldc, int M, int N, int K, int tiles_n, EpiArgs ep,
+                                                                int full_tiles) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave >> 2, wn = wave & 3;
-  const int t = xcd_remap(blockIdx.x, gridDim.x);
-  const int m0 = (t / tiles_n) * BM2, n0 = (t % tiles_n) * BN2;
+  // Work items [0, full_tiles) are whole 256x256 output tiles (full_tiles = a multiple of the CU count, or all tiles).
+  // The remaining "tail" tiles would occupy only part of the chip for one more full round; each is split into two
+  // 128x256 HALF items (rows [0,128) and [128,256) of the tile) that run the same pipeline with quadrant-row 0 only:
+  // wave (wm, wn) owns 64x64 outputs, slot A_q0 holds the item's 128 rows, slot A_q1 / phases 3-4 are idle.
+  // 591 tiles on 256 CUs: 3 rounds -> 2 + ~0.6, with no extra memory traffic.
+  const int nk = K >> 6;                         // even, >= 2 (dispatch)
+  int t, half = -1;
+  if ((int)blockIdx.x < full_tiles) {
+    t = xcd_remap(blockIdx.x, full_tiles);
+  } else {
+    const int idx = blockIdx.x - full_tiles;
+    t = full_tiles + (idx >> 1);
+    half = idx & 1;
+  }
+  const bool is_half = half >= 0;                // wave-uniform
+  const int m0 = (t / tiles_n) * BM2 + (is_half ? 128 * half : 0), n0 = (t % tiles_n) * BN2;
 
   // staging: wave w moves pieces 2w and 2w+1 of a slot (1 KiB = 8 slot rows of 128 B each); lane l -> row l>>3, 16-byte
   // chunk l&7 of the LDS image, i.e. logical chunk (l&7) ^ swz(row) of the source row (swizzle on the SOURCE side)
@@ -732,7 +798,8 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_8phase_kernel(const bf16_t* __
   for (int i = 0; i < 2; ++i) {
     const int rloc = 16 * wave + 8 * i + (lane >> 3);
     const int ch = (lane & 7) ^ (((rloc >> 1) & 3) << 1);
-    const int ra = m0 + 128 * (wave >> 2) + 16 * (wave & 3) + 8 * i + (lane >> 3);     // + 64 qm
+    // full tile: slot row 64 wm' + rr <-> tile row 128 wm' + 64 qm + rr; half item: <-> item row 64 wm' + rr
+    const int ra = m0 + (is_half ? 64 : 128) * (wave >> 2) + 16 * (wave & 3) + 8 * i + (lane >> 3);     // + 64 qm
     const int rb = n0 + 64 * (wave >> 1) + 16 * (wave & 1) + 8 * i + (lane >> 3);      // + 32 qn
     const int ra0 = ra < M ? ra : M - 1, ra1 = ra + 64 < M ? ra + 64 : M - 1;
     const int rb0 = rb < N ? rb : N - 1, rb1 = rb + 32 < N ? rb + 32 : N - 1;
@@ -811,7 +878,7 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_8phase_kernel(const bf16_t* __
     __builtin_amdgcn_sched_barrier(0);                                                                       \
     P8_READ_A(d_, P8_AQ0)                                                                                    \
     __builtin_amdgcn_sched_barrier(0);                                                                       \
-    if (STAGE_FIRST_) P8_STAGE(first_slot_buf_, P8_AQ1, first_slot_kt_)                                      \
+    if (STAGE_FIRST_ && !is_half) P8_STAGE(first_slot_buf_, P8_AQ1, first_slot_kt_)                          \
     asm volatile("s_waitcnt lgkmcnt(8)" ::: "memory"); /* the 4 B_q0 reads (issued first) have returned */   \
     P8_BAR()                                                                                                 \
     P8_LGKM0()                                                                                               \
@@ -826,25 +893,24 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_8phase_kernel(const bf16_t* __
     P8_MFMA(0, 2, bf1)                                                                                       \
     P8_BAR()                                                                                                 \
     /* phase 3/7 */                                                                                          \
-    P8_READ_A(d_, P8_AQ1)                                                                                    \
+    if (!is_half) P8_READ_A(d_, P8_AQ1)                                                                      \
     __builtin_amdgcn_sched_barrier(0);                                                                       \
     if (ST_) P8_STAGE(next_buf_, P8_AQ0, next_kt_)                                                           \
     P8_BAR()                                                                                                 \
     P8_LGKM0()                                                                                               \
-    P8_MFMA(4, 2, bf1)                                                                                       \
+    if (!is_half) P8_MFMA(4, 2, bf1)                                                                         \
     P8_BAR()                                                                                                 \
     /* phase 4/8 */                                                                                          \
     if (ST_) P8_STAGE(next_buf_, P8_BQ1, next_kt_)                                                           \
     asm volatile(WAIT_ ::: "memory");                                                                        \
     P8_BAR()                                                                                                 \
-    P8_MFMA(4, 0, bf0)                                                                                       \
+    if (!is_half) P8_MFMA(4, 0, bf0)                                                                         \
     P8_BAR()                                                                                                 \
   }
 
-  const int nk = K >> 6;                        // even, >= 2 (dispatch)
-  P8_STAGE(0, P8_BQ0, 0) P8_STAGE(0, P8_AQ0, 0) P8_STAGE(0, P8_BQ1, 0) P8_STAGE(0, P8_AQ1, 0)
+  P8_STAGE(0, P8_BQ0, 0) P8_STAGE(0, P8_AQ0, 0) P8_STAGE(0, P8_BQ1, 0) if (!is_half) P8_STAGE(0, P8_AQ1, 0)
   P8_STAGE(1, P8_BQ0, 1) P8_STAGE(1, P8_AQ0, 1) P8_STAGE(1, P8_BQ1, 1)
-  asm volatile("s_waitcnt vmcnt(6)" ::: "memory");     // K-tile 0 landed
+  asm volatile("s_waitcnt vmcnt(6)" ::: "memory");     // K-tile 0 landed (the 3 youngest slots may be in flight)
   P8_BAR()
   if (__builtin_amdgcn_readfirstlane(wave) >= 4) P8_BAR()      // waves 4-7 run one barrier behind
   int kt = 0;
@@ -865,10 +931,13 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_8phase_kernel(const bf16_t* __
 #undef P8_READ_A
 #undef P8_READ_B
 #undef P8_STAGE
+  // full tile: wave (wm, wn) finishes rows 128 wm + 64 h (h = 0, 1); half item: its only quadrant-row, rows 64 wm
 #pragma unroll
-  for (int h = 0; h < 2; ++h)
-    nt_epilogue<EPI, CT>(*reinterpret_cast<f32x4(*)[4][4]>(&acc[4 * h]), C, ldc, M, N, m0 + 128 * wm, n0 + 128 * (wn >> 1), h,
-                         wn & 1, lane, ep);
+  for (int h = 0; h < 2; ++h) {
+    if (h == 1 && is_half) break;
+    nt_epilogue<EPI, CT>(*reinterpret_cast<f32x4(*)[4][4]>(&acc[4 * h]), C, ldc, M, N, is_half ? m0 : m0 + 128 * wm,
+                         n0 + 128 * (wn >> 1), is_half ? wm : h, wn & 1, lane, ep);
+  }
 }
 
 __device__ __forceinline__ void tn_store(f32x4 (&acc)[4][4], float* __restrict__ Cs, long ldc, int M, int N, int m0, int n0,
@@ -1331,6 +1400,14 @@ int set_smem(K kernel) {
              : -1;
 }
 
+// Tail split of the 8-phase kernel: tiles beyond the last full round of the 256 CUs become two HALF items each when
+// that round would be less than half full (otherwise a whole-tile round is already the better use of the chip).
+constexpr int NT_CUS = 256;
+inline int nt_full_tiles(int tiles) {
+  const int tail = tiles % NT_CUS;
+  return (tiles >= NT_CUS && tail > 0 && 2 * tail <= NT_CUS) ? tiles - tail : tiles;
+}
+
 template <int EPI, typename CT>
 int launch_nt(const void* A, int lda, const void* B, int ldb, void* C, int ldc, int M, int N, int K, EpiArgs ep,
               hipStream_t s) {
@@ -1349,12 +1426,15 @@ int launch_nt(const void* A, int lda, const void* B, int ldb, void* C, int ldc, 
   const bool ring_ok = K > 0 && K % BKR == 0;
   const bool ring_pick = ring_ok && ((long)t2m * t2n >= 1024 || (K >= 2048 && (long)t2m * t2n >= 256));
   const bool p8_ok = K >= 128 && K % 128 == 0 && (long)M * lda < (1L << 31) && (long)N * ldb < (1L << 31);
-  if ((force == 2568 && p8_ok) || (force == 0 && ring_pick && p8_ok)) {
+  // 8-phase kernel: wherever the ring would be picked, and from one full round of the chip on (half-item tail)
+  const bool p8_pick = p8_ok && (ring_pick || (long)t2m * t2n >= NT_CUS);
+  if (((force == 2568 || force == 25680) && p8_ok) || (force == 0 && p8_pick)) {
     static const int a8 = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_nt_8phase_kernel<EPI, CT>),
                                               hipFuncAttributeMaxDynamicSharedMemorySize, P8_SMEM) == hipSuccess ? 0 : -1;
     if (a8) return MV_ERR_LAUNCH;
-    gemm_nt_8phase_kernel<EPI, CT><<<t2m * t2n, 512, P8_SMEM, s>>>((const bf16_t*)A, lda, (const bf16_t*)B, ldb, (CT*)C, ldc,
-                                                                   M, N, K, t2n, ep);
+    const int tiles = t2m * t2n, full = force == 25680 ? tiles : nt_full_tiles(tiles);     // 25680: whole tiles only (A/B)
+    gemm_nt_8phase_kernel<EPI, CT><<<full + 2 * (tiles - full), 512, P8_SMEM, s>>>(
+        (const bf16_t*)A, lda, (const bf16_t*)B, ldb, (CT*)C, ldc, M, N, K, t2n, ep, full);
     MV_CHECK_LAUNCH();
     return MV_OK;
   }
@@ -1410,7 +1490,8 @@ extern "C" int mv_gemm_nt_bf16(const void* A, int lda, const void* B, int ldb, v
 }
 
 extern "C" int mv_gemm_force_variant(int nt_variant, int tn_variant) {
-  const bool nt_ok = nt_variant == 0 || nt_variant == 128 || nt_variant == 256 || nt_variant == 2564 || nt_variant == 2568;
+  const bool nt_ok = nt_variant == 0 || nt_variant == 128 || nt_variant == 256 || nt_variant == 2564 || nt_variant == 2568 ||
+                     nt_variant == 25680;
   const bool tn_ok = tn_variant == 0 || tn_variant == 128 || tn_variant == 256;
   MV_REQUIRE(nt_ok && tn_ok, MV_ERR_UNSUPPORTED);
   g_force_nt.store(nt_variant, std::memory_order_relaxed);

@@ -132,6 +132,44 @@ def test_gemm_nt_every_variant(ops, variant, M, N, K):
         check(lib().mv_gemm_force_variant(0, 0), "force_variant")
 
 
+@pytest.mark.parametrize("M,N,K", [(4859, 3584, 512), (4864, 3584, 768)])
+def test_gemm_nt_tail_split(ops, M, N, K):
+    """266 tiles of 256x256 on 256 CUs: the 10 tail tiles run as 20 half items (128x256, quadrant-row 0 of the pipeline
+    only) -- every epilogue must give the same result as whole tiles, including the ragged last row block."""
+    from myrtle_vision.hip.lib import lib
+    a, w, b = bf(torch.randn(M, K, generator=g(1))), bf(torch.randn(N, K, generator=g(2)) * K ** -0.5), torch.randn(N, generator=g(3)) * 0.1
+    ad, wd = a.cuda(), w.float().cuda()
+    pre = (ad.float() @ wd.t()).double().cpu() + b.double()        # fp32 reference of exact bf16 products (GPU matmul)
+    out = torch.empty(M, N, device="cuda")
+    ops.linear_fwd(ad, M, K, wd, b.cuda(), out, N)
+    assert relerr(out, pre) < 1e-5
+    res = torch.randn(M, N, generator=g(4))
+    ops.linear_fwd(ad, M, K, wd, b.cuda(), out, N, epi=ops.EPI_RESIDUAL, aux=res.cuda(), ld_aux=N)
+    assert relerr(out, pre + res.double()) < 1e-5
+    act = torch.empty(M, N, device="cuda", dtype=torch.bfloat16)
+    h = torch.empty(M, N, device="cuda", dtype=torch.bfloat16)
+    ops.linear_fwd(ad, M, K, wd, b.cuda(), act, N, epi=ops.EPI_GELU, out2=h, ld_out2=N)
+    assert relerr(h.float(), pre) < 2.0 ** -8 and relerr(act.float(), gelu_erf(pre)) < 2.0 ** -8
+    # the same product from the ring kernel (whole tiles only): identical up to fp32 summation order
+    lib().mv_gemm_force_variant(2564, 0)
+    try:
+        out_ring = torch.empty(M, N, device="cuda")
+        ops.linear_fwd(ad, M, K, wd, b.cuda(), out_ring, N, epi=ops.EPI_RESIDUAL, aux=res.cuda(), ld_aux=N)
+    finally:
+        lib().mv_gemm_force_variant(0, 0)
+    assert relerr(out, out_ring.double().cpu()) < 2e-6
+    # DGELU through the dX entry point: C[M, K2] with K2 = 3584 columns, contraction over 512/768
+    dy = bf(torch.randn(M, K, generator=g(5)))
+    hh = bf(torch.randn(M, N, generator=g(6)))
+    w2 = bf(torch.randn(K, N, generator=g(7)) * K ** -0.5)         # nn.Linear weight [out=K, in=N]: dX = dy @ w2
+    want = (dy.cuda().float() @ w2.cuda().float()).double().cpu() * dgelu64(hh)
+    dx = torch.empty(M, N, device="cuda", dtype=torch.bfloat16)
+    part = torch.zeros((M + 63) // 64, N, device="cuda")
+    ops.linear_dx(dy.cuda(), M, K, w2.float().cuda(), dx, N, epi=ops.EPI_DGELU, aux=hh.cuda(), ld_aux=N, colsum_partial=part)
+    assert relerr(dx.float(), want) < 2.0 ** -8
+    assert relerr(part.sum(0), want.sum(0)) < 2e-3
+
+
 def test_gemm_nt_epilogues(ops):
     M, N, K = 1576, 768, 192
     a, w, b = bf(torch.randn(M, K, generator=g(1))), bf(torch.randn(N, K, generator=g(2)) * K ** -0.5), torch.randn(N, generator=g(3)) * 0.1

@@ -19,6 +19,19 @@ def timeit(fn, iters=10):
     e.record(); torch.cuda.synchronize()
     return s.elapsed_time(e) / iters * 1e-3
 
+# NT variants A/B-ed in ONE process on one device, rounds interleaved (timings from different boxes differ by up to 10 %)
+VARIANTS = [int(v) for v in os.environ.get("NT_VARIANTS", "0").split(",")]
+from myrtle_vision.hip.lib import lib as _lib
+
+def timeit_variants(fn, rounds=3, iters=8):
+    best = {v: 1e9 for v in VARIANTS}
+    for _ in range(rounds):
+        for v in VARIANTS:
+            _lib().mv_gemm_force_variant(v, 0)
+            best[v] = min(best[v], timeit(fn, iters))
+    _lib().mv_gemm_force_variant(0, 0)
+    return best
+
 rows = []
 for name, N, K, epi in [("qkv fwd", 2304, 768, "none"), ("proj fwd +res", 768, 768, "res"), ("fc1 fwd +gelu", 3072, 768, "gelu"),
                         ("fc2 fwd +res", 768, 3072, "res"), ("plain bf16 out N=3072", 3072, 768, "none"), ("plain K=3072", 768, 3072, "none")]:
@@ -32,7 +45,7 @@ for name, N, K, epi in [("qkv fwd", 2304, 768, "none"), ("proj fwd +res", 768, 7
     else:
         out, h = torch.empty(M, N, device=dev, dtype=torch.bfloat16), torch.empty(M, N, device=dev, dtype=torch.bfloat16)
         f = lambda: ops.linear_fwd(x, M, K, w, b, out, N, epi=ops.EPI_GELU, out2=h, ld_out2=N)
-    t = timeit(f); rows.append((f"NT {name}", 2.0 * M * N * K / t / 1e12, t * 1e6))
+    tv = timeit_variants(f); rows.append((f"NT {name}", [2.0 * M * N * K / tv[v] / 1e12 for v in VARIANTS], tv[VARIANTS[-1]] * 1e6))
 for name, N, K, epi in [("dX qkv (N=768,K=2304)", 2304, 768, "none"), ("dX fc2 +dgelu (->3072)", 768, 3072, "dgelu"), ("dX fc1 (K=3072)", 3072, 768, "none")]:
     # linear_dx(dy[M,N], W[N,K]) -> [M,K]
     dy, w = rnd(M, N), torch.randn(N, K, device=dev) * K ** -0.5
@@ -42,7 +55,13 @@ for name, N, K, epi in [("dX qkv (N=768,K=2304)", 2304, 768, "none"), ("dX fc2 +
         f = lambda: ops.linear_dx(dy, M, N, w, out, K, epi=ops.EPI_DGELU, aux=h, ld_aux=K)
     else:
         f = lambda: ops.linear_dx(dy, M, N, w, out, K)
-    t = timeit(f); rows.append((f"NT {name}", 2.0 * M * N * K / t / 1e12, t * 1e6))
+    tv = timeit_variants(f); rows.append((f"NT {name}", [2.0 * M * N * K / tv[v] / 1e12 for v in VARIANTS], tv[VARIANTS[-1]] * 1e6))
+if os.environ.get("NT_ONLY"):
+    print(f"{'shape':38s} " + " ".join(f"{v:>8d}" for v in VARIANTS) + "   (TFLOP/s per forced NT variant; 0 = automatic)")
+    for r in rows:
+        print(f"{r[0]:38s} " + " ".join(f"{x:8.1f}" for x in r[1]) + f"   {r[2]:8.1f} us")
+    sys.exit(0)
+rows = [(r[0], r[1][-1], r[2]) for r in rows]
 for name, N, K in [("dW qkv", 2304, 768), ("dW proj", 768, 768), ("dW fc1", 3072, 768), ("dW fc2", 768, 3072)]:
     dy, x = rnd(M, N), rnd(M, K)
     f = lambda: ops.linear_dw(dy, x, M, N, K)
