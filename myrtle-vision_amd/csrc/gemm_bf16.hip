@@ -1500,8 +1500,10 @@ extern "C" int mv_gemm_force_variant(int nt_variant, int tn_variant) {
 }
 
 extern "C" size_t mv_gemm_tn_workspace_bytes(int M, int N, int Kc) {
-  const TnPlan pl = tn_use_ring(M, N, Kc) ? tn_plan256(M, N, Kc) : tn_plan(M, N, Kc);
-  const size_t slabs = (size_t)pl.splits * (size_t)M * (size_t)N * sizeof(float);
+  // the larger of the two plans: independent of which variant is (or is forced to be) launched later
+  int splits = tn_plan(M, N, Kc).splits;
+  if (Kc > 0 && Kc % BKR == 0 && tn_plan256(M, N, Kc).splits > splits) splits = tn_plan256(M, N, Kc).splits;
+  const size_t slabs = (size_t)splits * (size_t)M * (size_t)N * sizeof(float);
   const size_t cs = (size_t)colsum_parts(Kc) * (size_t)M * sizeof(float);
   return slabs + cs + 256;
 }
@@ -1536,6 +1538,9 @@ extern "C" int mv_gemm_tn_bf16(const void* A, int lda, const void* B, int ldb, f
   if (attr != 0) return MV_ERR_LAUNCH;
   hipStream_t s = (hipStream_t)stream;
   const bool ring = tn_use_ring(M, N, Kc);
+  // (An 8-phase port of this kernel -- the gemm_nt_8phase_kernel schedule with [64 kc][128 col] slots -- measured 10-15 %
+  // SLOWER than the ring in the same process, 851 vs 968 and 909 vs 1031 TFLOP/s: the ring's DMA rows are whole
+  // 256-byte lines already, so the port only added barriers and halved the bytes in flight.  Not kept.)
   const TnPlan pl = ring ? tn_plan256(M, N, Kc) : tn_plan(M, N, Kc);
   const int tiles_mn = pl.tiles_m * pl.tiles_n;
   const bool direct = pl.splits == 1 && !accumulate;

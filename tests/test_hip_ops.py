@@ -220,7 +220,7 @@ def test_gemm_tn_dw_and_colsum(ops, Kc, M, N):
 
 
 @pytest.mark.parametrize("variant", [128, 256])
-@pytest.mark.parametrize("Kc,M,N", [(4096, 520, 300 // 4 * 4 + 4), (6400, 768, 768), (2080, 264, 1000)])
+@pytest.mark.parametrize("Kc,M,N", [(4096, 520, 300 // 4 * 4 + 4), (6400, 768, 768), (2080, 264, 1000), (9984, 776, 520)])
 def test_gemm_tn_every_variant(ops, variant, Kc, M, N):
     from myrtle_vision.hip.lib import lib, check
     dy, x = bf(torch.randn(Kc, M, generator=g(1))), bf(torch.randn(Kc, N, generator=g(2)))

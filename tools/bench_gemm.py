@@ -62,11 +62,21 @@ if os.environ.get("NT_ONLY"):
         print(f"{r[0]:38s} " + " ".join(f"{x:8.1f}" for x in r[1]) + f"   {r[2]:8.1f} us")
     sys.exit(0)
 rows = [(r[0], r[1][-1], r[2]) for r in rows]
+TN_VARIANTS = [int(v) for v in os.environ.get("TN_VARIANTS", "0").split(",")]
+trows = []
 for name, N, K in [("dW qkv", 2304, 768), ("dW proj", 768, 768), ("dW fc1", 3072, 768), ("dW fc2", 768, 3072)]:
     dy, x = rnd(M, N), rnd(M, K)
-    f = lambda: ops.linear_dw(dy, x, M, N, K)
-    t = timeit(f); rows.append((f"TN {name} (+reduce+colsum)", 2.0 * M * N * K / t / 1e12, t * 1e6))
-    f = lambda: ops.linear_dw(dy, x, M, N, K, want_bias=False)
-    t = timeit(f); rows.append((f"TN {name} (+reduce)", 2.0 * M * N * K / t / 1e12, t * 1e6))
+    for label, f in [("(+reduce+colsum)", lambda: ops.linear_dw(dy, x, M, N, K)),
+                     ("(+reduce)", lambda: ops.linear_dw(dy, x, M, N, K, want_bias=False))]:
+        best = {v: 1e9 for v in TN_VARIANTS}
+        for _ in range(3):
+            for v in TN_VARIANTS:
+                _lib().mv_gemm_force_variant(0, v)
+                best[v] = min(best[v], timeit(f, 8))
+        _lib().mv_gemm_force_variant(0, 0)
+        trows.append((f"TN {name} {label}", [2.0 * M * N * K / best[v] / 1e12 for v in TN_VARIANTS], best[TN_VARIANTS[-1]] * 1e6))
 for r in rows:
     print(f"{r[0]:38s} {r[1]:8.1f} TFLOP/s  {r[2]:9.1f} us")
+print(f"{'shape':38s} " + " ".join(f"{v:>8d}" for v in TN_VARIANTS) + "   (TFLOP/s per forced TN variant; 0 = automatic)")
+for r in trows:
+    print(f"{r[0]:38s} " + " ".join(f"{x:8.1f}" for x in r[1]) + f"   {r[2]:8.1f} us")
