@@ -39,6 +39,7 @@ class _LayerNorm(Function):
         rows = x.numel() // dim
         y, mean, rstd = ops.layernorm_fwd(x, dim, rows, dim, gamma, beta, out_dtype, eps)
         ctx.save_for_backward(x, gamma, mean, rstd)
+        ctx.beta = beta
         return y.view(x.shape)
 
     @staticmethod
@@ -48,7 +49,7 @@ class _LayerNorm(Function):
         rows = x.numel() // dim
         dy = _c(dy)
         dx = torch.empty_like(x)
-        dg, db = ops.layernorm_bwd(dy, x, dim, gamma, mean, rstd, None, dx, dim, rows, dim)
+        dg, db = ops.layernorm_bwd(dy, x, dim, gamma, mean, rstd, None, dx, dim, rows, dim, beta=ctx.beta)
         return dx, dg, db, None, None
 
 
@@ -72,6 +73,7 @@ class _Linear(Function):
         ops.linear_fwd(x2, M, K, weight, bias, out, N)
         ctx.save_for_backward(x2, weight)
         ctx.has_bias = bias is not None
+        ctx.bias = bias
         ctx.in_shape = x.shape
         return out.view(*x.shape[:-1], N)
 
@@ -94,7 +96,7 @@ class _Linear(Function):
             dx = torch.empty(M, K, dtype=x2.dtype, device=x2.device)
             ops.linear_dx(dy2, M, N, weight, dx, K, ld_dy=ld_dy)
             dx = dx.view(ctx.in_shape)
-        dw, db = ops.linear_dw(dy2, x2, M, N, K, ld_dy=ld_dy, want_bias=ctx.has_bias)
+        dw, db = ops.linear_dw(dy2, x2, M, N, K, ld_dy=ld_dy, want_bias=ctx.has_bias, weight=weight, bias=ctx.bias)
         return dx, dw, db, None
 
 
@@ -280,6 +282,8 @@ class _PatchEmbed(Function):
         ctx.save_for_backward(patches)
         ctx.dims = (B, T, D, pd, npatch)
         ctx.pos_shape, ctx.cls_shape = pos.shape, cls_token.shape
+        ctx.params = (weight, bias, cls_token, pos if pos.shape[-2:] == (T, D) and pos.is_leaf else None)
+        _chain_set(x, None)
         return x
 
     @staticmethod
@@ -287,9 +291,10 @@ class _PatchEmbed(Function):
         (patches,) = ctx.saved_tensors
         B, T, D, pd, npatch = ctx.dims
         dx = _c(dx.float())
-        dpos, dcls = ops.embed_bwd(dx, B, T, D)
+        weight, bias, cls_token, pos = ctx.params
+        dpos, dcls = ops.embed_bwd(dx, B, T, D, pos=pos, cls_token=cls_token)
         dy = ops.gather_patch_rows(dx, B, T, D, patches.dtype)
-        dw, db = ops.linear_dw(dy, patches, B * npatch, D, pd)
+        dw, db = ops.linear_dw(dy, patches, B * npatch, D, pd, weight=weight, bias=bias)
         return None, dw, db, dcls.view(ctx.cls_shape), dpos.view(ctx.pos_shape), None, None
 
 
@@ -322,17 +327,36 @@ def _take_side(dout, rows, dim):
     return ent[1], ent[2]
 
 
-def _ln_bwd_with_side(dy, x, D, g, mean, rstd, dout, M, adt):
-    """LayerNorm backward + residual gradient; in bf16 mode also publishes the bf16 copy and column sums of dx."""
+def _ln_bwd_with_side(dy, x, D, g, b, mean, rstd, dout, M, adt, up_bias=None):
+    """LayerNorm backward + residual gradient; in bf16 mode also publishes the bf16 copy and column sums of dx.
+    ``up_bias``: the bias of the Linear that produced x (recorded in forward, ``_chain``): the column sums ARE its
+    gradient, so they are written straight to its destination."""
     dx = torch.empty_like(x)
     if adt == torch.bfloat16:
         dx16 = torch.empty(M, D, dtype=torch.bfloat16, device=x.device)
-        cs = torch.empty(D, dtype=torch.float32, device=x.device)
-        dg, db = ops.layernorm_bwd(dy, x, D, g, mean, rstd, dout, dx, D, M, D, dx16=dx16, dx_colsum=cs)
+        cs = ops.grad_out(up_bias, (D,), x.device)
+        dg, db = ops.layernorm_bwd(dy, x, D, g, mean, rstd, dout, dx, D, M, D, dx16=dx16, dx_colsum=cs, beta=b)
         _publish_side(dx, dx16, cs)
     else:
-        dg, db = ops.layernorm_bwd(dy, x, D, g, mean, rstd, dout, dx, D, M, D)
+        dg, db = ops.layernorm_bwd(dy, x, D, g, mean, rstd, dout, dx, D, M, D, beta=b)
     return dx, dg, db
+
+
+# Forward-order link between consecutive block functions: (address of the tensor a block returned, the bias of the
+# Linear that produced it).  The next block reads it to learn whose bias gradient the column sums of its dx are.
+_chain = [None]
+
+
+def _chain_set(out, bias):
+    _chain[0] = (out.data_ptr(), bias)
+
+
+def _chain_take(x):
+    c = _chain[0]
+    return c[1] if c is not None and c[0] == x.data_ptr() else None
+
+
+
 class _AttnBlock(Function):
     """x + to_out(attention(to_qkv(LN(x))))  ==  Residual(PreNorm(dim, Attention)) (vit.py:131-141, 84-99)."""
 
@@ -342,6 +366,7 @@ class _AttnBlock(Function):
         B, T, D = x.shape
         M = B * T
         x = _c(x)
+        ctx.up_bias = _chain_take(x)
         y, mean, rstd = ops.layernorm_fwd(x, D, M, D, g, b, adt)
         inner3 = wqkv.shape[0]
         inner = inner3 // 3
@@ -360,6 +385,8 @@ class _AttnBlock(Function):
         ops.linear_fwd(o.view(M, inner), M, inner, wo, bo, out, D, epi=EPI_RESIDUAL, aux=x, ld_aux=D)
         ctx.save_for_backward(x, g, mean, rstd, y, qkv, o, lse if lse is not None else probs, wqkv, wo)
         ctx.cfg = (heads, scale, lse is not None)
+        ctx.small = (b, bqkv, bo)
+        _chain_set(out, bo)
         return out
 
     @staticmethod
@@ -375,7 +402,8 @@ class _AttnBlock(Function):
         d_act, dbo = _take_side(dout, M, D) if adt == torch.bfloat16 else (None, None)
         if d_act is None:
             d_act = ops.cast(dout, adt).view(M, D)                # dY of the projection, activation dtype
-        dwo, dbo2 = ops.linear_dw(d_act, o.view(M, inner), M, D, inner, want_bias=dbo is None)
+        b, bqkv, bo = ctx.small
+        dwo, dbo2 = ops.linear_dw(d_act, o.view(M, inner), M, D, inner, want_bias=dbo is None, weight=wo, bias=bo)
         dbo = dbo if dbo is not None else dbo2
         do = torch.empty(B, T, inner, dtype=adt, device=x.device)
         ops.linear_dx(d_act, M, D, wo, do, inner)
@@ -384,10 +412,10 @@ class _AttnBlock(Function):
         else:
             dqkv = ops.cast(ops.attention_bwd_fp32(lse_or_probs, ops.cast(qkv, torch.float32), ops.cast(do, torch.float32),
                                                    B, T, heads, inner // heads, scale), adt)
-        dwqkv, dbqkv = ops.linear_dw(dqkv.view(M, inner3), y, M, inner3, D)
+        dwqkv, dbqkv = ops.linear_dw(dqkv.view(M, inner3), y, M, inner3, D, weight=wqkv, bias=bqkv)
         dy = torch.empty(M, D, dtype=adt, device=x.device)
         ops.linear_dx(dqkv.view(M, inner3), M, inner3, wqkv, dy, D)
-        dx, dg, db = _ln_bwd_with_side(dy, x, D, g, mean, rstd, dout, M, adt)   # + residual gradient
+        dx, dg, db = _ln_bwd_with_side(dy, x, D, g, b, mean, rstd, dout, M, adt, ctx.up_bias)   # + residual gradient
         return dx, dg, db, dwqkv, dbqkv, dwo, dbo, None, None, None
 
 
@@ -405,6 +433,7 @@ class _MlpBlock(Function):
         M = B * T
         Hd = w1.shape[0]
         x = _c(x)
+        ctx.up_bias = _chain_take(x)
         y, mean, rstd = ops.layernorm_fwd(x, D, M, D, g, b, adt)
         h = torch.empty(M, Hd, dtype=adt, device=x.device)     # pre-activation (kept for GELU')
         a = torch.empty(M, Hd, dtype=adt, device=x.device)
@@ -412,6 +441,8 @@ class _MlpBlock(Function):
         out = torch.empty_like(x)
         ops.linear_fwd(a, M, Hd, w2, b2, out, D, epi=EPI_RESIDUAL, aux=x, ld_aux=D)
         ctx.save_for_backward(x, g, mean, rstd, y, h, a, w1, w2)
+        ctx.small = (b, b1, b2)
+        _chain_set(out, b2)
         return out
 
     @staticmethod
@@ -425,21 +456,22 @@ class _MlpBlock(Function):
         d_act, db2 = _take_side(dout, M, D) if adt == torch.bfloat16 else (None, None)
         if d_act is None:
             d_act = ops.cast(dout, adt).view(M, D)
-        dw2, db2b = ops.linear_dw(d_act, a, M, D, Hd, want_bias=db2 is None)
+        b, b1, b2 = ctx.small
+        dw2, db2b = ops.linear_dw(d_act, a, M, D, Hd, want_bias=db2 is None, weight=w2, bias=b2)
         db2 = db2 if db2 is not None else db2b
         dh = torch.empty(M, Hd, dtype=adt, device=x.device)
         if adt == torch.bfloat16:
             # (dY W2) * gelu'(h); the epilogue also leaves per-64-row column sums of dh = fc1's bias-gradient partials
             part = torch.empty((M + 63) // 64, Hd, dtype=torch.float32, device=x.device)
             ops.linear_dx(d_act, M, D, w2, dh, Hd, epi=EPI_DGELU, aux=h, ld_aux=Hd, colsum_partial=part)
-            db1 = ops.colsum(part, part.shape[0], Hd, Hd, torch.empty(Hd, dtype=torch.float32, device=x.device))
-            dw1, _ = ops.linear_dw(dh, y, M, Hd, D, want_bias=False)
+            db1 = ops.colsum(part, part.shape[0], Hd, Hd, ops.grad_out(b1, (Hd,), x.device))
+            dw1, _ = ops.linear_dw(dh, y, M, Hd, D, want_bias=False, weight=w1)
         else:
             ops.linear_dx(d_act, M, D, w2, dh, Hd, epi=EPI_DGELU, aux=h, ld_aux=Hd)
-            dw1, db1 = ops.linear_dw(dh, y, M, Hd, D)
+            dw1, db1 = ops.linear_dw(dh, y, M, Hd, D, weight=w1, bias=b1)
         dy = torch.empty(M, D, dtype=adt, device=x.device)
         ops.linear_dx(dh, M, Hd, w1, dy, D)
-        dx, dg, db = _ln_bwd_with_side(dy, x, D, g, mean, rstd, dout, M, adt)
+        dx, dg, db = _ln_bwd_with_side(dy, x, D, g, b, mean, rstd, dout, M, adt, ctx.up_bias)
         return dx, dg, db, dw1, db1, dw2, db2, None
 
 
@@ -463,6 +495,7 @@ class _ClsHead(Function):
         logits = torch.empty(B, C, dtype=torch.float32, device=x.device)
         ops.linear_fwd(y, B, D, w, bias, logits, C)
         ctx.save_for_backward(x, g, mean, rstd, y, w)
+        ctx.small = (b, bias)
         return logits
 
     @staticmethod
@@ -474,11 +507,12 @@ class _ClsHead(Function):
         ld = ops.pad8(C) if adt == torch.bfloat16 else C
         dl = torch.zeros(B, ld, dtype=adt, device=x.device)
         dl[:, :C] = dlogits                                                # tiny (B x C) pad+cast: cold glue
-        dw, dbias = ops.linear_dw(dl, y, B, C, D, ld_dy=ld)
+        b, bias = ctx.small
+        dw, dbias = ops.linear_dw(dl, y, B, C, D, ld_dy=ld, weight=w, bias=bias)
         dy = torch.empty(B, D, dtype=adt, device=x.device)
         ops.linear_dx(dl, B, C, w, dy, D, ld_dy=ld)
         dx = torch.zeros_like(x)
-        dg, db = ops.layernorm_bwd(dy, x, T * D, g, mean, rstd, None, dx, T * D, B, D)
+        dg, db = ops.layernorm_bwd(dy, x, T * D, g, mean, rstd, None, dx, T * D, B, D, beta=b)
         return dx, dg, db, dw, dbias, None
 
 
@@ -498,23 +532,24 @@ def _seg_small_fwd(x, g, b, w, bias, prec):
     y, mean, rstd = ops.layernorm_fwd(xp, D, M, D, g, b, adt)
     small = torch.empty(M, C, dtype=torch.float32, device=x.device)      # [B, h*w, C]
     ops.linear_fwd(y, M, D, w, bias, small, C)
-    return small, (xp, g, mean, rstd, y, w)
+    return small, (xp, g, mean, rstd, y, w), (b, bias)
 
 
-def _seg_small_bwd(saved, dims, dl, ld):
+def _seg_small_bwd(saved, small_params, dims, dl, ld):
     """Backward of _seg_small_fwd from d(small) given as [M, ld] in the activation dtype (columns >= C zero)."""
     xp, g, mean, rstd, y, w = saved
+    b, bias = small_params
     B, T, D, C = dims
     npatch = T - 1
     M = B * npatch
     adt = y.dtype
-    dw, dbias = ops.linear_dw(dl, y, M, C, D, ld_dy=ld)
+    dw, dbias = ops.linear_dw(dl, y, M, C, D, ld_dy=ld, weight=w, bias=bias)
     dy = torch.empty(M, D, dtype=adt, device=dl.device)
     ops.linear_dx(dl, M, C, w, dy, D, ld_dy=ld)
     dx = torch.zeros(B, T, D, dtype=torch.float32, device=dl.device)
     # rows of image b start at dx[b, 1]: the patch rows of one image are contiguous, images are T*D apart
     dxp = torch.empty(M, D, dtype=torch.float32, device=dl.device)
-    dg, db = ops.layernorm_bwd(dy, xp, D, g, mean, rstd, None, dxp, D, M, D)
+    dg, db = ops.layernorm_bwd(dy, xp, D, g, mean, rstd, None, dxp, D, M, D, beta=b)
     dx[:, 1:, :] = dxp.view(B, npatch, D)
     return dx, dg, db, dw, dbias
 
@@ -527,7 +562,7 @@ class _SegHead(Function):
         B, T, D = x.shape
         C = w.shape[0]
         npatch = T - 1
-        small, saved = _seg_small_fwd(x, g, b, w, bias, prec)
+        small, saved, ctx.small = _seg_small_fwd(x, g, b, w, bias, prec)
         big = ops.upsample_bilinear_fwd(small, npatch * C, 1, C, B, C, grid, grid, size, size)
         ctx.save_for_backward(*saved)
         ctx.dims = (B, T, D, C, grid, size)
@@ -549,7 +584,7 @@ class _SegHead(Function):
             dl[:, :C] = dsmall                                                # (B*196 x 17) pad+cast: cold glue
         else:
             dl = dsmall
-        return (*_seg_small_bwd(saved, (B, T, D, C), dl, ld), None, None, None)
+        return (*_seg_small_bwd(saved, ctx.small, (B, T, D, C), dl, ld), None, None, None)
 
 
 class _SegHeadLoss(Function):
@@ -560,7 +595,7 @@ class _SegHeadLoss(Function):
     def forward(ctx, x, g, b, w, bias, labels, grid, size, prec):
         B, T, D = x.shape
         C = w.shape[0]
-        small, saved = _seg_small_fwd(x, g, b, w, bias, prec)
+        small, saved, ctx.small = _seg_small_fwd(x, g, b, w, bias, prec)
         stats, lse, pred, labels = ops.seg_ce_fwd(small, labels, B, C, grid, grid, size, size)
         adt = ops.act_dtype(prec)
         ctx.needs = any(ctx.needs_input_grad[:5])
@@ -578,7 +613,7 @@ class _SegHeadLoss(Function):
         dl, *saved = ctx.saved_tensors
         B, T, D, C, ld = ctx.dims
         dl = dl * gloss.to(dl.dtype)                                          # [B*h*w, ld]: tiny
-        return (*_seg_small_bwd(saved, (B, T, D, C), dl, ld), None, None, None, None)
+        return (*_seg_small_bwd(saved, ctx.small, (B, T, D, C), dl, ld), None, None, None, None)
 
 
 def seg_head_loss(x, g, b, w, bias, labels, grid, size, prec):

@@ -98,6 +98,39 @@ def workspace(nbytes: int, device) -> torch.Tensor:
 
 
 # ------------------------------------------------------------------------------------------------------------
+# gradient destinations
+# ------------------------------------------------------------------------------------------------------------
+# ``optim.ParamArena`` keeps every parameter gradient in one flat buffer (the all-reduce / AdamW operand).  The backward
+# kernels write a parameter's gradient STRAIGHT into its arena slot when the parameter has no gradient yet: autograd
+# then adopts the returned view as ``param.grad`` (no ``grad += new`` launch, no zero-fill of 344 MB per step).  If the
+# parameter already holds a gradient (micro-batch accumulation) a fresh tensor is returned and autograd adds as usual.
+_grad_slots = {}
+
+
+def register_grad_slot(param, slot):
+    """``slot``: flat fp32 view of ``param.numel()`` elements that must receive d(loss)/d(param)."""
+    key = id(param)
+    _grad_slots[key] = slot
+    weakref.finalize(param, _grad_slots.pop, key, None)
+
+
+def grad_slot(param):
+    return _grad_slots.get(id(param)) if param is not None else None
+
+
+def grad_out(param, shape, device):
+    """fp32 tensor of ``shape`` for the kernels to write the gradient of ``param`` into (``param`` may be None)."""
+    slot = grad_slot(param)
+    if slot is not None and param.grad is None:
+        n = 1
+        for d in shape:
+            n *= d
+        if n == slot.numel():
+            return slot.view(shape)
+    return torch.empty(shape, dtype=torch.float32, device=device)
+
+
+# ------------------------------------------------------------------------------------------------------------
 # weights prepared for the MFMA path
 # ------------------------------------------------------------------------------------------------------------
 class PreparedWeight:
@@ -150,12 +183,13 @@ def layernorm_fwd(x, ldx, rows, dim, gamma, beta, out_dtype, eps=1e-5):
     return y, mean, rstd
 
 
-def layernorm_bwd(dy, x, ldx, gamma, mean, rstd, dx_add, dx, lddx, rows, dim, dx16=None, dx_colsum=None):
+def layernorm_bwd(dy, x, ldx, gamma, mean, rstd, dx_add, dx, lddx, rows, dim, dx16=None, dx_colsum=None, beta=None):
     """Writes dx (fp32 rows ``lddx`` apart; ``dx_add`` added if given, same layout) -> (dgamma, dbeta).
-    Optional fused by-products: ``dx16`` (bf16 [rows, dim] copy of dx) and ``dx_colsum`` (fp32 [dim] column sums)."""
+    Optional fused by-products: ``dx16`` (bf16 [rows, dim] copy of dx) and ``dx_colsum`` (fp32 [dim] column sums).
+    ``gamma`` / ``beta`` (the parameters) select the gradient destinations (``grad_out``)."""
     require_cuda(dy, x, dx)
-    dgamma = torch.empty(dim, dtype=torch.float32, device=x.device)
-    dbeta = torch.empty(dim, dtype=torch.float32, device=x.device)
+    dgamma = grad_out(gamma, (dim,), x.device)
+    dbeta = grad_out(beta, (dim,), x.device)
     nbytes = lib().mv_layernorm_bwd_workspace_bytes(rows, dim)
     ws = workspace(nbytes, x.device)
     check(lib().mv_layernorm_bwd(_p(dy), _DT[dy.dtype], _p(x), ldx, _p(gamma), _p(mean), _p(rstd), _p(dx_add), _p(dx),
@@ -209,12 +243,13 @@ def linear_dx(dy, M, N, weight, out, ldc, *, ld_dy=None, epi=EPI_NONE, aux=None,
     return out
 
 
-def linear_dw(dy, x, M, N, K, *, ld_dy=None, ldx=None, want_bias=True):
-    """dW[N, K] = dy[M, N]^T @ x[M, K] (fp32), db[N] = column sums of dy."""
+def linear_dw(dy, x, M, N, K, *, ld_dy=None, ldx=None, want_bias=True, weight=None, bias=None):
+    """dW[N, K] = dy[M, N]^T @ x[M, K] (fp32), db[N] = column sums of dy.  ``weight`` / ``bias`` (the parameters, optional)
+    select the gradient destinations (``grad_out``)."""
     ld_dy = N if ld_dy is None else ld_dy
     ldx = K if ldx is None else ldx
-    dw = torch.empty(N, K, dtype=torch.float32, device=x.device)
-    db = torch.empty(N, dtype=torch.float32, device=x.device) if want_bias else None
+    dw = grad_out(weight, (N, K), x.device)
+    db = grad_out(bias, (N,), x.device) if want_bias else None
     if dy.dtype == torch.bfloat16:
         nbytes = lib().mv_gemm_tn_workspace_bytes(N, K, M)
         ws = workspace(nbytes, x.device)
@@ -332,9 +367,9 @@ def embed_cls(cls, pos, x, B, T, D):
     check(lib().mv_embed_cls(_p(cls), _p(pos), _p(x), B, T, D, _s()), "embed_cls", B=B, T=T, D=D)
 
 
-def embed_bwd(dx, B, T, D):
-    dpos = torch.empty(T, D, dtype=torch.float32, device=dx.device)
-    dcls = torch.empty(D, dtype=torch.float32, device=dx.device)
+def embed_bwd(dx, B, T, D, pos=None, cls_token=None):
+    dpos = grad_out(pos, (T, D), dx.device)
+    dcls = grad_out(cls_token, (D,), dx.device)
     check(lib().mv_embed_bwd(_p(dx), _p(dpos), _p(dcls), 0, B, T, D, _s()), "embed_bwd", B=B, T=T, D=D)
     return dpos, dcls
 

@@ -59,6 +59,7 @@ class GradAllReducer:
         def hook(param):
             if not self.enabled:
                 return
+            self.arena.sync_grad(j)              # no-op when the gradient was written in place (the normal case)
             b = self.bucket_of[j]
             self.pending[b] -= 1
             if self.pending[b] == 0 and not self.launched[b]:
@@ -76,6 +77,9 @@ class GradAllReducer:
         if self.enabled:
             for b in range(len(self.ranges)):
                 if not self.launched[b]:
+                    for j in range(self.ranges[b][2], self.ranges[b][3]):
+                        if self.arena.params[j].grad is None:
+                            self.arena.sync_grad(j)          # no gradient this step: the slot must hold zeros
                     self._launch(b)
             for h in self.handles:
                 h.wait()

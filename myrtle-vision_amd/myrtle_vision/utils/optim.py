@@ -51,13 +51,33 @@ class ParamArena:
                 n = p.numel()
                 self.flat_param[o:o + n].copy_(p.detach().reshape(-1).float())
                 p.data = self.flat_param[o:o + n].view(p.shape)
-                p.grad = self.flat_grad[o:o + n].view(p.shape)
+                p.grad = None
+                ops.register_grad_slot(p, self.flat_grad[o:o + n])      # backward kernels write d/dp here directly
+
+    def slot(self, j):
+        o = self.offsets[j]
+        return self.flat_grad[o:o + self.params[j].numel()]
 
     def zero_grad(self):
-        self.flat_grad.zero_()
-        for p, o in zip(self.params, self.offsets):     # re-attach if something set them to None
-            if p.grad is None or p.grad.data_ptr() != self.flat_grad.data_ptr() + 4 * o:
-                p.grad = self.flat_grad[o:o + p.numel()].view(p.shape)
+        """``set_to_none`` semantics: with no gradient attached, the backward kernels write each parameter's gradient
+        straight into its arena slot and autograd adopts that view (``ops.grad_out``) -- no zero-fill, no adds."""
+        for p in self.params:
+            p.grad = None
+
+    def sync_grad(self, j):
+        """Make slot j hold parameter j's gradient: a no-op on the fast path (the gradient already IS the slot);
+        copies a gradient autograd materialised elsewhere; zero-fills the slot of a parameter that received none."""
+        p, slot = self.params[j], self.slot(j)
+        g = p.grad
+        if g is None:
+            slot.zero_()
+        elif g.data_ptr() != slot.data_ptr():
+            slot.copy_(g.detach().reshape(-1))
+            p.grad = slot.view(p.shape)
+
+    def sync_grads(self):
+        for j in range(len(self.params)):
+            self.sync_grad(j)
 
     def bump_versions(self):
         """The AdamW kernel writes through raw pointers: tell autograd / the bf16 weight cache the data changed."""
@@ -86,6 +106,7 @@ class AdamW:
 
     @torch.no_grad()
     def step(self):
+        self.arena.sync_grads()
         self.step_count += 1
         b1, b2 = self.defaults["betas"]
         a = self.arena

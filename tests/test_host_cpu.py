@@ -158,12 +158,22 @@ def test_param_arena_groups_and_views():
     assert "pos_embedding_det" not in arena.names and "det_tokens" not in arena.names
     for k, v in vit.state_dict().items():
         assert torch.equal(v, before[k])                                   # flattening preserved every value
-    for p, o in zip(arena.params, arena.offsets):
+    from myrtle_vision.hip import ops
+    for j, (p, o) in enumerate(zip(arena.params, arena.offsets)):
         assert p.data_ptr() == arena.flat_param.data_ptr() + 4 * o and o % 4 == 0
-        assert p.grad.data_ptr() == arena.flat_grad.data_ptr() + 4 * o
+        # no gradient attached: the backward kernels get the arena slot itself as their output (ops.grad_out)
+        assert p.grad is None and arena.slot(j).data_ptr() == arena.flat_grad.data_ptr() + 4 * o
+        assert ops.grad_out(p, p.shape, p.device).data_ptr() == arena.slot(j).data_ptr()
+    # fallback path: a gradient autograd materialised elsewhere is moved into its slot, a missing one zero-fills it
     arena.flat_grad.fill_(1.0)
+    p0 = arena.params[0]
+    p0.grad = torch.full_like(p0, 2.0)
+    assert ops.grad_out(p0, p0.shape, p0.device).data_ptr() != arena.slot(0).data_ptr()    # accumulation: fresh tensor
+    arena.sync_grads()
+    assert p0.grad.data_ptr() == arena.slot(0).data_ptr() and float(arena.slot(0).min()) == 2.0
+    assert sum(float(arena.slot(j).abs().sum()) for j in range(1, len(arena.params))) == 0.0   # (alignment gaps are in no slot)
     arena.zero_grad()
-    assert float(arena.flat_grad.abs().sum()) == 0.0
+    assert all(p.grad is None for p in arena.params)
 
 
 def test_checkpoint_wire_format_roundtrip(tmp_path):
@@ -272,6 +282,7 @@ def test_gradient_allreduce_world2_gloo(tmp_path):
     g = torch.Generator().manual_seed(7)
     X, Y = torch.randn(8, 12, generator=g), torch.randn(8, 3, generator=g)
     ((model(X) - Y) ** 2).mean().backward()
+    arena.sync_grads()                                               # torch's own gradients -> arena slots; unused -> zeros
     assert torch.allclose(arena.flat_grad, r0["grad"], atol=1e-6, rtol=1e-5)
     f0, f1 = torch.load(tmp_path / "final0.pt"), torch.load(tmp_path / "final1.pt")
     assert torch.equal(f0, f1)                                       # identical parameters on all ranks after K steps

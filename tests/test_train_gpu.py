@@ -58,3 +58,53 @@ def test_quantized_evaluation_path(tmp_path):
     cfg["vit_config"]["q_format"] = "FP16_32"
     q = evaluate(copy.deepcopy(cfg), "classification", quantize=True, calib_steps=1)
     assert abs(q["accuracy"] - fp32["accuracy"]) <= 0.2                     # fp16 weights barely move predictions
+
+
+@pytest.mark.parametrize("decoder,precision,size", [("classification", "bf16", 224), ("classification", "fp32", 224),
+                                                    ("segmentation", "bf16", 224), ("classification", "bf16", 80)])
+def test_gradients_land_in_their_arena_slots(decoder, precision, size):
+    """Zero-copy gradients: after backward EVERY arena parameter's .grad IS its slot of the flat buffer (the kernels wrote
+    there; autograd adopted the view -- no add, no copy), values equal the plain path without an arena, and a second
+    micro-batch accumulates (slot += new) exactly like torch's ``grad += new``."""
+    from myrtle_vision.hip.functional import cross_entropy
+    from myrtle_vision.models.vit import ViT
+    from myrtle_vision.utils.optim import ParamArena
+    from myrtle_vision.utils.utils import seed_everything
+    kw = dict(decoder=decoder, image_size=size, patch_size=16, num_classes=7, dim=128, depth=2, heads=2, mlp_dim=256,
+              dropout=0.0, emb_dropout=0.0)
+    g = torch.Generator().manual_seed(3)
+    img = torch.randn(2, 3, size, size, generator=g).cuda()
+    labels = (torch.randint(0, 7, (2,), generator=g) if decoder == "classification"
+              else torch.randint(0, 7, (2, size, size), generator=g)).cuda()
+
+    def loss_of(v, x, y):
+        return v.segmentation_loss(x, y)[0] if decoder == "segmentation" else cross_entropy(v(x), y)
+
+    seed_everything(11)
+    ref = ViT(precision=precision, q_format="FP32", **kw).cuda()
+    loss_of(ref, img, labels).backward()
+    want = {n: p.grad.clone() for n, p in ref.named_parameters() if p.grad is not None}
+
+    seed_everything(11)
+    vit = ViT(precision=precision, q_format="FP32", **kw).cuda()
+    arena = ParamArena(vit.named_parameters(), skip=vit.unused_parameter_names())
+    arena.flat_grad.fill_(float("nan"))                      # nothing may rely on a zero-filled buffer
+    arena.zero_grad()
+    loss_of(vit, img, labels).backward()
+    names = dict(zip(arena.names, range(len(arena.names))))
+    assert set(names) == set(want)
+    for n, j in names.items():
+        p = arena.params[j]
+        assert p.grad is not None, n
+        # at a non-native grid the positional embedding goes through the bicubic-resize glue on torch: its gradient is
+        # materialised by autograd and moved into the slot by sync_grads() (the fallback path)
+        if not (n == "pos_embedding" and size != 224):
+            assert p.grad.data_ptr() == arena.slot(j).data_ptr(), n                         # written in place
+        assert torch.equal(p.grad, want[n]), n                                              # same kernels, same bits
+    # second micro-batch: gradients accumulate into the slots
+    loss_of(vit, img, labels).backward()
+    arena.sync_grads()
+    for n, j in names.items():
+        p = arena.params[j]
+        assert p.grad.data_ptr() == arena.slot(j).data_ptr(), n
+        assert torch.allclose(p.grad, 2 * want[n], rtol=1e-6, atol=1e-30), n
