@@ -1515,6 +1515,12 @@ extern "C" int mv_colsum(const void* x, int x_dtype, long ld, float* out, int ac
   const int parts = colsum_parts(rows);
   MV_REQUIRE(workspace_bytes >= (size_t)parts * cols * sizeof(float), MV_ERR_WORKSPACE);
   hipStream_t s = (hipStream_t)stream;
+  if (x_dtype == MV_F32 && rows <= 2048) {      // already a partial-sum table (e.g. the DGELU epilogue's): one stage is enough
+    mv_reduce_rows_kernel<<<mv_reduce_rows_grid(cols), 1024, 0, s>>>((const float*)x, (int)rows, cols, ld, out, out, out, cols, cols,
+                                                                     accumulate);
+    MV_CHECK_LAUNCH();
+    return MV_OK;
+  }
   const int rpb = (int)((rows + parts - 1) / parts);
   dim3 grid(mv_cdiv(cols, 256), parts);
   if (x_dtype == MV_F32)
@@ -1522,7 +1528,7 @@ extern "C" int mv_colsum(const void* x, int x_dtype, long ld, float* out, int ac
   else
     colsum_partial_kernel<bf16_t><<<grid, 256, 0, s>>>((const bf16_t*)x, ld, workspace, rows, cols, rpb < 1 ? 1 : rpb);
   MV_CHECK_LAUNCH();
-  mv_reduce_rows_kernel<<<mv_cdiv(cols, 64), 1024, 0, s>>>(workspace, parts, cols, (long)cols, out, out, cols, accumulate);
+  mv_reduce_rows_kernel<<<mv_reduce_rows_grid(cols), 1024, 0, s>>>(workspace, parts, cols, (long)cols, out, out, out, cols, cols, accumulate);
   MV_CHECK_LAUNCH();
   return MV_OK;
 }

@@ -256,12 +256,19 @@ extern "C" int mv_layernorm_bwd(const void* dy, int dy_dtype, const float* x, lo
     MV_CHECK_LAUNCH();
   }
   const int groups = dx_colsum ? 3 : 2;
-  mv_reduce_rows_kernel<<<mv_cdiv(2 * dim, 64), 1024, 0, s>>>(workspace, rows > 0 ? grid : 0, 2 * dim, (long)groups * dim, dgamma,
-                                                             dbeta, dim, accumulate);
-  if (dx_colsum) {
+  // ONE finishing launch for all (2 or 3) column groups of the workspace: dgamma | dbeta | dx column sums.  (accumulate
+  // applies to dgamma/dbeta; the column sums are always overwritten: their group is reduced into a zero-initialised
+  // view only when accumulate == 0, otherwise it takes its own launch.)
+  if (dx_colsum && accumulate) {
+    mv_reduce_rows_kernel<<<mv_reduce_rows_grid(2 * dim), 1024, 0, s>>>(workspace, rows > 0 ? grid : 0, 2 * dim, (long)groups * dim,
+                                                                        dgamma, dbeta, dbeta, dim, 2 * dim, 1);
     MV_CHECK_LAUNCH();
-    mv_reduce_rows_kernel<<<mv_cdiv(dim, 64), 1024, 0, s>>>(workspace + 2 * dim, rows > 0 ? grid : 0, dim, (long)groups * dim,
-                                                           dx_colsum, dx_colsum, dim, 0);
+    mv_reduce_rows_kernel<<<mv_reduce_rows_grid(dim), 1024, 0, s>>>(workspace + 2 * dim, rows > 0 ? grid : 0, dim,
+                                                                    (long)groups * dim, dx_colsum, dx_colsum, dx_colsum, dim, dim, 0);
+  } else {
+    mv_reduce_rows_kernel<<<mv_reduce_rows_grid(groups * dim), 1024, 0, s>>>(workspace, rows > 0 ? grid : 0, groups * dim,
+                                                                             (long)groups * dim, dgamma, dbeta, dx_colsum, dim,
+                                                                             2 * dim, accumulate);
   }
   MV_CHECK_LAUNCH();
   return MV_OK;

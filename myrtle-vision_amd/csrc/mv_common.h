@@ -71,24 +71,28 @@ __device__ __forceinline__ float dgelu_f(float x) {
 }
 
 // out[c] (+)= sum over rows r of partial[r * ld + c]: the second stage of the deterministic two-stage reductions
-// (LayerNorm dgamma/dbeta, bias-gradient column sums).  One 1024-thread block per 64 columns: the 16 waves take
-// rows round-robin with coalesced 256-byte reads, then combine through LDS.  Columns >= split go to out1.
+// (LayerNorm dgamma/dbeta/dx column sums, bias-gradient column sums).  One 1024-thread block per 16 columns (so even
+// a 768-column reduction spreads over 48+ CUs): lane l takes column l&15 and row phase l>>4 of its wave, the 64 row
+// phases of the block walk the rows round-robin, then combine through LDS in a fixed order.
+// Columns [0, split0) go to out0, [split0, split1) to out1, the rest to out2.
+constexpr int MV_RR_COLS = 16;
 static __global__ __launch_bounds__(1024) void mv_reduce_rows_kernel(const float* __restrict__ partial, int nrows,
                                                                      int ncols, long ld, float* out0, float* out1,
-                                                                     int split, int accumulate) {
-  __shared__ float red[16][64];
+                                                                     float* out2, int split0, int split1, int accumulate) {
+  __shared__ float red[64][MV_RR_COLS];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int c = blockIdx.x * 64 + lane;
+  const int c = blockIdx.x * MV_RR_COLS + (lane & 15), phase = wave * 4 + (lane >> 4);
   float s = 0.f;
   if (c < ncols)
-    for (int r = wave; r < nrows; r += 16) s += partial[(long)r * ld + c];
-  red[wave][lane] = s;
+    for (int r = phase; r < nrows; r += 64) s += partial[(long)r * ld + c];
+  red[phase][lane & 15] = s;
   __syncthreads();
-  if (wave == 0 && c < ncols) {
+  if (threadIdx.x < MV_RR_COLS && c < ncols) {
     float t = 0.f;
-#pragma unroll
-    for (int w = 0; w < 16; ++w) t += red[w][lane];
-    float* o = (c < split) ? (out0 + c) : (out1 + (c - split));
+#pragma unroll 8
+    for (int w = 0; w < 64; ++w) t += red[w][threadIdx.x];
+    float* o = (c < split0) ? (out0 + c) : (c < split1) ? (out1 + (c - split0)) : (out2 + (c - split1));
     *o = accumulate ? (*o + t) : t;
   }
 }
+inline int mv_reduce_rows_grid(int ncols) { return (ncols + MV_RR_COLS - 1) / MV_RR_COLS; }
