@@ -18,6 +18,10 @@
 // conflict-free order for transposed reads of 128-byte rows in the sw128 image (tools/lds_bank_sim.py).
 #include "mv_common.h"
 
+#ifndef MV_ATTN_ABLATE
+#define MV_ATTN_ABLATE 0   // diagnostic builds only (tools/ablate_attn.sh): bit k removes one phase of attn_bwd4_kernel
+#endif
+
 namespace {
 
 constexpr float LOG2E = 1.4426950408889634f;
@@ -69,6 +73,24 @@ __device__ __forceinline__ bf16x8 row_frag128(const char* tile, int row_base, in
   return *reinterpret_cast<const bf16x8*>(tile + row_base * 128 + rf_off);
 }
 
+// K and V of one head, global -> LDS by DMA ([rows][64] bf16 = 128-byte rows, the sw128 image; one wave-instruction =
+// 8 rows).  Every piece is in flight at once and no register is touched.  (The register path -- load, select zero for
+// rows >= N, ds_write -- compiled to load / s_waitcnt vmcnt(0) / ds_write once per 16 bytes: ~14 exposed memory round
+// trips per thread.)  Rows >= N are CLAMPED to row N-1, not zeroed: padded keys are masked (`key < N`: p = 0 exactly)
+// and padded queries are either never stored (forward) or masked through lse = +inf (backward), so their
+// contributions are 0 x finite.  The caller waits (s_waitcnt vmcnt(0)) and barriers before reading.
+__device__ __forceinline__ void stage_kv_dma(const bf16_t* base, long D, int N, char* sK, int rows_k, char* sV, int rows_v,
+                                             int wave, int nwaves, int lane) {
+  const int prow = lane >> 3, pch = lane & 7;
+  for (int pc = wave; pc < rows_k / 8; pc += nwaves) {
+    const int row = 8 * pc + prow;
+    const long rr = row < N ? row : N - 1;
+    const int ch = pch ^ (((row >> 1) & 3) << 1);
+    glds16(base + rr * 3 * D + D + ch * 8, sK + pc * 1024);
+    if (pc < rows_v / 8) glds16(base + rr * 3 * D + 2 * D + ch * 8, sV + pc * 1024);
+  }
+}
+
 // ------------------------------------------------------------------------------------------------
 // forward: one 256-thread workgroup per (image, head); waves take 16-query tiles round-robin
 // ------------------------------------------------------------------------------------------------
@@ -84,28 +106,26 @@ __global__ __launch_bounds__(256, (NKT <= 14 ? 2 : 1)) void attn_fwd_kernel(cons
   const int b = blockIdx.x / H, h = blockIdx.x % H;
   const long D = (long)H * 64;
   const bf16_t* base = qkv + (long)b * N * 3 * D + h * 64;
-  const u32x4 zero4 = {0u, 0u, 0u, 0u};
-  for (int idx = tid; idx < NP * 8; idx += 256) {
-    const int row = idx >> 3, ch = idx & 7;
-    const long rr = row < N ? row : N - 1;  // unconditional load from a clamped row, zeroed by select
-    u32x4 kv = *reinterpret_cast<const u32x4*>(base + rr * 3 * D + D + ch * 8);
-    u32x4 vv = *reinterpret_cast<const u32x4*>(base + rr * 3 * D + 2 * D + ch * 8);
-    kv = row < N ? kv : zero4;
-    vv = row < N ? vv : zero4;
-    *reinterpret_cast<u32x4*>(sK + sw128(row, ch)) = kv;
-    *reinterpret_cast<u32x4*>(sV + sw128(row, ch)) = vv;
-  }
+  stage_kv_dma(base, D, N, sK, NP, sV, NP, wave, 4, lane);
+  const int nqt = (N + 15) >> 4;
+  // Q fragments straight from global memory, one 16-query tile ahead: the next tile's loads are in flight while this
+  // one computes (rows >= N clamped: those outputs are not stored)
+  auto load_q = [&](int qt, int ks) -> u32x4 {
+    const int qrow = qt * 16 + (lane & 15);
+    return *reinterpret_cast<const u32x4*>(base + (long)(qrow < N ? qrow : N - 1) * 3 * D + 32 * ks + 8 * g);
+  };
+  u32x4 qn0 = load_q(wave < nqt ? wave : 0, 0), qn1 = load_q(wave < nqt ? wave : 0, 1);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // this wave's K/V DMA pieces (and its first Q tile) have landed
   __syncthreads();
 
-  const int nqt = (N + 15) >> 4;
   for (int qt = wave; qt < nqt; qt += 4) {
     const int qrow = qt * 16 + (lane & 15);
     bf16x8 qf[2];
-#pragma unroll
-    for (int ks = 0; ks < 2; ++ks) {
-      u32x4 t = *reinterpret_cast<const u32x4*>(base + (long)(qrow < N ? qrow : N - 1) * 3 * D + 32 * ks + 8 * g);
-      t = qrow < N ? t : zero4;
-      qf[ks] = __builtin_bit_cast(bf16x8, t);
+    qf[0] = __builtin_bit_cast(bf16x8, qn0);
+    qf[1] = __builtin_bit_cast(bf16x8, qn1);
+    if (qt + 4 < nqt) {
+      qn0 = load_q(qt + 4, 0);
+      qn1 = load_q(qt + 4, 1);
     }
     f32x4 st[NKT];
     float mx = -INFINITY;
@@ -188,16 +208,7 @@ __global__ __launch_bounds__(512, 1) void attn_bwd_kernel(const bf16_t* __restri
   const u32x4 zero4 = {0u, 0u, 0u, 0u};
   const float c2 = scale * LOG2E;
 
-  for (int idx = tid; idx < NP * 8; idx += 512) {
-    const int row = idx >> 3, ch = idx & 7;
-    const long rr = row < N ? row : N - 1;  // unconditional load from a clamped row, zeroed by select
-    u32x4 kv = *reinterpret_cast<const u32x4*>(base + rr * 3 * D + D + ch * 8);
-    u32x4 vv = *reinterpret_cast<const u32x4*>(base + rr * 3 * D + 2 * D + ch * 8);
-    kv = row < N ? kv : zero4;
-    vv = row < N ? vv : zero4;
-    *reinterpret_cast<u32x4*>(sK + sw128(row, ch)) = kv;
-    *reinterpret_cast<u32x4*>(sV + sw128(row, ch)) = vv;
-  }
+  stage_kv_dma(base, D, N, sK, NP, sV, NP, wave, 8, lane);
   // dS^T rows of key tiles that are entirely padding are never written: keep them finite (0 * K-pad-row = 0)
   for (int idx = tid; idx < 2 * NP * 4; idx += 512) reinterpret_cast<u32x4*>(sDS)[idx] = zero4;
   for (int row = tid; row < NP; row += 512) {
@@ -223,8 +234,8 @@ __global__ __launch_bounds__(512, 1) void attn_bwd_kernel(const bf16_t* __restri
   const long pair_ld = p_which == 0 ? 3 * D : D;
   auto load_pair = [&](int u) -> u32x4 {
     const int q = 32 * u + p_row;
-    const u32x4 v = *reinterpret_cast<const u32x4*>(pair_src + (long)(q < N ? q : N - 1) * pair_ld);
-    return q < N ? v : zero4;
+    // rows >= N clamped, not zeroed (masked through lse = +inf): a select would make the compiler wait for the load at once
+    return *reinterpret_cast<const u32x4*>(pair_src + (long)(q < N ? q : N - 1) * pair_ld);
   };
   auto store_pair = [&](int buf, u32x4 v) {
     *reinterpret_cast<u32x4*>(sPair + buf * 8192 + p_which * 4096 + sw128(p_row, p_ch)) = v;
@@ -241,6 +252,7 @@ __global__ __launch_bounds__(512, 1) void attn_bwd_kernel(const bf16_t* __restri
 
   constexpr int NQP = NKT / 2;
   store_pair(0, load_pair(0));
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // this wave's K/V DMA pieces have landed
   __syncthreads();
 
   const int nkt_valid = (N + 15) >> 4;
@@ -304,7 +316,6 @@ __global__ __launch_bounds__(512, 1) void attn_bwd_kernel(const bf16_t* __restri
       const int trk = dt == 0 ? L.tr[0] : dt == 1 ? L.tr[1] : dt == 2 ? L.tr[2] : L.tr[3];   // static indices (no scratch)
       const int dsoff = (4 * g + ((lane >> 2) & 3)) * 64 + ((t ^ (g & 1)) << 5) + 8 * (lane & 3);
       f32x4 dq = {0.f, 0.f, 0.f, 0.f};
-      const int q4 = (lane >> 2) & 3, p = lane & 3;
       for (int v = 0; v < NQP; ++v) {
         if (32 * v >= N) break;
         const char* dsp = sds + 2048 * v + dsoff;               // swds(32 v + 4g + q4, t) + 8 p ; the +16-row block is +1024
@@ -360,21 +371,13 @@ __global__ __launch_bounds__(256, 2) void attn_bwd4_kernel(const bf16_t* __restr
   const u32x4 zero4 = {0u, 0u, 0u, 0u};
   const float c2 = scale * LOG2E;
 
-  for (int idx = tid; idx < NPK * 8; idx += 256) {
-    const int row = idx >> 3, ch = idx & 7;
-    const long rr = row < N ? row : N - 1;
-    u32x4 kv = *reinterpret_cast<const u32x4*>(base + rr * 3 * D + D + ch * 8);
-    u32x4 vv = *reinterpret_cast<const u32x4*>(base + rr * 3 * D + 2 * D + ch * 8);
-    kv = row < N ? kv : zero4;
-    vv = row < N ? vv : zero4;
-    *reinterpret_cast<u32x4*>(sK + sw128(row, ch)) = kv;
-    if (row < NPV) *reinterpret_cast<u32x4*>(sV + sw128(row, ch)) = vv;
-  }
+  // K, V by DMA (the serialized register path was 112 of this kernel's 313 us: stage_kv_dma)
+  stage_kv_dma(base, D, N, sK, NPK, sV, NPV, wave, 4, lane);
   for (int idx = tid; idx < NPK * 4; idx += 256) reinterpret_cast<u32x4*>(sDS)[idx] = zero4;   // padding key rows stay 0
   if (tid < NPK) {
     const int row = tid;
     float dl = 0.f, l2 = INFINITY;
-    if (row < N) {
+    if (row < N && !(MV_ATTN_ABLATE & 8)) {
       l2 = lse[((long)b * H + h) * N + row] * LOG2E;
 #pragma unroll
       for (int c = 0; c < 8; ++c) {
@@ -396,8 +399,9 @@ __global__ __launch_bounds__(256, 2) void attn_bwd4_kernel(const bf16_t* __restr
     const int q = 32 * u + row;
     const bf16_t* src = which == 0 ? base + ch * 8 : dobase + ch * 8;
     const long ld = which == 0 ? 3 * D : D;
-    const u32x4 v = *reinterpret_cast<const u32x4*>(src + (long)(q < N ? q : N - 1) * ld);
-    return q < N ? v : zero4;
+    // rows >= N: clamped, not zeroed (masked through lse = +inf, see above) -- a select here forces the compiler to wait
+    // for the load at once, which turned this prefetch into a stall
+    return *reinterpret_cast<const u32x4*>(src + (long)(q < N ? q : N - 1) * ld);
   };
   auto store_pair = [&](int e, u32x4 v) {
     const int idx = tid + 256 * e;
@@ -416,6 +420,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd4_kernel(const bf16_t* __restr
 
   store_pair(0, load_pair(0, 0));
   store_pair(1, load_pair(0, 1));
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // this wave's K/V DMA pieces have landed
   __syncthreads();
 
   const char* sQ = sPair;
@@ -423,27 +428,39 @@ __global__ __launch_bounds__(256, 2) void attn_bwd4_kernel(const bf16_t* __restr
   const int nkt_valid = (N + 15) >> 4;
   for (int u = 0; u < NQP; ++u) {
     u32x4 nx0 = zero4, nx1 = zero4;
-    if (u + 1 < NQP) {
+    if (u + 1 < NQP && !(MV_ATTN_ABLATE & 4)) {
       nx0 = load_pair(u + 1, 0);
       nx1 = load_pair(u + 1, 1);
     }
-    if (32 * u < N) {
+    if (32 * u < N && !(MV_ATTN_ABLATE & 16)) {
+      // The query pair's TRANSPOSED fragments (operands of the dV / dK products) do not depend on the key tile: read them
+      // once per pair (8 fragments, 32 VGPRs) instead of once per key tile.  (Hoisting the row fragments as well spills.)
+      bf16x8 dotr[4], qtr[4];
+#pragma unroll
+      for (int dt = 0; dt < 4; ++dt) {
+        dotr[dt] = tr_frag128(sDO, 0, L.tr[dt]);
+        qtr[dt] = tr_frag128(sQ, 0, L.tr[dt]);
+      }
 #pragma unroll
       for (int i = 0; i < KPW; ++i) {
         const int kt = wave + 4 * i;
         if (kt >= nkt_valid || kt >= NKT) continue;
         const int key = kt * 16 + (lane & 15);
         f32x4 s[2], dp[2];
+        bf16x8 kf[2], vf[2];
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+          kf[ks] = row_frag128(sK, kt * 16, L.rf[ks]);
+          vf[ks] = row_frag128(sV, kt * 16, L.rf[ks]);
+        }
 #pragma unroll
         for (int t = 0; t < 2; ++t) {
           s[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
           dp[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
           for (int ks = 0; ks < 2; ++ks) {
-            s[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(row_frag128(sQ, t * 16, L.rf[ks]),
-                                                           row_frag128(sK, kt * 16, L.rf[ks]), s[t], 0, 0, 0);
-            dp[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(row_frag128(sDO, t * 16, L.rf[ks]),
-                                                            row_frag128(sV, kt * 16, L.rf[ks]), dp[t], 0, 0, 0);
+            s[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(row_frag128(sQ, t * 16, L.rf[ks]), kf[ks], s[t], 0, 0, 0);
+            dp[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(row_frag128(sDO, t * 16, L.rf[ks]), vf[ks], dp[t], 0, 0, 0);
           }
         }
         f32x4 pp[2], ds[2];
@@ -452,34 +469,33 @@ __global__ __launch_bounds__(256, 2) void attn_bwd4_kernel(const bf16_t* __restr
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
             const int ql = 32 * u + 16 * t + 4 * g + r;
-            float p = __builtin_amdgcn_exp2f(s[t][r] * c2 - sLse[ql]);
-            p = key < N ? p : 0.f;
+            float p = (MV_ATTN_ABLATE & 2) ? s[t][r] : __builtin_amdgcn_exp2f(s[t][r] * c2 - sLse[ql]);
+            p = ((MV_ATTN_ABLATE & 2) || key < N) ? p : 0.f;
             pp[t][r] = p;
-            ds[t][r] = p * (dp[t][r] - sDelta[ql]) * scale;
+            ds[t][r] = (MV_ATTN_ABLATE & 2) ? dp[t][r] : p * (dp[t][r] - sDelta[ql]) * scale;
           }
         const bf16x8 pf = pack8(pp[0], pp[1]);
         const bf16x8 dsf = pack8(ds[0], ds[1]);
 #pragma unroll
         for (int dt = 0; dt < 4; ++dt) {
-          adv[i][dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(tr_frag128(sDO, 0, L.tr[dt]), pf, adv[i][dt], 0, 0, 0);
-          adk[i][dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(tr_frag128(sQ, 0, L.tr[dt]), dsf, adk[i][dt], 0, 0, 0);
+          adv[i][dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(dotr[dt], pf, adv[i][dt], 0, 0, 0);
+          adk[i][dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qtr[dt], dsf, adk[i][dt], 0, 0, 0);
         }
 #pragma unroll
         for (int t = 0; t < 2; ++t) *reinterpret_cast<bf16x4*>(sDS + swds(key, t) + 8 * g) = pack4(ds[t]);
       }
     }
     __syncthreads();                                   // S-phase done everywhere: dS^T complete, Q/dO pair no longer read
-    if (u + 1 < NQP) {
+    if (u + 1 < NQP && !(MV_ATTN_ABLATE & 4)) {
       store_pair(0, nx0);
       store_pair(1, nx1);
     }
     // dQ^T[d][q] = sum_key K^T[d][key] dS^T[key][q]: 2 q-tiles x 4 d-tiles = 8 output tiles, two per wave
-    if (32 * u < N) {
+    if (32 * u < N && !(MV_ATTN_ABLATE & 1)) {
       const int t = wave >> 1;
       const int trk0 = (wave & 1) ? L.tr[2] : L.tr[0], trk1 = (wave & 1) ? L.tr[3] : L.tr[1];
       const int dsoff = (4 * g + ((lane >> 2) & 3)) * 64 + ((t ^ (g & 1)) << 5) + 8 * (lane & 3);
       f32x4 dq0 = {0.f, 0.f, 0.f, 0.f}, dq1 = {0.f, 0.f, 0.f, 0.f};
-      const int q4 = (lane >> 2) & 3, p = lane & 3;
       for (int v = 0; v < NQP; ++v) {
         if (32 * v >= N) break;
         const char* dsp = sDS + 2048 * v + dsoff;

@@ -427,11 +427,7 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(const bf16_t* __restric
 // ------------------------------------------------------------------------------------------------
 // NT kernel, direct-to-LDS staging (K % 64 == 0)
 // ------------------------------------------------------------------------------------------------
-__device__ __forceinline__ void glds16(const void* gsrc, void* lds_wave_base) {
-  // 16 B per lane; LDS destination = wave-uniform base (M0) + lane * 16
-  __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gsrc,
-                                   (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
-}
+// glds16 (LDS-DMA, 16 B per lane): mv_common.h
 
 template <int EPI, typename CT>
 __global__ __launch_bounds__(256, 2) void gemm_nt_glds_kernel(const bf16_t* __restrict__ A, int lda,

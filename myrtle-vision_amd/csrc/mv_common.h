@@ -70,6 +70,14 @@ __device__ __forceinline__ float dgelu_f(float x) {
   return cdf + x * pdf;
 }
 
+// Direct global -> LDS copy (LDS-DMA), 16 bytes per lane: the LDS destination is a WAVE-UNIFORM base (M0) + lane * 16,
+// so a wave-instruction fills 1 KiB of consecutive LDS; any swizzle goes on the per-lane SOURCE address.  Counted in
+// vmcnt; nothing orders it against ds_reads except an explicit s_waitcnt vmcnt + barrier.
+__device__ __forceinline__ void glds16(const void* gsrc, void* lds_wave_base) {
+  __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gsrc,
+                                   (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
+}
+
 // out[c] (+)= sum over rows r of partial[r * ld + c]: the second stage of the deterministic two-stage reductions
 // (LayerNorm dgamma/dbeta/dx column sums, bias-gradient column sums).  One 1024-thread block per 16 columns (so even
 // a 768-column reduction spreads over 48+ CUs): lane l takes column l&15 and row phase l>>4 of its wave, the 64 row
