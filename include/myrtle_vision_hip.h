@@ -45,6 +45,10 @@ enum {
   MV_EPI_RESIDUAL = 2, /* C = acc + bias + aux              (aux: fp32 [M, ld_aux]) */
   MV_EPI_DGELU = 3,    /* C = acc * gelu_erf'(aux)          (aux: pre-activation, dtype of A); bf16 kernel only: out2 (optional)
                           = fp32 [ceil(M/64), ld_out2] per-64-row column sums of C (bias-gradient partials) */
+  MV_EPI_GELU_GRAD = 5, /* bf16 kernel only: C = gelu_erf(acc + bias), out2 (optional) = gelu_erf'(acc + bias): what the
+                           backward needs, so that its epilogue is MV_EPI_MUL instead of re-evaluating erf */
+  MV_EPI_MUL = 6,      /* bf16 kernel only: C = acc * aux (aux: dtype of A, e.g. the gelu' left by MV_EPI_GELU_GRAD);
+                          out2 as MV_EPI_DGELU (per-64-row column sums of C) */
   MV_EPI_EMBED = 4     /* patch-embedding: row m of the GEMM is patch (m % aux_i) of image (m / aux_i);
                           C row = img*(aux_i+1) + 1 + patch;  C = acc + bias + aux[1 + patch]  (aux: fp32 [aux_i+1, N]) */
 };

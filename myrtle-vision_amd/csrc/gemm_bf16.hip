@@ -124,6 +124,16 @@ __device__ __forceinline__ float gelu_fast(float x) {
   float e;
   return 0.5f * x * (1.0f + erf_fast(x * 0.70710678118654752440f, e));
 }
+// gelu(x) and gelu'(x) together (they share the erf and the Gaussian factor): the forward epilogue of fc1 can leave
+// gelu'(h) for the backward pass, whose epilogue is then a plain multiply (MV_EPI_GELU_GRAD / MV_EPI_MUL)
+__device__ __forceinline__ void gelu_both_fast(float x, float& gl, float& dg) {
+  float e;
+  const float cdf = 0.5f * (1.0f + erf_fast(x * 0.70710678118654752440f, e));
+  gl = x * cdf;
+  dg = fmaf(x * 0.39894228040143267794f, e, cdf);
+}
+constexpr bool epi_is_gelu(int e) { return e == MV_EPI_GELU || e == MV_EPI_GELU_GRAD; }
+constexpr bool epi_is_dgelu(int e) { return e == MV_EPI_DGELU || e == MV_EPI_MUL; }
 __device__ __forceinline__ float dgelu_fast(float x) {
   float e;
   const float cdf = 0.5f * (1.0f + erf_fast(x * 0.70710678118654752440f, e));
@@ -158,10 +168,11 @@ __device__ __forceinline__ void nt_epilogue(f32x4 (&acc)[4][4], CT* __restrict__
                         ((ep.ld_out2 & 3) == 0) && ((reinterpret_cast<uintptr_t>(ep.bias) & 15) == 0);
   if (interior) {
     const int mb = m0 + wm * 64 + (lane & 15), nb = n0 + wn * 64 + 4 * (lane >> 4);
-    float4 bv[4];
+    float4 bv[4];                                      // (the input-gradient epilogues never carry a bias: constants there)
 #pragma unroll
     for (int j = 0; j < 4; ++j)
-      bv[j] = ep.bias ? *reinterpret_cast<const float4*>(ep.bias + nb + j * 16) : make_float4(0.f, 0.f, 0.f, 0.f);
+      bv[j] = (!epi_is_dgelu(EPI) && ep.bias) ? *reinterpret_cast<const float4*>(ep.bias + nb + j * 16)
+                                               : make_float4(0.f, 0.f, 0.f, 0.f);
     long crow[4];
     int prow[4];
 #pragma unroll
@@ -186,7 +197,7 @@ __device__ __forceinline__ void nt_epilogue(f32x4 (&acc)[4][4], CT* __restrict__
         }
     }
     bf16x4 hx[4][4];                                   // DGELU: the saved pre-activation, kept packed (32 VGPRs, not 64)
-    if constexpr (EPI == MV_EPI_DGELU) {
+    if constexpr (epi_is_dgelu(EPI)) {
 #pragma unroll
       for (int i = 0; i < 4; ++i)
 #pragma unroll
@@ -199,8 +210,8 @@ __device__ __forceinline__ void nt_epilogue(f32x4 (&acc)[4][4], CT* __restrict__
     for (int j = 0; j < 4; ++j)
 #pragma unroll
       for (int r = 0; r < 4; ++r) cs[j][r] = 0.f;
-    if constexpr (sizeof(CT) == 2 && (EPI == MV_EPI_NONE || EPI == MV_EPI_GELU || EPI == MV_EPI_DGELU)) {
-      if (((ldc & 7) == 0) && ((ep.ld_out2 & 7) == 0 || EPI != MV_EPI_GELU)) {
+    if constexpr (sizeof(CT) == 2 && (EPI == MV_EPI_NONE || epi_is_gelu(EPI) || epi_is_dgelu(EPI))) {
+      if (((ldc & 7) == 0) && ((ep.ld_out2 & 7) == 0 || !epi_is_gelu(EPI))) {
         const int g = lane >> 4;
         const int nw = n0 + wn * 64 + 16 * (g & 1) + 8 * (g >> 1);      // + 32 jp: first of this lane's 8 columns
 #pragma unroll
@@ -213,23 +224,34 @@ __device__ __forceinline__ void nt_epilogue(f32x4 (&acc)[4][4], CT* __restrict__
               const int j = 2 * jp + q;
               v[q][0] = acc[i][j][0] + bv[j].x; v[q][1] = acc[i][j][1] + bv[j].y;
               v[q][2] = acc[i][j][2] + bv[j].z; v[q][3] = acc[i][j][3] + bv[j].w;
-              if constexpr (EPI == MV_EPI_GELU) {
+              if constexpr (epi_is_gelu(EPI)) {
 #pragma unroll
-                for (int r = 0; r < 4; ++r) { hpre[q][r] = v[q][r]; v[q][r] = gelu_fast(v[q][r]); }
-              } else if constexpr (EPI == MV_EPI_DGELU) {
-                v[q][0] *= dgelu_fast((float)hx[i][j][0]); v[q][1] *= dgelu_fast((float)hx[i][j][1]);
-                v[q][2] *= dgelu_fast((float)hx[i][j][2]); v[q][3] *= dgelu_fast((float)hx[i][j][3]);
+                for (int r = 0; r < 4; ++r) {
+                  if constexpr (EPI == MV_EPI_GELU_GRAD) {
+                    float gl, dg;
+                    gelu_both_fast(v[q][r], gl, dg);
+                    hpre[q][r] = dg;                       // out2 <- gelu'(pre-activation)
+                    v[q][r] = gl;
+                  } else {
+                    hpre[q][r] = v[q][r];
+                    v[q][r] = gelu_fast(v[q][r]);
+                  }
+                }
+              } else if constexpr (epi_is_dgelu(EPI)) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                  v[q][r] *= (EPI == MV_EPI_MUL) ? (float)hx[i][j][r] : dgelu_fast((float)hx[i][j][r]);
                 cs[j][0] += v[q][0]; cs[j][1] += v[q][1]; cs[j][2] += v[q][2]; cs[j][3] += v[q][3];
               }
             }
-            if constexpr (EPI == MV_EPI_GELU) {
+            if constexpr (epi_is_gelu(EPI)) {
               if (ep.out2)
                 *reinterpret_cast<u32x4*>(reinterpret_cast<bf16_t*>(ep.out2) + (long)(mb + i * 16) * ep.ld_out2 + nw + 32 * jp) =
                     pair_swap_bf16(hpre[0], hpre[1]);
             }
             *reinterpret_cast<u32x4*>(C + crow[i] * ldc + nw + 32 * jp) = pair_swap_bf16(v[0], v[1]);
           }
-        if constexpr (EPI == MV_EPI_DGELU) {
+        if constexpr (epi_is_dgelu(EPI)) {
           if (ep.out2) nt_colsum_flush(cs, reinterpret_cast<float*>(ep.out2), ep.ld_out2, (m0 + wm * 64) >> 6, nb, N, lane);
         }
         return;
@@ -241,20 +263,24 @@ __device__ __forceinline__ void nt_epilogue(f32x4 (&acc)[4][4], CT* __restrict__
       for (int j = 0; j < 4; ++j) {
         float v[4] = {acc[i][j][0] + bv[j].x, acc[i][j][1] + bv[j].y, acc[i][j][2] + bv[j].z, acc[i][j][3] + bv[j].w};
         const int n = nb + j * 16;
-        if constexpr (EPI == MV_EPI_GELU) {
-          if (ep.out2) store4(reinterpret_cast<bf16_t*>(ep.out2) + (long)(mb + i * 16) * ep.ld_out2 + n, v, true, 4);
+        if constexpr (epi_is_gelu(EPI)) {
+          float o2[4] = {v[0], v[1], v[2], v[3]};
 #pragma unroll
-          for (int r = 0; r < 4; ++r) v[r] = gelu_fast(v[r]);
+          for (int r = 0; r < 4; ++r) {
+            if constexpr (EPI == MV_EPI_GELU_GRAD) gelu_both_fast(o2[r], v[r], o2[r]);
+            else v[r] = gelu_fast(v[r]);
+          }
+          if (ep.out2) store4(reinterpret_cast<bf16_t*>(ep.out2) + (long)(mb + i * 16) * ep.ld_out2 + n, o2, true, 4);
         } else if constexpr (EPI == MV_EPI_RESIDUAL || EPI == MV_EPI_EMBED) {
           v[0] += ax[i][j].x; v[1] += ax[i][j].y; v[2] += ax[i][j].z; v[3] += ax[i][j].w;
-        } else if constexpr (EPI == MV_EPI_DGELU) {
-          v[0] *= dgelu_fast((float)hx[i][j][0]); v[1] *= dgelu_fast((float)hx[i][j][1]);
-          v[2] *= dgelu_fast((float)hx[i][j][2]); v[3] *= dgelu_fast((float)hx[i][j][3]);
+        } else if constexpr (epi_is_dgelu(EPI)) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) v[r] *= (EPI == MV_EPI_MUL) ? (float)hx[i][j][r] : dgelu_fast((float)hx[i][j][r]);
           cs[j][0] += v[0]; cs[j][1] += v[1]; cs[j][2] += v[2]; cs[j][3] += v[3];
         }
         store4(C + crow[i] * ldc + n, v, true, 4);
       }
-    if constexpr (EPI == MV_EPI_DGELU) {
+    if constexpr (epi_is_dgelu(EPI)) {
       if (ep.out2) nt_colsum_flush(cs, reinterpret_cast<float*>(ep.out2), ep.ld_out2, (m0 + wm * 64) >> 6, nb, N, lane);
     }
     return;
@@ -289,21 +315,25 @@ __device__ __forceinline__ void nt_epilogue(f32x4 (&acc)[4][4], CT* __restrict__
         for (int r = 0; r < 4; ++r)
           if (r < nvalid) v[r] += ep.bias[n + r];
       }
-      if constexpr (EPI == MV_EPI_GELU) {
-        if (ep.out2) store4(reinterpret_cast<bf16_t*>(ep.out2) + (long)m * ep.ld_out2 + n, v, vec && (ep.ld_out2 & 3) == 0, nvalid);
+      if constexpr (epi_is_gelu(EPI)) {
+        float o2[4] = {v[0], v[1], v[2], v[3]};
 #pragma unroll
-        for (int r = 0; r < 4; ++r) v[r] = gelu_fast(v[r]);
+        for (int r = 0; r < 4; ++r) {
+          if constexpr (EPI == MV_EPI_GELU_GRAD) gelu_both_fast(o2[r], v[r], o2[r]);
+          else v[r] = gelu_fast(v[r]);
+        }
+        if (ep.out2) store4(reinterpret_cast<bf16_t*>(ep.out2) + (long)m * ep.ld_out2 + n, o2, vec && (ep.ld_out2 & 3) == 0, nvalid);
       } else if constexpr (EPI == MV_EPI_RESIDUAL) {
         const float* ax = reinterpret_cast<const float*>(ep.aux) + (long)m * ep.ld_aux + n;
 #pragma unroll
         for (int r = 0; r < 4; ++r)
           if (r < nvalid) v[r] += ax[r];
-      } else if constexpr (EPI == MV_EPI_DGELU) {
+      } else if constexpr (epi_is_dgelu(EPI)) {
         const bf16_t* ax = reinterpret_cast<const bf16_t*>(ep.aux) + (long)m * ep.ld_aux + n;
 #pragma unroll
         for (int r = 0; r < 4; ++r)
           if (r < nvalid) {
-            v[r] *= dgelu_fast((float)ax[r]);
+            v[r] *= (EPI == MV_EPI_MUL) ? (float)ax[r] : dgelu_fast((float)ax[r]);
             cs[j][r] += v[r];
           }
       } else if constexpr (EPI == MV_EPI_EMBED) {
@@ -315,7 +345,7 @@ __device__ __forceinline__ void nt_epilogue(f32x4 (&acc)[4][4], CT* __restrict__
       store4(C + crow * ldc + n, v, vec, nvalid);
     }
   }
-  if constexpr (EPI == MV_EPI_DGELU) {
+  if constexpr (epi_is_dgelu(EPI)) {
     if (ep.out2 && m0 + wm * 64 < M)
       nt_colsum_flush(cs, reinterpret_cast<float*>(ep.out2), ep.ld_out2, (m0 + wm * 64) >> 6, n0 + wn * 64 + 4 * (lane >> 4), N, lane);
   }
@@ -927,13 +957,35 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_8phase_kernel(const bf16_t* __
 #undef P8_READ_A
 #undef P8_READ_B
 #undef P8_STAGE
-  // full tile: wave (wm, wn) finishes rows 128 wm + 64 h (h = 0, 1); half item: its only quadrant-row, rows 64 wm
+  // full tile: wave (wm, wn) finishes rows 128 wm + 64 h (h = 0, 1); half item: its only quadrant-row, rows 64 wm.
+  // The epilogues that hoist a whole aux tile into registers (DGELU / MUL: 32, RESIDUAL: 64 VGPRs) cannot also hold both
+  // 64-register accumulator halves: the second half waits in LDS (free now: every wave has passed the final barrier
+  // after its last fragment read, and no DMA is outstanding) -- a 16 x ds_write_b128 / ds_read_b128 round trip per lane
+  // instead of 60-170 registers spilled to scratch memory.
+  constexpr bool park = epi_is_dgelu(EPI) || EPI == MV_EPI_RESIDUAL;
+  f32x4* const parked = reinterpret_cast<f32x4*>(smem) + wave * 16 * 64 + lane;
+  if (park && !is_half) {
 #pragma unroll
-  for (int h = 0; h < 2; ++h) {
-    if (h == 1 && is_half) break;
-    nt_epilogue<EPI, CT>(*reinterpret_cast<f32x4(*)[4][4]>(&acc[4 * h]), C, ldc, M, N, is_half ? m0 : m0 + 128 * wm,
-                         n0 + 128 * (wn >> 1), is_half ? wm : h, wn & 1, lane, ep);
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) parked[(i * 4 + j) * 64] = acc[4 + i][j];
   }
+  nt_epilogue<EPI, CT>(*reinterpret_cast<f32x4(*)[4][4]>(&acc[0]), C, ldc, M, N, is_half ? m0 : m0 + 128 * wm,
+                       n0 + 128 * (wn >> 1), is_half ? wm : 0, wn & 1, lane, ep);
+  if (is_half) return;
+  f32x4 acc2[4][4];
+  if (park) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) acc2[i][j] = parked[(i * 4 + j) * 64];
+  } else {
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) acc2[i][j] = acc[4 + i][j];
+  }
+  nt_epilogue<EPI, CT>(acc2, C, ldc, M, N, m0 + 128 * wm, n0 + 128 * (wn >> 1), 1, wn & 1, lane, ep);
 }
 
 __device__ __forceinline__ void tn_store(f32x4 (&acc)[4][4], float* __restrict__ Cs, long ldc, int M, int N, int m0, int n0,
@@ -1477,6 +1529,12 @@ extern "C" int mv_gemm_nt_bf16(const void* A, int lda, const void* B, int ldb, v
     case MV_EPI_DGELU:
       MV_REQUIRE(c_dtype == MV_BF16 && aux, MV_ERR_UNSUPPORTED);
       return launch_nt<MV_EPI_DGELU, bf16_t>(A, lda, B, ldb, C, ldc, M, N, K, ep, s);
+    case MV_EPI_GELU_GRAD:
+      MV_REQUIRE(c_dtype == MV_BF16, MV_ERR_UNSUPPORTED);
+      return launch_nt<MV_EPI_GELU_GRAD, bf16_t>(A, lda, B, ldb, C, ldc, M, N, K, ep, s);
+    case MV_EPI_MUL:
+      MV_REQUIRE(c_dtype == MV_BF16 && aux, MV_ERR_UNSUPPORTED);
+      return launch_nt<MV_EPI_MUL, bf16_t>(A, lda, B, ldb, C, ldc, M, N, K, ep, s);
     case MV_EPI_EMBED:
       MV_REQUIRE(c_dtype == MV_F32 && aux && aux_i > 0, MV_ERR_UNSUPPORTED);
       return launch_nt<MV_EPI_EMBED, float>(A, lda, B, ldb, C, ldc, M, N, K, ep, s);

@@ -18,7 +18,7 @@ import torch
 from torch.autograd import Function
 
 from . import ops
-from .ops import EPI_DGELU, EPI_EMBED, EPI_GELU, EPI_NONE, EPI_RESIDUAL
+from .ops import EPI_DGELU, EPI_EMBED, EPI_GELU, EPI_GELU_GRAD, EPI_MUL, EPI_NONE, EPI_RESIDUAL
 
 
 def _c(t):
@@ -435,9 +435,11 @@ class _MlpBlock(Function):
         x = _c(x)
         ctx.up_bias = _chain_take(x)
         y, mean, rstd = ops.layernorm_fwd(x, D, M, D, g, b, adt)
-        h = torch.empty(M, Hd, dtype=adt, device=x.device)     # pre-activation (kept for GELU')
+        # bf16: the fc1 epilogue leaves gelu'(pre-activation) for the backward pass (one multiply there instead of another
+        # erf evaluation per element); fp32 exact mode keeps the pre-activation itself
+        h = torch.empty(M, Hd, dtype=adt, device=x.device)
         a = torch.empty(M, Hd, dtype=adt, device=x.device)
-        ops.linear_fwd(y, M, D, w1, b1, a, Hd, epi=EPI_GELU, out2=h, ld_out2=Hd)
+        ops.linear_fwd(y, M, D, w1, b1, a, Hd, epi=EPI_GELU_GRAD if adt == torch.bfloat16 else EPI_GELU, out2=h, ld_out2=Hd)
         out = torch.empty_like(x)
         ops.linear_fwd(a, M, Hd, w2, b2, out, D, epi=EPI_RESIDUAL, aux=x, ld_aux=D)
         ctx.save_for_backward(x, g, mean, rstd, y, h, a, w1, w2)
@@ -463,7 +465,7 @@ class _MlpBlock(Function):
         if adt == torch.bfloat16:
             # (dY W2) * gelu'(h); the epilogue also leaves per-64-row column sums of dh = fc1's bias-gradient partials
             part = torch.empty((M + 63) // 64, Hd, dtype=torch.float32, device=x.device)
-            ops.linear_dx(d_act, M, D, w2, dh, Hd, epi=EPI_DGELU, aux=h, ld_aux=Hd, colsum_partial=part)
+            ops.linear_dx(d_act, M, D, w2, dh, Hd, epi=EPI_MUL, aux=h, ld_aux=Hd, colsum_partial=part)   # h = gelu' here
             db1 = ops.colsum(part, part.shape[0], Hd, Hd, ops.grad_out(b1, (Hd,), x.device))
             dw1, _ = ops.linear_dw(dh, y, M, Hd, D, want_bias=False, weight=w1)
         else:

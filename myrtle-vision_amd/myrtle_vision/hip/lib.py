@@ -13,7 +13,7 @@ import torch  # noqa: F401  -- FIRST: brings PyTorch-ROCm's HIP runtime into the
 from .build import LIB_PATH
 
 MV_F32, MV_BF16 = 0, 1
-EPI_NONE, EPI_GELU, EPI_RESIDUAL, EPI_DGELU, EPI_EMBED = 0, 1, 2, 3, 4
+EPI_NONE, EPI_GELU, EPI_RESIDUAL, EPI_DGELU, EPI_EMBED, EPI_GELU_GRAD, EPI_MUL = 0, 1, 2, 3, 4, 5, 6
 
 _P, _I, _L, _F, _Z = ctypes.c_void_p, ctypes.c_int, ctypes.c_long, ctypes.c_float, ctypes.c_size_t
 _KIND = {"p": _P, "i": _I, "l": _L, "f": _F, "z": _Z}

@@ -123,6 +123,18 @@ def test_gemm_nt_every_variant(ops, variant, M, N, K):
             dx = torch.empty(M, K, device="cuda", dtype=torch.bfloat16)
             ops.linear_dx(dy.cuda(), M, N, wp, dx, K, epi=ops.EPI_DGELU, aux=hh.cuda(), ld_aux=K)
             assert relerr(dx.float(), want) < 2.0 ** -8
+        # GELU_GRAD leaves gelu'(pre) for the backward pass; MUL consumes it (+ column-sum partials)
+        gd = torch.zeros(M, ldn, device="cuda", dtype=torch.bfloat16)
+        ops.linear_fwd(a.cuda(), M, K, wp, b.cuda(), act, ldn, epi=ops.EPI_GELU_GRAD, out2=gd, ld_out2=ldn)
+        assert relerr(act[:, :N].float(), gelu_erf(pre)) < 2.0 ** -8 and relerr(gd[:, :N].float(), dgelu64(pre)) < 2.0 ** -8
+        if N % 8 == 0:
+            dy, gg = bf(torch.randn(M, N, generator=g(5))), bf(torch.randn(M, K, generator=g(8)))
+            want = (dy.double() @ w.double()) * gg.double()
+            dx = torch.empty(M, K, device="cuda", dtype=torch.bfloat16)
+            part = torch.zeros((M + 63) // 64, K, device="cuda")
+            ops.linear_dx(dy.cuda(), M, N, wp, dx, K, epi=ops.EPI_MUL, aux=gg.cuda(), ld_aux=K, colsum_partial=part)
+            assert relerr(dx.float(), want) < 2.0 ** -8
+            assert relerr(part.sum(0), want.sum(0)) < 3e-3
         # a second launch is bit-identical (no race between DMA and fragment reads shows up as a flaky tile)
         out2 = torch.empty(M, N, device="cuda")
         for _ in range(3):

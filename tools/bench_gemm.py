@@ -34,6 +34,7 @@ def timeit_variants(fn, rounds=3, iters=8):
 
 rows = []
 for name, N, K, epi in [("qkv fwd", 2304, 768, "none"), ("proj fwd +res", 768, 768, "res"), ("fc1 fwd +gelu", 3072, 768, "gelu"),
+                        ("fc1 fwd +gelu+grad", 3072, 768, "gelugrad"),
                         ("fc2 fwd +res", 768, 3072, "res"), ("plain bf16 out N=3072", 3072, 768, "none"), ("plain K=3072", 768, 3072, "none")]:
     x, w, b = rnd(M, K), torch.randn(N, K, device=dev) * K ** -0.5, torch.randn(N, device=dev)
     if epi == "none":
@@ -44,15 +45,19 @@ for name, N, K, epi in [("qkv fwd", 2304, 768, "none"), ("proj fwd +res", 768, 7
         f = lambda: ops.linear_fwd(x, M, K, w, b, out, N, epi=ops.EPI_RESIDUAL, aux=res, ld_aux=N)
     else:
         out, h = torch.empty(M, N, device=dev, dtype=torch.bfloat16), torch.empty(M, N, device=dev, dtype=torch.bfloat16)
-        f = lambda: ops.linear_fwd(x, M, K, w, b, out, N, epi=ops.EPI_GELU, out2=h, ld_out2=N)
+        code = ops.EPI_GELU if epi == "gelu" else ops.EPI_GELU_GRAD
+        f = lambda: ops.linear_fwd(x, M, K, w, b, out, N, epi=code, out2=h, ld_out2=N)
     tv = timeit_variants(f); rows.append((f"NT {name}", [2.0 * M * N * K / tv[v] / 1e12 for v in VARIANTS], tv[VARIANTS[-1]] * 1e6))
-for name, N, K, epi in [("dX qkv (N=768,K=2304)", 2304, 768, "none"), ("dX fc2 +dgelu (->3072)", 768, 3072, "dgelu"), ("dX fc1 (K=3072)", 3072, 768, "none")]:
+for name, N, K, epi in [("dX qkv (N=768,K=2304)", 2304, 768, "none"), ("dX fc2 +dgelu (->3072)", 768, 3072, "dgelu"),
+                        ("dX fc2 +mul   (->3072)", 768, 3072, "mul"), ("dX fc1 (K=3072)", 3072, 768, "none")]:
     # linear_dx(dy[M,N], W[N,K]) -> [M,K]
     dy, w = rnd(M, N), torch.randn(N, K, device=dev) * K ** -0.5
     out = torch.empty(M, K, device=dev, dtype=torch.bfloat16)
-    if epi == "dgelu":
+    if epi in ("dgelu", "mul"):
         h = rnd(M, K)
-        f = lambda: ops.linear_dx(dy, M, N, w, out, K, epi=ops.EPI_DGELU, aux=h, ld_aux=K)
+        part = torch.empty((M + 63) // 64, K, device=dev)
+        code = ops.EPI_DGELU if epi == "dgelu" else ops.EPI_MUL
+        f = lambda: ops.linear_dx(dy, M, N, w, out, K, epi=code, aux=h, ld_aux=K, colsum_partial=part)
     else:
         f = lambda: ops.linear_dx(dy, M, N, w, out, K)
     tv = timeit_variants(f); rows.append((f"NT {name}", [2.0 * M * N * K / tv[v] / 1e12 for v in VARIANTS], tv[VARIANTS[-1]] * 1e6))
