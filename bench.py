@@ -9,7 +9,7 @@ One process per GPU.  A "step" = zero_grad + forward + cross-entropy + backward 
 RCCL/xGMI overlapped with backward when N > 1) + AdamW, on a synthetic batch that is already resident in HBM
 (per-GPU batch 256, weak scaling: global batch = 256 * N).  Rank 0 prints ONE JSON line.
 
-`roofline`: the dominant kernel is gemm_nt_kernel (mv_gemm_nt_bf16: every nn.Linear forward and input-gradient
+`roofline`: the dominant kernel family is gemm_nt_8phase_kernel (mv_gemm_nt_bf16: every nn.Linear forward and input-gradient
 product, 2/3 of all FLOPs).  achieved = sum of algorithmic FLOPs (2*M*N*K per launch) / sum of launch durations,
 measured with events recorded on the launch stream around every launch inside the timed region.
 `cpu_baseline`: the CPU oracle (oracle/vit_oracle.py, kind "port") timed on this host's cores, rank 0, N=1 only.
@@ -213,7 +213,7 @@ def main():
             summ = timer.summary()
             k = summ.get("gemm_nt_bf16")
             if k:
-                out["roofline"] = {"bound": "mfma", "kernel": "gemm_nt_kernel (mv_gemm_nt_bf16)",
+                out["roofline"] = {"bound": "mfma", "kernel": "gemm_nt_8phase_kernel family (mv_gemm_nt_bf16)",
                                    "achieved": round(k["tflops"], 1), "peak": BF16_DENSE_PEAK_TFLOPS, "unit": "TFLOP/s",
                                    "frac": round(k["tflops"] / BF16_DENSE_PEAK_TFLOPS, 4), "traffic": pmc_traffic("gemm_nt"),
                                    "launches": k["launches"], "avg_launch_us": round(k["avg_us"], 1),
