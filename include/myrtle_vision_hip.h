@@ -183,6 +183,23 @@ int mv_seg_ce_fwd(const float* small, const int64_t* labels, float* lse, uint8_t
 int mv_seg_ce_bwd(const float* small, const int64_t* labels, const float* lse, void* dsmall, int ds_dtype, int ld_ds,
                   float grad_scale, int B, int C, int h, int w, int H, int W, mv_stream_t stream);
 
+/* ---- image batch preparation: Normalize(ToTensor(hflip?(resize(crop(img, box), size, BILINEAR)))) ----
+ * replaces the per-image torchvision/Pillow pipeline of the DataLoader worker (datasets/resisc45.py:40-69,
+ * datasets/dlrsd.py:39-66, transforms/segmentation.py) on decoded uint8 frames, bit-exact to Pillow's 8-bit resampler.
+ * src: uint8 [B][Hs][Ws][3] (images img_stride bytes apart).  Per image and axis the host supplies Pillow's
+ * precompute_coeffs tables with crop offset / CenterCrop window folded in: bounds bh/bv int32 [B, out, 2] = (first
+ * source index, tap count <= ks) and 22-bit fixed-point coefficients kh/kv int32 [B, out, ks].  flip: uint8 [B].
+ * out: fp32 [B, 3, out_h, out_w] = ((pixel / 255) - mean[c]) / std[c]  (mean 0, std 1: plain ToTensor). */
+int mv_image_prepare(const uint8_t* src, long img_stride, int Hs, int Ws, const int32_t* kh, const int32_t* bh,
+                     const int32_t* kv, const int32_t* bv, int ks, const uint8_t* flip, float mean0, float mean1,
+                     float mean2, float std0, float std1, float std2, float* out, int B, int out_h, int out_w,
+                     mv_stream_t stream);
+/* segmentation masks: Image.resize(NEAREST) of the crop as a gather through per-axis source index tables yi [B, out_h],
+ * xi [B, out_w] (Pillow's ImagingScaleAffine indices, crop offset folded in); out int64 [B, out_h, out_w] = src + add
+ * (DLRSD labels are PNG value - 1, datasets/dlrsd.py:80). */
+int mv_mask_prepare(const uint8_t* src, long img_stride, int Hs, int Ws, const int32_t* yi, const int32_t* xi,
+                    const uint8_t* flip, int add, int64_t* out, int B, int out_h, int out_w, mv_stream_t stream);
+
 /* ---- optimizer: AdamW step (timm create_optimizer 'adamw' -> torch.optim.AdamW), classification/train.py:161-166,274-277 ----
  * flat fp32 arrays of n elements; decoupled weight decay; bias corrections passed in (host computes from step) */
 int mv_adamw(float* p, const float* g, float* m, float* v, long n, float lr, float beta1, float beta2, float eps,

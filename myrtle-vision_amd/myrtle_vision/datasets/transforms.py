@@ -50,9 +50,11 @@ class RandomResizedCrop:
     def __call__(self, img, mask=None):
         top, left, ch, cw = self._params(*img.size)
         box = (left, top, left + cw, top + ch)
-        img = img.resize(self.size, _BILINEAR, box=box)
+        # torchvision F.resized_crop: crop, THEN resize (the filter support clamps at the crop edge; PIL's resize(box=)
+        # would reach outside the box)
+        img = img.crop(box).resize(self.size, _BILINEAR)
         if mask is not None:
-            mask = mask.resize(self.size, _NEAREST, box=box)
+            mask = mask.crop(box).resize(self.size, _NEAREST)
         return img, mask
 
 

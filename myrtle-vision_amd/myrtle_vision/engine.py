@@ -59,9 +59,61 @@ def _datasets(task, data_config):
         collate = None
     else:
         from myrtle_vision.datasets.dlrsd import Dlrsd as DS, collate_both as collate
-    mk = lambda mode, files, ops_: DS(mode=mode, dataset_path=data_config["dataset_path"], imagepaths=data_config[files],
-                                      label_map_path=data_config["label_map"], transform_config=data_config[ops_])
+    mk = lambda mode, files, ops_, plan=None: DS(mode=mode, dataset_path=data_config["dataset_path"],
+                                                 imagepaths=data_config[files], label_map_path=data_config["label_map"],
+                                                 transform_config=data_config[ops_], device_plan=plan)
     return mk, collate
+
+
+def _device_plan(data_config, ops_, enabled=True):
+    """DevicePlan for a ``transform_ops_*`` section, or None (host transforms) when disabled or the chain is not one the
+    GPU path covers.  MYRTLE_VISION_DEVICE_TRANSFORMS=0 forces the host path."""
+    if not enabled or os.environ.get("MYRTLE_VISION_DEVICE_TRANSFORMS", "1") == "0":
+        return None
+    from myrtle_vision.datasets.device_transforms import DevicePlan
+    try:
+        return DevicePlan(data_config[ops_])
+    except ValueError:
+        return None
+
+
+def _workers():
+    """The reference uses one worker that also resizes/normalises; with those on the GPU the workers only decode, and
+    there may be as many as this process's CPU share allows (capped: a 1-GPU job owns 16 cores)."""
+    try:
+        n = len(os.sched_getaffinity(0))
+    except AttributeError:
+        n = os.cpu_count() or 2
+    return max(1, min(8, n - 2))
+
+
+class BatchFeed:
+    """DataLoader -> (images fp32 [B,3,H,W], labels) ON THE DEVICE, for either path: host transforms (tensors are copied
+    over) or a DevicePlan (uint8 frames + tables are copied over and mv_image_prepare / mv_mask_prepare finish the
+    job).  Same batches either way (tests/test_image_prep.py)."""
+
+    def __init__(self, dataset, plan, task, device, collate, **loader_kw):
+        from myrtle_vision.datasets.device_transforms import DevicePlan
+        self.plan, self.task, self.device = plan, task, device
+        if plan is not None:
+            loader_kw.setdefault("num_workers", _workers())
+            collate = DevicePlan.collate
+        else:
+            loader_kw.setdefault("num_workers", 1)                          # classification/train.py:117
+        self.loader = DataLoader(dataset, collate_fn=collate, pin_memory=True, **loader_kw)
+
+    def __len__(self):
+        return len(self.loader)
+
+    def __iter__(self):
+        for batch in self.loader:
+            if self.plan is None:
+                imgs, labels = batch
+                yield imgs.to(self.device, non_blocking=True), labels.to(self.device, non_blocking=True)
+            else:
+                packed, labels = batch
+                imgs, masks = self.plan.apply(packed, self.device, mask_add=-1 if self.task == "segmentation" else 0)
+                yield imgs, (masks if self.task == "segmentation" else labels.to(self.device, non_blocking=True))
 
 
 def _fused_seg_tail(task, criterion):
@@ -76,8 +128,7 @@ def validation(val_loader, device, criterion, vit, task, num_classes):
     total_loss, total_acc, n = 0.0, 0.0, max(len(val_loader), 1)
     miou = MIoU(num_classes, "cpu") if task == "segmentation" else None
     vit.eval()
-    for imgs, labels in val_loader:
-        imgs, labels = imgs.to(device), labels.to(device)
+    for imgs, labels in val_loader:                            # a BatchFeed: both already on the device
         if _fused_seg_tail(task, criterion):
             loss, acc, pred = vit.segmentation_loss(imgs, labels)        # no [B,C,H,W] logits
             total_loss += float(loss) / n
@@ -115,13 +166,15 @@ def train_worker(rank, num_gpus, config, task="classification"):
         print("output directory:", out_dir)
 
     mk, collate = _datasets(task, data_config)
-    trainset = mk("train", "train_files", "transform_ops_train")
-    valset = mk("eval", "valid_files", "transform_ops_val")
+    use_dev = train_config.get("device_transforms", True)
+    plan_t, plan_v = _device_plan(data_config, "transform_ops_train", use_dev), _device_plan(data_config, "transform_ops_val", use_dev)
+    trainset = mk("train", "train_files", "transform_ops_train", plan_t)
+    valset = mk("eval", "valid_files", "transform_ops_val", plan_v)
     sampler = ShardSampler(len(trainset), rank, world, seed=train_config["seed"]) if num_gpus > 1 else None
-    train_loader = DataLoader(trainset, num_workers=1, shuffle=(sampler is None), sampler=sampler, batch_size=batch_size,
-                              pin_memory=True, drop_last=train_config["drop_last_batch"], collate_fn=collate)
-    val_loader = DataLoader(valset, num_workers=1, batch_size=batch_size, pin_memory=True,
-                            drop_last=train_config["drop_last_batch"], collate_fn=collate)
+    train_loader = BatchFeed(trainset, plan_t, task, device, collate, shuffle=(sampler is None), sampler=sampler,
+                             batch_size=batch_size, drop_last=train_config["drop_last_batch"])
+    val_loader = BatchFeed(valset, plan_v, task, device, collate, batch_size=batch_size,
+                           drop_last=train_config["drop_last_batch"])
 
     vit, _ = get_models(config)
     backbone = train_config.get("pretrained_backbone")
@@ -165,7 +218,6 @@ def train_worker(rank, num_gpus, config, task="classification"):
                 last_val = validation(val_loader, device, criterion, vit, task, num_classes)
             if n_accum == 0:
                 optimizer.zero_grad()
-            imgs, labels = imgs.to(device, non_blocking=True), labels.to(device, non_blocking=True)
             reducer.enabled = reducer.world > 1 and (n_accum == n_batch_accum - 1)
             if _fused_seg_tail(task, criterion):
                 loss, acc_t, _ = vit.segmentation_loss(imgs, labels)
@@ -233,24 +285,26 @@ def evaluate(config, task, quantize=False, calib_steps=0, quantized_ckpt=False):
     vit = vit.to("cuda")
     load_checkpoint(model=vit, optimizer=None, lr_scheduler=None, filepath=train_config["checkpoint_path"])
     mk, collate = _datasets(task, data_config)
+    dev = torch.device("cuda")
+    plan = _device_plan(data_config, "transform_ops_val", train_config.get("device_transforms", True))
     if quantize:
         if not quantized_ckpt:
             vit.quantizer.prepare_qat(q_format)
-        calib = DataLoader(mk("eval", "valid_files", "transform_ops_val"), batch_size=train_config["local_batch_size"],
-                           collate_fn=collate)
+        calib = BatchFeed(mk("eval", "valid_files", "transform_ops_val", plan), plan, task, dev, collate,
+                          batch_size=train_config["local_batch_size"])
         vit.train()
         for step, (imgs, _) in enumerate(calib):                           # test_quantize.py:26-34
             if step >= calib_steps:
                 break
-            vit(imgs.to("cuda"))
+            vit(imgs)
         vit.convert()
-    testset = mk("eval" if task == "classification" else "test", "test_files", "transform_ops_val")
-    loader = DataLoader(testset, batch_size=train_config["local_batch_size"], collate_fn=collate)
+    testset = mk("eval" if task == "classification" else "test", "test_files", "transform_ops_val", plan)
+    loader = BatchFeed(testset, plan, task, dev, collate, batch_size=train_config["local_batch_size"])
     vit.eval()
     preds, gts = [], []
     miou = MIoU(data_config["number_of_classes"], "cpu") if task == "segmentation" else None
     for imgs, labels in loader:
-        out = vit(imgs.to("cuda")).argmax(dim=1).cpu()
+        out, labels = vit(imgs).argmax(dim=1).cpu(), labels.cpu()
         preds.append(out.reshape(-1))
         gts.append(labels.reshape(-1))
         if miou is not None:

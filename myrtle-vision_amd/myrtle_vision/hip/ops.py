@@ -520,6 +520,29 @@ def seg_ce_bwd(small, labels, lse, B, C, h, w, H, W, *, grad_dtype=torch.float32
     return ds
 
 
+def image_prepare(raw, kh, bh, kv, bv, flip, mean, std):
+    """uint8 [B, Hs, Ws, 3] + Pillow resampling tables -> fp32 [B, 3, oh, ow] (crop/resize/flip/ToTensor/Normalize)."""
+    require_cuda(raw, kh, bh, kv, bv, flip)
+    B, Hs, Ws, _ = raw.shape
+    oh, ow, ks = kv.shape[1], kh.shape[1], kh.shape[2]
+    out = torch.empty(B, 3, oh, ow, dtype=torch.float32, device=raw.device)
+    check(lib().mv_image_prepare(_p(raw), Hs * Ws * 3, Hs, Ws, _p(kh), _p(bh), _p(kv), _p(bv), ks, _p(flip),
+                                 mean[0], mean[1], mean[2], std[0], std[1], std[2], _p(out), B, oh, ow, _s()),
+          "image_prepare", B=B, Hs=Hs, Ws=Ws, oh=oh, ow=ow, ks=ks)
+    return out
+
+
+def mask_prepare(mask, yi, xi, flip, add=0):
+    """uint8 [B, Hs, Ws] + NEAREST index tables -> int64 [B, oh, ow] (+ add)."""
+    require_cuda(mask, yi, xi, flip)
+    B, Hs, Ws = mask.shape
+    oh, ow = yi.shape[1], xi.shape[1]
+    out = torch.empty(B, oh, ow, dtype=torch.int64, device=mask.device)
+    check(lib().mv_mask_prepare(_p(mask), Hs * Ws, Hs, Ws, _p(yi), _p(xi), _p(flip), add, _p(out), B, oh, ow, _s()),
+          "mask_prepare", B=B, Hs=Hs, Ws=Ws, oh=oh, ow=ow)
+    return out
+
+
 def adamw_step(p, g, m, v, *, lr, beta1, beta2, eps, weight_decay, step, grad_scale=1.0):
     """In-place AdamW on flat fp32 tensors (torch.optim.AdamW semantics)."""
     require_cuda(p, g, m, v)
