@@ -108,3 +108,65 @@ def test_gradients_land_in_their_arena_slots(decoder, precision, size):
         p = arena.params[j]
         assert p.grad.data_ptr() == arena.slot(j).data_ptr(), n
         assert torch.allclose(p.grad, 2 * want[n], rtol=1e-6, atol=1e-30), n
+
+
+def _ddp_rank(rank, world, port, tmpdir):
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)          # both ranks share GPU 0; the exchange is the point
+    torch.cuda.set_device(0)
+    from myrtle_vision.hip.functional import cross_entropy
+    from myrtle_vision.models.vit import ViT
+    from myrtle_vision.utils.ddp import GradAllReducer, broadcast_parameters
+    from myrtle_vision.utils.optim import AdamW, ParamArena
+    from myrtle_vision.utils.utils import seed_everything
+    seed_everything(100 + rank)                                             # different initial weights: the broadcast must fix it
+    vit = ViT(precision="bf16", q_format="FP32", decoder="classification", image_size=224, patch_size=16, num_classes=10,
+              dim=128, depth=2, heads=2, mlp_dim=256, dropout=0.0, emb_dropout=0.0).cuda()
+    arena = ParamArena(vit.named_parameters(), skip=vit.unused_parameter_names())
+    opt = AdamW(arena, lr=1e-3, weight_decay=0.05)
+    red = GradAllReducer(arena, bucket_bytes=256 << 10)                     # several buckets
+    assert len(red.ranges) > 2
+    broadcast_parameters(arena)
+    opt.grad_scale = red.grad_scale
+    g = torch.Generator().manual_seed(5)
+    X, Y = torch.randn(8, 3, 224, 224, generator=g), torch.randint(0, 10, (8,), generator=g)
+    x, y = X[rank::world].cuda(), Y[rank::world].cuda()                     # DistributedSampler-style shard
+    for step in range(3):
+        opt.zero_grad()
+        cross_entropy(vit(x), y).backward()
+        red.finish()
+        if step == 0:
+            torch.save({"grad": (arena.flat_grad * red.grad_scale).cpu(), "param": arena.flat_param.cpu()},
+                       os.path.join(tmpdir, f"r{rank}.pt"))
+        opt.step()
+    torch.save(arena.flat_param.cpu(), os.path.join(tmpdir, f"final{rank}.pt"))
+    dist.destroy_process_group()
+
+
+def test_ddp_two_ranks_match_single_process(tmp_path):
+    """SURVEY 8e parity check on the HIP path: all-reduced gradients of a rank-sharded batch == the single-process gradient
+    of the concatenated batch (mean loss), and the ranks hold identical parameters after K optimizer steps."""
+    import torch.multiprocessing as mp
+    from myrtle_vision.hip.functional import cross_entropy
+    from myrtle_vision.models.vit import ViT
+    from myrtle_vision.utils.optim import ParamArena
+    from myrtle_vision.utils.utils import seed_everything
+    port = 29700 + (os.getpid() % 200)
+    mp.spawn(_ddp_rank, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    r0, r1 = torch.load(tmp_path / "r0.pt"), torch.load(tmp_path / "r1.pt")
+    assert torch.equal(r0["param"], r1["param"]) and torch.equal(r0["grad"], r1["grad"])
+    seed_everything(100)                                                    # rank 0's initial weights
+    vit = ViT(precision="bf16", q_format="FP32", decoder="classification", image_size=224, patch_size=16, num_classes=10,
+              dim=128, depth=2, heads=2, mlp_dim=256, dropout=0.0, emb_dropout=0.0).cuda()
+    arena = ParamArena(vit.named_parameters(), skip=vit.unused_parameter_names())
+    assert torch.equal(arena.flat_param.cpu(), r0["param"])
+    g = torch.Generator().manual_seed(5)
+    X, Y = torch.randn(8, 3, 224, 224, generator=g), torch.randint(0, 10, (8,), generator=g)
+    cross_entropy(vit(X.cuda()), Y.cuda()).backward()
+    arena.sync_grads()
+    want, got = arena.flat_grad.cpu(), r0["grad"]
+    # bf16 activations: the two shards round differently from the concatenated batch; compare at bf16 resolution
+    assert float((want - got).norm() / want.norm()) < 2e-2
+    f0, f1 = torch.load(tmp_path / "final0.pt"), torch.load(tmp_path / "final1.pt")
+    assert torch.equal(f0, f1)
