@@ -106,9 +106,11 @@ int mv_gemm_f32(const float* A, long sa_m, long sa_k, long sa_b1, long sa_b2, co
  * out: bf16 [B, N, H*64] = (softmax(q k^T * scale) v).transpose(1,2).reshape(B,N,C);  lse: fp32 [B,H,N].
  * dim_head must be 64 (all shipped configs; ViT default dim_head=64, vit.py:178); N <= 320. */
 int mv_attention_fwd(const void* qkv, void* out, float* lse, int B, int N, int H, float scale, mv_stream_t stream);
-/* dqkv: bf16 [B, N, 3, H, 64]; dout/out: bf16 [B, N, H*64] */
-int mv_attention_bwd(const void* qkv, const void* out, const void* dout, const float* lse, void* dqkv, int B, int N,
-                     int H, float scale, mv_stream_t stream);
+/* dqkv: bf16 [B, N, 3, H, 64]; dout/out: bf16 [B, N, H*64].  colsum (optional): fp32 [B, 3*H*64], row b = column sums
+ * of image b's dqkv rows (fp32 accumulators, before the bf16 rounding) -- summed over b they are to_qkv's bias gradient,
+ * so no separate pass over dqkv is needed for it. */
+int mv_attention_bwd(const void* qkv, const void* out, const void* dout, const float* lse, void* dqkv, float* colsum,
+                     int B, int N, int H, float scale, mv_stream_t stream);
 
 /* ---- row softmax for the materialised attention path (fp32): attn.softmax(dim=-1) vit.py:93 ---- */
 int mv_softmax_fwd(const float* x, float* y, long rows, int cols, float scale, mv_stream_t stream);

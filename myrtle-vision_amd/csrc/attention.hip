@@ -181,13 +181,39 @@ __global__ __launch_bounds__(256, (NKT <= 14 ? 2 : 1)) void attn_fwd_kernel(cons
   }
 }
 
+// Column sums of dQ / dK / dV of one (image, head) = that head's slice of the to_qkv bias gradient for this image: the
+// wave-local sums (16 lanes with equal lane>>4 hold the 16 rows of a tile) go through LDS, and 192 threads write
+// colsum[b][which][h][d].  Deterministic: fixed shuffle tree, waves added in order.  Padded rows contribute exact zeros
+// (their p is 0), so nothing is masked here.  red: LDS, NW * 192 floats, free at this point.
+template <int NW>
+__device__ __forceinline__ void attn_colsum_zero(float* red, int tid, int nthreads) {
+  for (int i = tid; i < NW * 192; i += nthreads) red[i] = 0.f;
+}
+__device__ __forceinline__ float rowsum16(float v) {
+  v += __shfl_xor(v, 1, 64);
+  v += __shfl_xor(v, 2, 64);
+  v += __shfl_xor(v, 4, 64);
+  v += __shfl_xor(v, 8, 64);
+  return v;
+}
+template <int NW>
+__device__ __forceinline__ void attn_colsum_store(const float* red, float* __restrict__ gout, long D, int tid) {
+  if (tid < 192) {
+    float t = 0.f;
+#pragma unroll
+    for (int w = 0; w < NW; ++w) t += red[w * 192 + tid];
+    gout[(long)(tid >> 6) * D + (tid & 63)] = t;          // which = tid / 64, d = tid % 64
+  }
+}
+
 // ------------------------------------------------------------------------------------------------
 // backward: one 512-thread workgroup per (image, head); wave w owns key tiles w, w+8, (w+16)
 // ------------------------------------------------------------------------------------------------
 template <int NKT, int KPW>  // NKT 16-key tiles (even), KPW key tiles per wave
 __global__ __launch_bounds__(512, 1) void attn_bwd_kernel(const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ out,
                                                           const bf16_t* __restrict__ dout, const float* __restrict__ lse,
-                                                          bf16_t* __restrict__ dqkv, int N, int H, float scale) {
+                                                          bf16_t* __restrict__ dqkv, float* __restrict__ colsum, int N, int H,
+                                                          float scale) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr int NP = NKT * 16;
   char* sK = smem;                         // [NP][64] bf16, sw128
@@ -251,6 +277,7 @@ __global__ __launch_bounds__(512, 1) void attn_bwd_kernel(const bf16_t* __restri
     }
 
   constexpr int NQP = NKT / 2;
+  f32x4 dqs = {0.f, 0.f, 0.f, 0.f};                      // running column sums of this wave's dQ tile (over query pairs)
   store_pair(0, load_pair(0));
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // this wave's K/V DMA pieces have landed
   __syncthreads();
@@ -324,6 +351,7 @@ __global__ __launch_bounds__(512, 1) void attn_bwd_kernel(const bf16_t* __restri
       }
       const int q = 32 * u + 16 * t + (lane & 15);
       if (q < N) *reinterpret_cast<bf16x4*>(dbase + (long)q * 3 * D + dt * 16 + 4 * g) = pack4(dq);
+      dqs += dq;
     }
   }
 
@@ -339,6 +367,37 @@ __global__ __launch_bounds__(512, 1) void attn_bwd_kernel(const bf16_t* __restri
       }
     }
   }
+  if (colsum) {                                          // to_qkv bias-gradient partials of this (image, head)
+    float* red = reinterpret_cast<float*>(sDS);
+    __syncthreads();
+    attn_colsum_zero<8>(red, tid, 512);
+    __syncthreads();
+    const int dtq = wave & 3;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const float v = rowsum16(dqs[r]);
+      if ((lane & 15) == 0) red[wave * 192 + dtq * 16 + 4 * g + r] = v;
+    }
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        float vk = 0.f, vv = 0.f;
+#pragma unroll
+        for (int i = 0; i < KPW; ++i) {
+          vk += adk[i][dt][r];
+          vv += adv[i][dt][r];
+        }
+        vk = rowsum16(vk);
+        vv = rowsum16(vv);
+        if ((lane & 15) == 0) {
+          red[wave * 192 + 64 + dt * 16 + 4 * g + r] = vk;
+          red[wave * 192 + 128 + dt * 16 + 4 * g + r] = vv;
+        }
+      }
+    __syncthreads();
+    attn_colsum_store<8>(red, colsum + (long)b * 3 * D + h * 64, D, tid);
+  }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -350,7 +409,8 @@ __global__ __launch_bounds__(512, 1) void attn_bwd_kernel(const bf16_t* __restri
 // trimmed to the 13 real key tiles -> 79,616 B.  Wave w owns key tiles w, w+4, w+8, w+12 (128 accumulator VGPRs).
 __global__ __launch_bounds__(256, 2) void attn_bwd4_kernel(const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ out,
                                                            const bf16_t* __restrict__ dout, const float* __restrict__ lse,
-                                                           bf16_t* __restrict__ dqkv, int N, int H, float scale) {
+                                                           bf16_t* __restrict__ dqkv, float* __restrict__ colsum, int N, int H,
+                                                           float scale) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr int NKT = 13, NPK = 224, NPV = 208, NQP = 7, KPW = 4;
   char* sK = smem;                           // [224][64] bf16 (rows >= N zero; rows 208..223 exist for the key-pair reads)
@@ -426,6 +486,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd4_kernel(const bf16_t* __restr
   const char* sQ = sPair;
   const char* sDO = sPair + 4096;
   const int nkt_valid = (N + 15) >> 4;
+  f32x4 dqs0 = {0.f, 0.f, 0.f, 0.f}, dqs1 = {0.f, 0.f, 0.f, 0.f};   // running column sums of this wave's two dQ tiles
   for (int u = 0; u < NQP; ++u) {
     u32x4 nx0 = zero4, nx1 = zero4;
     if (u + 1 < NQP && !(MV_ATTN_ABLATE & 4)) {
@@ -509,6 +570,8 @@ __global__ __launch_bounds__(256, 2) void attn_bwd4_kernel(const bf16_t* __restr
         *reinterpret_cast<bf16x4*>(dst) = pack4(dq0);
         *reinterpret_cast<bf16x4*>(dst + 16) = pack4(dq1);
       }
+      dqs0 += dq0;
+      dqs1 += dq1;
     }
     __syncthreads();                                   // dS^T reads done; next Q/dO pair visible
   }
@@ -524,6 +587,39 @@ __global__ __launch_bounds__(256, 2) void attn_bwd4_kernel(const bf16_t* __restr
         *reinterpret_cast<bf16x4*>(dbase + (long)key * 3 * D + 2 * D + dt * 16 + 4 * g) = pack4(adv[i][dt]);
       }
     }
+  }
+  if (colsum) {                                          // to_qkv bias-gradient partials of this (image, head)
+    float* red = reinterpret_cast<float*>(sDS);          // the loop's last barrier freed dS^T
+    attn_colsum_zero<4>(red, tid, 256);
+    __syncthreads();
+    const int dq_d0 = 32 * (wave & 1);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const float v0 = rowsum16(dqs0[r]), v1 = rowsum16(dqs1[r]);
+      if ((lane & 15) == 0) {
+        red[wave * 192 + dq_d0 + 4 * g + r] = v0;
+        red[wave * 192 + dq_d0 + 16 + 4 * g + r] = v1;
+      }
+    }
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        float vk = 0.f, vv = 0.f;
+#pragma unroll
+        for (int i = 0; i < KPW; ++i) {
+          vk += adk[i][dt][r];
+          vv += adv[i][dt][r];
+        }
+        vk = rowsum16(vk);
+        vv = rowsum16(vv);
+        if ((lane & 15) == 0) {
+          red[wave * 192 + 64 + dt * 16 + 4 * g + r] = vk;
+          red[wave * 192 + 128 + dt * 16 + 4 * g + r] = vv;
+        }
+      }
+    __syncthreads();
+    attn_colsum_store<4>(red, colsum + (long)b * 3 * D + h * 64, D, tid);
   }
 }
 
@@ -560,8 +656,8 @@ extern "C" int mv_attention_fwd(const void* qkv, void* out, float* lse, int B, i
   return MV_OK;
 }
 
-extern "C" int mv_attention_bwd(const void* qkv, const void* out, const void* dout, const float* lse, void* dqkv, int B,
-                                int N, int H, float scale, mv_stream_t stream) {
+extern "C" int mv_attention_bwd(const void* qkv, const void* out, const void* dout, const float* lse, void* dqkv,
+                                float* colsum, int B, int N, int H, float scale, mv_stream_t stream) {
   MV_REQUIRE(B >= 0 && N > 0 && H > 0 && N <= 320, MV_ERR_SHAPE);
   MV_REQUIRE(mv_aligned16(qkv) && mv_aligned16(out) && mv_aligned16(dout) && mv_aligned16(dqkv), MV_ERR_ALIGN);
   if (B == 0) return MV_OK;
@@ -572,17 +668,17 @@ extern "C" int mv_attention_bwd(const void* qkv, const void* out, const void* do
     static const int a = set_smem(attn_bwd4_kernel, smem4);
     if (a) return MV_ERR_LAUNCH;
     attn_bwd4_kernel<<<B * H, 256, smem4, s>>>((const bf16_t*)qkv, (const bf16_t*)out, (const bf16_t*)dout, lse,
-                                              (bf16_t*)dqkv, N, H, scale);
+                                              (bf16_t*)dqkv, colsum, N, H, scale);
   } else if (N <= 224) {
     static const int a = set_smem(attn_bwd_kernel<14, 2>, bwd_smem(14));
     if (a) return MV_ERR_LAUNCH;
     attn_bwd_kernel<14, 2><<<B * H, 512, bwd_smem(14), s>>>((const bf16_t*)qkv, (const bf16_t*)out, (const bf16_t*)dout,
-                                                          lse, (bf16_t*)dqkv, N, H, scale);
+                                                          lse, (bf16_t*)dqkv, colsum, N, H, scale);
   } else {
     static const int a = set_smem(attn_bwd_kernel<20, 3>, bwd_smem(20));
     if (a) return MV_ERR_LAUNCH;
     attn_bwd_kernel<20, 3><<<B * H, 512, bwd_smem(20), s>>>((const bf16_t*)qkv, (const bf16_t*)out, (const bf16_t*)dout,
-                                                          lse, (bf16_t*)dqkv, N, H, scale);
+                                                          lse, (bf16_t*)dqkv, colsum, N, H, scale);
   }
   MV_CHECK_LAUNCH();
   return MV_OK;

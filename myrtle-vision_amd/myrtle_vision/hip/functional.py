@@ -407,12 +407,17 @@ class _AttnBlock(Function):
         dbo = dbo if dbo is not None else dbo2
         do = torch.empty(B, T, inner, dtype=adt, device=x.device)
         ops.linear_dx(d_act, M, D, wo, do, inner)
+        dbqkv = None
         if fused:
-            dqkv = ops.attention_bwd(qkv, o, do, lse_or_probs, B, T, heads, scale)
+            # the kernel also leaves per-image column sums of dqkv: to_qkv's bias gradient without another pass over dqkv
+            part = torch.empty(B, inner3, dtype=torch.float32, device=x.device)
+            dqkv = ops.attention_bwd(qkv, o, do, lse_or_probs, B, T, heads, scale, colsum=part)
+            dbqkv = ops.colsum(part, B, inner3, inner3, ops.grad_out(bqkv, (inner3,), x.device))
         else:
             dqkv = ops.cast(ops.attention_bwd_fp32(lse_or_probs, ops.cast(qkv, torch.float32), ops.cast(do, torch.float32),
                                                    B, T, heads, inner // heads, scale), adt)
-        dwqkv, dbqkv = ops.linear_dw(dqkv.view(M, inner3), y, M, inner3, D, weight=wqkv, bias=bqkv)
+        dwqkv, dbq2 = ops.linear_dw(dqkv.view(M, inner3), y, M, inner3, D, want_bias=dbqkv is None, weight=wqkv, bias=bqkv)
+        dbqkv = dbqkv if dbqkv is not None else dbq2
         dy = torch.empty(M, D, dtype=adt, device=x.device)
         ops.linear_dx(dqkv.view(M, inner3), M, inner3, wqkv, dy, D)
         dx, dg, db = _ln_bwd_with_side(dy, x, D, g, b, mean, rstd, dout, M, adt, ctx.up_bias)   # + residual gradient

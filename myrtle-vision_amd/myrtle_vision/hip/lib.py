@@ -30,7 +30,7 @@ SIGNATURES = {
     "mv_gemm_tn_bf16": ("pipipi" "iii" "i" "p" "pz" "p", _I),
     "mv_gemm_f32": ("pllll" "pllll" "pllll" "iii" "ii" "fi" "pi" "pli" "pl" "p", _I),
     "mv_attention_fwd": ("ppp" "iii" "f" "p", _I),
-    "mv_attention_bwd": ("ppppp" "iii" "f" "p", _I),
+    "mv_attention_bwd": ("pppppp" "iii" "f" "p", _I),
     "mv_softmax_fwd": ("pp" "li" "f" "p", _I),
     "mv_softmax_bwd": ("ppp" "li" "f" "p", _I),
     "mv_patchify": ("ppi" "iiiii" "p", _I),

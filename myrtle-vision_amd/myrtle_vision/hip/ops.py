@@ -290,10 +290,11 @@ def attention_fwd(qkv, B, N, H, scale):
     return out, lse
 
 
-def attention_bwd(qkv, out, dout, lse, B, N, H, scale):
+def attention_bwd(qkv, out, dout, lse, B, N, H, scale, colsum=None):
+    """-> dqkv.  ``colsum`` (optional fp32 [B, 3*H*64]) receives per-image column sums of dqkv (bias-gradient partials)."""
     dqkv = torch.empty_like(qkv)
-    check(lib().mv_attention_bwd(_p(qkv), _p(out), _p(dout), _p(lse), _p(dqkv), B, N, H, scale, _s()), "attention_bwd",
-          B=B, N=N, H=H)
+    check(lib().mv_attention_bwd(_p(qkv), _p(out), _p(dout), _p(lse), _p(dqkv), _p(colsum), B, N, H, scale, _s()),
+          "attention_bwd", B=B, N=N, H=H)
     return dqkv
 
 

@@ -305,10 +305,17 @@ def test_attention_fused_fwd_bwd(ops, B, N, H):
     q, k, _ = qkv.double().view(B, N, 3, H, 64).permute(2, 0, 3, 1, 4)
     lse_ref = torch.logsumexp((q @ k.transpose(-2, -1)) * scale, dim=-1)
     assert float((lse.cpu().double() - lse_ref).abs().max()) < 1e-4
-    dqkv = ops.attention_bwd(qkv.cuda(), out, dout.cuda(), lse, B, N, H, scale)
+    part = torch.full((B, 3 * H * 64), float("nan"), device="cuda")
+    dqkv = ops.attention_bwd(qkv.cuda(), out, dout.cuda(), lse, B, N, H, scale, colsum=part)
     got, ref = dqkv.float().cpu().view(B, N, 3, H, 64), ref_in.grad.view(B, N, 3, H, 64)
     for i, name in enumerate("qkv"):
         assert relerr(got[:, :, i], ref[:, :, i]) < 3e-2, name
+    # fused per-image column sums (to_qkv bias-gradient partials): the sums of what the kernel wrote, before bf16 rounding
+    sums = dqkv.float().sum(1).cpu()                                      # [B, 3*H*64] from the rounded outputs
+    assert relerr(part.cpu(), sums) < 5e-3
+    assert relerr(part.cpu().double(), ref_in.grad.sum(1)) < 3e-2
+    dq2 = ops.attention_bwd(qkv.cuda(), out, dout.cuda(), lse, B, N, H, scale)           # colsum is optional
+    assert torch.equal(dq2, dqkv)
 
 
 @pytest.mark.parametrize("B,N,H,dh", [(2, 197, 3, 64), (1, 40, 2, 32)])
