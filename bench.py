@@ -202,7 +202,9 @@ def main():
             "metric": METRIC[args.workload],
             "value": round(img_s, 2), "unit": "images/sec", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(1e3 * elapsed / args.steps, 3), "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": args.precision, "data": "synthetic",
+            "vs_baseline": None,
+            "dtype": "int8 codes on bf16 MFMA, fp32 accumulate" if args.workload == "infer-int8" else args.precision,
+            "data": "synthetic",
             "config": {"workload": WORKLOAD[args.workload] + ("" if not args.no_optimizer else " [optimizer step OFF]"),
                        "per_gpu_batch": args.batch, "global_batch": args.batch * world,
                        "parallelism": f"dp{world}", "final_loss": round(final_loss, 4)},

@@ -87,6 +87,11 @@ int mv_layernorm_bwd(const void* dy, int dy_dtype, const float* x, long ldx, con
 int mv_gemm_nt_bf16(const void* A, int lda, const void* B, int ldb, void* C, int ldc, int c_dtype, int M, int N,
                     int K, const float* bias, int epilogue, const void* aux, int ld_aux, int aux_i, void* out2,
                     int ld_out2, mv_stream_t stream);
+/* the same with C = alpha * (A . B^T) (+ bias, epilogue): the integer-code products of the converted int8 path
+ * (mv_quant_affine_codes), where alpha = scale_activation * scale_weight. */
+int mv_gemm_nt_bf16_scaled(const void* A, int lda, const void* B, int ldb, void* C, int ldc, int c_dtype, int M, int N,
+                           int K, float alpha, const float* bias, int epilogue, const void* aux, int ld_aux, int aux_i,
+                           void* out2, int ld_out2, mv_stream_t stream);
 /* weight gradient  dW[M,N] (fp32) (+)= A[Kc,M]^T . B[Kc,N]  (A = dY, B = X; contraction over tokens) --
  * autograd's mm(dY^T, X) for every nn.Linear above.  Split over Kc into fp32 slabs in `workspace`,
  * reduced deterministically.  colsum (optional, fp32 [M]) (+)= column sums of A = bias gradient. */
@@ -148,6 +153,11 @@ int mv_quant_fixed(const float* x, float* y, long n, int wl, int fl, int clamp, 
 /* per-tensor affine fake-quant (MinMaxObserver qparams, utils/quantize.py:242-249) */
 int mv_quant_affine(const float* x, float* y, long n, float scale, int zero_point, int qmin, int qmax,
                     mv_stream_t stream);
+/* integer codes of the affine quantiser, re-centred: codes[r, c] = clamp(rint(x / scale) + zp, qmin, qmax) - zp as bf16
+ * (exact: |code| <= 256), rows ld elements apart with zeroed padding -- an MFMA operand whose products with another
+ * code tensor, accumulated in fp32, are the exact integer dot products of real int8 inference. */
+int mv_quant_affine_codes(const float* x, void* codes, long rows, int cols, int ld, float scale, int zero_point, int qmin,
+                          int qmax, mv_stream_t stream);
 /* running min/max observer: minmax[0] = min(minmax[0], min x), minmax[1] = max(minmax[1], max x);
  * minmax points at FOUR floats: [2..3] are scratch for the reduction */
 int mv_minmax(const float* x, long n, float* minmax, mv_stream_t stream);

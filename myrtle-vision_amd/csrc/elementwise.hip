@@ -224,6 +224,26 @@ __global__ void quant_affine_kernel(const float* __restrict__ x, float* __restri
   }
 }
 
+// Integer CODES of the same quantiser, re-centred: c = clamp(rint(x / scale) + zp, qmin, qmax) - zp, an integer in
+// [qmin - zp, qmax - zp] (|c| <= 255 for 8-bit), written as bf16 -- exactly representable, so a bf16 MFMA GEMM of two
+// code tensors with fp32 accumulation IS the integer dot product (mv_gemm_nt_bf16_scaled applies scale_x * scale_w).
+// Rows are written with leading dimension ld (>= cols, padding zeroed) so the result is a valid MFMA operand.
+__global__ void quant_affine_codes_kernel(const float* __restrict__ x, bf16_t* __restrict__ y, long rows, int cols, int ld,
+                                          float inv, int zp, int qmin, int qmax) {
+  const long n = rows * ld;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+    const long r = i / ld;
+    const int c = (int)(i - r * ld);
+    float v = 0.f;
+    if (c < cols) {
+      float q = rintf(x[r * cols + c] * inv) + (float)zp;
+      q = fminf(fmaxf(q, (float)qmin), (float)qmax);
+      v = q - (float)zp;
+    }
+    y[i] = (bf16_t)v;
+  }
+}
+
 // order-preserving float <-> uint map so min/max can use integer atomics
 __device__ __forceinline__ unsigned f2ord(float f) {
   const unsigned u = __float_as_uint(f);
@@ -619,6 +639,17 @@ extern "C" int mv_quant_affine(const float* x, float* y, long n, float scale, in
   MV_REQUIRE(n >= 0 && scale > 0.f && qmin < qmax, MV_ERR_SHAPE);
   if (n == 0) return MV_OK;
   quant_affine_kernel<<<ew_grid(n), 256, 0, S_>>>(x, y, n, scale, 1.0f / scale, zero_point, qmin, qmax);
+  MV_CHECK_LAUNCH();
+  return MV_OK;
+}
+
+extern "C" int mv_quant_affine_codes(const float* x, void* codes, long rows, int cols, int ld, float scale, int zero_point,
+                                     int qmin, int qmax, mv_stream_t stream) {
+  MV_REQUIRE(rows >= 0 && cols > 0 && ld >= cols && scale > 0.f && qmin < qmax, MV_ERR_SHAPE);
+  MV_REQUIRE(qmax - zero_point <= 256 && zero_point - qmin <= 256, MV_ERR_UNSUPPORTED);     // exact in bf16
+  if (rows == 0) return MV_OK;
+  quant_affine_codes_kernel<<<ew_grid(rows * ld), 256, 0, S_>>>(x, (bf16_t*)codes, rows, cols, ld, 1.0f / scale, zero_point,
+                                                                qmin, qmax);
   MV_CHECK_LAUNCH();
   return MV_OK;
 }

@@ -54,6 +54,7 @@ __device__ __forceinline__ int xcd_remap(int bid, int nwg) {
 }
 
 struct EpiArgs {
+  float alpha;          // C = alpha * acc (+ bias ...): 1 except for the integer-code GEMMs of the int8 path
   const float* bias;
   const void* aux;
   int ld_aux;
@@ -222,8 +223,8 @@ __device__ __forceinline__ void nt_epilogue(f32x4 (&acc)[4][4], CT* __restrict__
 #pragma unroll
             for (int q = 0; q < 2; ++q) {
               const int j = 2 * jp + q;
-              v[q][0] = acc[i][j][0] + bv[j].x; v[q][1] = acc[i][j][1] + bv[j].y;
-              v[q][2] = acc[i][j][2] + bv[j].z; v[q][3] = acc[i][j][3] + bv[j].w;
+              v[q][0] = fmaf(acc[i][j][0], ep.alpha, bv[j].x); v[q][1] = fmaf(acc[i][j][1], ep.alpha, bv[j].y);
+              v[q][2] = fmaf(acc[i][j][2], ep.alpha, bv[j].z); v[q][3] = fmaf(acc[i][j][3], ep.alpha, bv[j].w);
               if constexpr (epi_is_gelu(EPI)) {
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
@@ -261,7 +262,8 @@ __device__ __forceinline__ void nt_epilogue(f32x4 (&acc)[4][4], CT* __restrict__
     for (int i = 0; i < 4; ++i)
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
-        float v[4] = {acc[i][j][0] + bv[j].x, acc[i][j][1] + bv[j].y, acc[i][j][2] + bv[j].z, acc[i][j][3] + bv[j].w};
+        float v[4] = {fmaf(acc[i][j][0], ep.alpha, bv[j].x), fmaf(acc[i][j][1], ep.alpha, bv[j].y),
+                      fmaf(acc[i][j][2], ep.alpha, bv[j].z), fmaf(acc[i][j][3], ep.alpha, bv[j].w)};
         const int n = nb + j * 16;
         if constexpr (epi_is_gelu(EPI)) {
           float o2[4] = {v[0], v[1], v[2], v[3]};
@@ -309,7 +311,7 @@ __device__ __forceinline__ void nt_epilogue(f32x4 (&acc)[4][4], CT* __restrict__
       if (n >= N) continue;
       const int nvalid = (N - n) >= 4 ? 4 : (N - n);
       const bool vec = ldc_vec && nvalid == 4;
-      float v[4] = {acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]};
+      float v[4] = {acc[i][j][0] * ep.alpha, acc[i][j][1] * ep.alpha, acc[i][j][2] * ep.alpha, acc[i][j][3] * ep.alpha};
       if (ep.bias) {
 #pragma unroll
         for (int r = 0; r < 4; ++r)
@@ -1507,15 +1509,26 @@ int launch_nt(const void* A, int lda, const void* B, int ldb, void* C, int ldc, 
 
 }  // namespace
 
+extern "C" int mv_gemm_nt_bf16_scaled(const void* A, int lda, const void* B, int ldb, void* C, int ldc, int c_dtype, int M,
+                                      int N, int K, float alpha, const float* bias, int epilogue, const void* aux, int ld_aux,
+                                      int aux_i, void* out2, int ld_out2, mv_stream_t stream);
+
 extern "C" int mv_gemm_nt_bf16(const void* A, int lda, const void* B, int ldb, void* C, int ldc, int c_dtype, int M,
                                int N, int K, const float* bias, int epilogue, const void* aux, int ld_aux, int aux_i,
                                void* out2, int ld_out2, mv_stream_t stream) {
+  return mv_gemm_nt_bf16_scaled(A, lda, B, ldb, C, ldc, c_dtype, M, N, K, 1.0f, bias, epilogue, aux, ld_aux, aux_i, out2,
+                                ld_out2, stream);
+}
+
+extern "C" int mv_gemm_nt_bf16_scaled(const void* A, int lda, const void* B, int ldb, void* C, int ldc, int c_dtype, int M,
+                                      int N, int K, float alpha, const float* bias, int epilogue, const void* aux, int ld_aux,
+                                      int aux_i, void* out2, int ld_out2, mv_stream_t stream) {
   MV_REQUIRE(M >= 0 && N >= 0 && K >= 0, MV_ERR_SHAPE);
   if (M == 0 || N == 0) return MV_OK;
   MV_REQUIRE(lda % 8 == 0 && ldb % 8 == 0 && lda >= ((K + 7) & ~7) && ldb >= ((K + 7) & ~7), MV_ERR_ALIGN);
   MV_REQUIRE(mv_aligned16(A) && mv_aligned16(B) && mv_aligned16(C), MV_ERR_ALIGN);
   hipStream_t s = (hipStream_t)stream;
-  EpiArgs ep{bias, aux, ld_aux, aux_i, out2, ld_out2};
+  EpiArgs ep{alpha, bias, aux, ld_aux, aux_i, out2, ld_out2};
   switch (epilogue) {
     case MV_EPI_NONE:
       return c_dtype == MV_F32 ? launch_nt<MV_EPI_NONE, float>(A, lda, B, ldb, C, ldc, M, N, K, ep, s)

@@ -438,6 +438,29 @@ def quant_affine(x, scale, zero_point, qmin, qmax):
     return y
 
 
+def quant_affine_codes(x, rows, cols, scale, zero_point, qmin, qmax):
+    """fp32 [rows, cols] -> bf16 [rows, pad8(cols)] integer codes (q - zero_point) of the affine quantiser (exact)."""
+    require_cuda(x)
+    xf = x.detach().float().contiguous()
+    ld = pad8(cols)
+    codes = torch.empty(rows, ld, dtype=torch.bfloat16, device=x.device)
+    check(lib().mv_quant_affine_codes(_p(xf), _p(codes), rows, cols, ld, float(scale), int(zero_point), qmin, qmax, _s()),
+          "quant_affine_codes", rows=rows, cols=cols)
+    return codes
+
+
+def linear_codes(xc, wc, M, N, K, alpha, bias, out):
+    """out fp32 [M, N] = alpha * (xc [M, pad8(K)] . wc [N, pad8(K)]^T) + bias: integer-code operands on the bf16 MFMA
+    path = exact int8 arithmetic (|codes| <= 256, fp32 accumulation)."""
+    t0 = _timer.begin() if _timer is not None else None
+    check(lib().mv_gemm_nt_bf16_scaled(_p(xc), xc.shape[1], _p(wc), wc.shape[1], _p(out), N, _DT[out.dtype], M, N, K,
+                                       float(alpha), _p(bias), EPI_NONE, None, 0, 0, None, 0, _s()),
+          "gemm_nt_bf16_scaled", M=M, N=N, K=K)
+    if t0 is not None:
+        _timer.end("gemm_nt_bf16", t0, 2.0 * M * N * K)
+    return out
+
+
 def minmax_update(x, state):
     """state: fp32 [4] on device, [0]=running min, [1]=running max (init +inf/-inf)."""
     xf = x.detach().float().contiguous()

@@ -131,7 +131,8 @@ class QuantStub(nn.Module):
         return self.activation_post_process is None and not self._forward_hooks
 
     def forward(self, x):
-        if self.activation_post_process is None:
+        # passthrough: a converted int8 Linear behind this stub quantises its input itself (straight to integer codes)
+        if self.activation_post_process is None or getattr(self, "passthrough", False):
             return x
         return self.activation_post_process(x)
 
@@ -241,6 +242,41 @@ class QLinear(nn.Linear):
         mod.weight_fake_quant = None
         mod.activation_post_process = None
         return mod
+
+
+class Int8Linear(nn.Linear):
+    """Converted PyTorchINT8 Linear: per-tensor affine uint8 activations x symmetric int8 weights on the matrix cores.
+    Input and weight are turned into INTEGER CODES ((q - zero_point) and w_q, |code| <= 255: exact in bf16), the bf16
+    MFMA GEMM with fp32 accumulation is then the exact integer dot product, and scale_x * scale_w (+ bias) is applied in
+    its epilogue.  Equal to ``linear(fake_quantize(x), fake_quantize(W)) `` -- what the fp32 fallback below computes --
+    up to fp32 summation order.  (The reference's own converted int8 path does not run: SURVEY 9.2.)"""
+
+    precision = "fp32"
+
+    @classmethod
+    def from_observed(cls, lin, act_observer, weight_scale):
+        lin.__class__ = cls
+        lin.act_observer = act_observer                       # frozen MinMaxObserver: (scale, zero_point), qmin, qmax
+        lin.weight_scale = float(weight_scale)
+        N, K = lin.weight.shape
+        codes = torch.zeros(N, ops.pad8(K), dtype=torch.bfloat16, device=lin.weight.device)
+        codes[:, :K] = torch.round(lin.weight.data.float() / lin.weight_scale)
+        lin.weight_codes = codes
+        return lin
+
+    def forward(self, x):
+        s_x, z_x = self.act_observer.frozen
+        if torch.is_grad_enabled() and (x.requires_grad or self.weight.requires_grad):
+            return _hip_linear(self.act_observer(x), self.weight, self.bias, torch.float32)     # fake-quant STE path
+        ops.require_cuda(x)
+        K = x.shape[-1]
+        N = self.weight.shape[0]
+        x2 = x.reshape(-1, K)
+        M = x2.shape[0]
+        xc = ops.quant_affine_codes(x2, M, K, s_x, z_x, self.act_observer.qmin, self.act_observer.qmax)
+        out = torch.empty(M, N, dtype=torch.float32, device=x.device)
+        ops.linear_codes(xc, self.weight_codes, M, N, K, s_x * self.weight_scale, self.bias, out)
+        return out.view(*x.shape[:-1], N)
 
 
 class QLayerNorm(nn.LayerNorm):
@@ -370,6 +406,9 @@ class ModelQuantizer:
                     obs(lin.weight.data)
                     obs.freeze()
                     lin.weight.data = obs(lin.weight.data).data
+                    # inference runs on integer codes through the MFMA GEMM; the stub in front becomes a passthrough
+                    Int8Linear.from_observed(lin, module[0].activation_post_process, obs.frozen[0])
+                    module[0].passthrough = True
             return
         if self.q_format in (QFormat.FP16_16, QFormat.FP16_32, QFormat.TF32):
             # reference :340-346: Linear and LayerNorm weights quantised once; activation quantisers removed

@@ -501,3 +501,54 @@ def test_adamw_matches_torch(ops):
         opt.step()
         ops.adamw_step(p, (gr * step).cuda(), m, v, lr=1e-3, beta1=0.9, beta2=0.999, eps=1e-8, weight_decay=0.05, step=step)
     assert relerr(p, ref.data) < 2e-6
+
+
+@pytest.mark.parametrize("M,N,K", [(394, 768, 768), (50, 45, 200), (1030, 300, 3072)])
+def test_int8_codes_gemm_equals_fake_quant_linear(ops, M, N, K):
+    """Converted-int8 Linear on the MFMA path: integer codes (exact in bf16) x integer codes, fp32 accumulation, scale in the
+    epilogue == linear(fake_quantize(x), fake_quantize(W)) + b as torch computes it in fp32."""
+    x = torch.randn(M, K, generator=g(1)) * 2 + 0.3
+    w = torch.randn(N, K, generator=g(2)) * K ** -0.5
+    b = torch.randn(N, generator=g(3))
+    s_x = float((x.max() - min(x.min(), 0)) / 255.0)
+    z_x = int(min(max(round(-float(min(x.min(), 0)) / s_x), 0), 255))
+    s_w = float(w.abs().max() / 127.5)
+    xq = torch.fake_quantize_per_tensor_affine(x, s_x, z_x, 0, 255)
+    wq = torch.fake_quantize_per_tensor_affine(w, s_w, 0, -128, 127)
+    want = torch.nn.functional.linear(xq.double(), wq.double(), b.double())
+    xc = ops.quant_affine_codes(x.cuda(), M, K, s_x, z_x, 0, 255)
+    assert xc.shape == (M, (K + 7) & ~7) and xc.dtype == torch.bfloat16
+    codes = xc[:, :K].float().cpu()
+    assert torch.equal(codes, torch.round(xq / s_x))                     # the integer (q - z), exactly
+    assert (xc[:, K:] == 0).all() and codes.abs().max() <= 255
+    wc = torch.zeros(N, (K + 7) & ~7, dtype=torch.bfloat16)
+    wc[:, :K] = torch.round(wq / s_w)
+    out = torch.empty(M, N, device="cuda")
+    ops.linear_codes(xc, wc.cuda(), M, N, K, s_x * s_w, b.cuda(), out)
+    assert relerr(out, want) < 2e-6
+
+
+def test_int8_converted_model_fast_path_equals_fake_quant_path():
+    """ViT.convert() for PyTorchINT8 installs Int8Linear: under no_grad it runs integer codes through the MFMA GEMM; with
+    grad enabled it runs the fp32 fake-quant (straight-through) path.  Same numbers up to fp32 summation order."""
+    from myrtle_vision.models.vit import ViT
+    from myrtle_vision.utils.quantize import Int8Linear
+    from myrtle_vision.utils.utils import seed_everything
+    seed_everything(3)
+    vit = ViT(precision="bf16", q_format="PyTorchINT8", decoder="classification", image_size=224, patch_size=16, num_classes=10,
+              dim=128, depth=2, heads=2, mlp_dim=256, dropout=0.0, emb_dropout=0.0).cuda()
+    gen = torch.Generator().manual_seed(4)
+    vit.train()
+    with torch.no_grad():
+        for _ in range(3):                                                # min/max calibration (test_quantize.py:26-34)
+            vit(torch.randn(4, 3, 224, 224, generator=gen).cuda())
+    vit.convert()
+    vit.eval()
+    assert sum(isinstance(m, Int8Linear) for m in vit.modules()) == 2 * 4 + 2      # 4 per block + patch embedding + head
+    img = torch.randn(4, 3, 224, 224, generator=gen).cuda()
+    with torch.no_grad():
+        fast = vit(img)
+    slow = vit(img)                                                       # grad mode: fake-quant fp32 path
+    assert slow.requires_grad and not fast.requires_grad
+    assert relerr(fast, slow.detach().double().cpu()) < 1e-4
+    assert torch.equal(fast.argmax(1), slow.argmax(1))
