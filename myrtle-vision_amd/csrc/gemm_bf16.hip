@@ -1253,8 +1253,8 @@ __global__ __launch_bounds__(512, 2) void gemm_tn_ring_kernel(const bf16_t* __re
     char* la_ = wave_lds + (slot_) * RSTAGE_BYTES;                                     \
     char* lb_ = la_ + 16384;                                                           \
     const long ao_ = (kt_) * astep, bo_ = (kt_) * bstep;                               \
-    glds16(pa[0] + ao_, la_);   glds16(pa[1] + ao_, la_ + 1024);                       \
-    glds16(pb[0] + bo_, lb_);   glds16(pb[1] + bo_, lb_ + 1024);                       \
+    glds16_hidden(pa[0] + ao_, la_);   glds16_hidden(pa[1] + ao_, la_ + 1024);         \
+    glds16_hidden(pb[0] + bo_, lb_);   glds16_hidden(pb[1] + bo_, lb_ + 1024);         \
   }
 
   f32x4 acc[8][4];

@@ -78,6 +78,21 @@ __device__ __forceinline__ void glds16(const void* gsrc, void* lds_wave_base) {
                                    (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
 }
 
+// The same copy issued through inline asm, INVISIBLE to the compiler's s_waitcnt bookkeeping.  Needed wherever LDS is read
+// through an intrinsic without alias information (ds_read_b64_tr_b16): seeing a pending LDS-DMA, hipcc orders such a read
+// after ALL of them with s_waitcnt vmcnt(0) -- which drained the 3-stage prefetch of gemm_tn_ring_kernel at every stage and
+// the next item's K/V prefetch of the persistent attention kernel at every tile.  With the hidden form nothing but the
+// caller's own counted s_waitcnt vmcnt(N) + barrier orders the DMA (recipe: cdna_hip_programming.md section 5.7; M0 is
+// compiler-reserved, so it is saved, written and restored inside the one statement).
+__device__ __forceinline__ void glds16_hidden(const void* gsrc, void* lds_wave_base) {
+  unsigned keep;
+  const unsigned dst = __builtin_amdgcn_readfirstlane((unsigned)(size_t)lds_wave_base);   // LDS byte address (low 32 bits)
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+               : "=&s"(keep)
+               : "v"(gsrc), "s"(dst)
+               : "memory");
+}
+
 // out[c] (+)= sum over rows r of partial[r * ld + c]: the second stage of the deterministic two-stage reductions
 // (LayerNorm dgamma/dbeta/dx column sums, bias-gradient column sums).  One 1024-thread block per 16 columns (so even
 // a 768-column reduction spreads over 48+ CUs): lane l takes column l&15 and row phase l>>4 of its wave, the 64 row
