@@ -115,7 +115,10 @@ def main():
         raise SystemExit("bench.py needs an MI355X: the HIP path has no CPU fallback")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if world > 1:
+    force_dist = world == 1 and os.environ.get("MV_FORCE_DIST") == "1"   # rehearsal: the RCCL code path with one rank
+    if force_dist:
+        os.environ.setdefault("MASTER_PORT", "29533")
+    if world > 1 or force_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         backend = os.environ.get("MV_DIST_BACKEND", "nccl")     # "nccl" = RCCL; "gloo" only to rehearse N ranks on one GPU
         if backend == "nccl":
@@ -141,6 +144,9 @@ def main():
     arena = ParamArena(vit.named_parameters(), skip=vit.unused_parameter_names())
     opt = AdamW(arena, lr=6.25e-5, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.05)      # vit_base.json
     reducer = GradAllReducer(arena)
+    if force_dist:
+        reducer.enabled = True                                  # launch the bucketed all-reduces although world == 1
+        dist.broadcast(arena.flat_param, src=0)
     broadcast_parameters(arena)
     opt.grad_scale = reducer.grad_scale
 
@@ -178,7 +184,7 @@ def main():
     for _ in range(args.warmup):
         loss = step()
     timer = None if args.no_kernel_timer else ops.KernelTimer()
-    if world > 1:
+    if world > 1 or force_dist:
         dist.barrier()
     torch.cuda.synchronize()
     ops.set_kernel_timer(timer)
@@ -225,7 +231,7 @@ def main():
         if world == 1 and not args.no_cpu_baseline and args.workload == "cls":
             out["cpu_baseline"] = cpu_baseline()
         print(json.dumps(out))
-    if world > 1:
+    if world > 1 or force_dist:
         dist.destroy_process_group()
 
 
