@@ -942,6 +942,9 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_8phase_kernel(const bf16_t* __
   P8_BAR()
   if (__builtin_amdgcn_readfirstlane(wave) >= 4) P8_BAR()      // waves 4-7 run one barrier behind
   int kt = 0;
+#if MV_ABLATE == 16
+  kt = nk - 2;                                   // diagnostic: only the peeled last iteration runs
+#endif
   for (; kt < nk - 2; kt += 2) {
     // phases 1-4: compute buffer 0 (K-tile kt); stage A_q1[kt+1] -> buffer 1, then B_q0/A_q0/B_q1[kt+2] -> buffer 0
     P8_KTILE(0, 1, 1, kt + 1, 0, kt + 2, 0, 0, "s_waitcnt vmcnt(6)", 1)
@@ -964,6 +967,17 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_8phase_kernel(const bf16_t* __
   // 64-register accumulator halves: the second half waits in LDS (free now: every wave has passed the final barrier
   // after its last fragment read, and no DMA is outstanding) -- a 16 x ds_write_b128 / ds_read_b128 round trip per lane
   // instead of 60-170 registers spilled to scratch memory.
+#if MV_ABLATE == 8
+  {                                              // diagnostic: no epilogue; one conditional store keeps the accumulators alive
+    float keep = 0.f;
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) keep += acc[i][j][0] + acc[i][j][1] + acc[i][j][2] + acc[i][j][3];
+    if (keep == 12345.678f) C[0] = (CT)keep;
+    return;
+  }
+#endif
   constexpr bool park = epi_is_dgelu(EPI) || EPI == MV_EPI_RESIDUAL;
   f32x4* const parked = reinterpret_cast<f32x4*>(smem) + wave * 16 * 64 + lane;
   if (park && !is_half) {
