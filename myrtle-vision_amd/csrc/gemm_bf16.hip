@@ -163,7 +163,9 @@ __device__ __forceinline__ u32x4 pair_swap_bf16(const float (&va)[4], const floa
 
 template <int EPI, typename CT>
 __device__ __forceinline__ void nt_epilogue(f32x4 (&acc)[4][4], CT* __restrict__ C, int ldc, int M, int N, int m0, int n0,
-                                            int wm, int wn, int lane, const EpiArgs& ep) {
+                                            int wm, int wn, int lane, const EpiArgs& ep, const float* bias_lds = nullptr) {
+  // bias_lds (persistent kernel): the bias of this 128-column region staged in LDS (zeros when there is none); indexed
+  // relative to the region, so the epilogue issues no global load at all
   // (m0, n0) = origin of the 128x128 region this call covers; wave (wm, wn) owns its 64x64 quadrant
   const bool interior = (m0 + BM <= M) && (n0 + BN <= N) && ((ldc & 3) == 0) && ((ep.ld_aux & 3) == 0) &&
                         ((ep.ld_out2 & 3) == 0) && ((reinterpret_cast<uintptr_t>(ep.bias) & 15) == 0);
@@ -172,8 +174,9 @@ __device__ __forceinline__ void nt_epilogue(f32x4 (&acc)[4][4], CT* __restrict__
     float4 bv[4];                                      // (the input-gradient epilogues never carry a bias: constants there)
 #pragma unroll
     for (int j = 0; j < 4; ++j)
-      bv[j] = (!epi_is_dgelu(EPI) && ep.bias) ? *reinterpret_cast<const float4*>(ep.bias + nb + j * 16)
-                                               : make_float4(0.f, 0.f, 0.f, 0.f);
+      bv[j] = bias_lds ? *reinterpret_cast<const float4*>(bias_lds + wn * 64 + 4 * (lane >> 4) + j * 16)
+              : (!epi_is_dgelu(EPI) && ep.bias) ? *reinterpret_cast<const float4*>(ep.bias + nb + j * 16)
+                                                : make_float4(0.f, 0.f, 0.f, 0.f);
     long crow[4];
     int prow[4];
 #pragma unroll
@@ -798,10 +801,11 @@ template <int EPI, typename CT>
 __global__ __launch_bounds__(512, 2) void gemm_nt_8phase_kernel(const bf16_t* __restrict__ A, int lda,
                                                                 const bf16_t* __restrict__ B, int ldb, CT* __restrict__ C,
                                                                 int ldc, int M, int N, int K, int tiles_n, EpiArgs ep,
-                                                                int full_tiles) {
+                                                                int full_tiles, int item0) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave >> 2, wn = wave & 3;
+  const int bid = blockIdx.x + item0;            // item0 > 0: only the items from item0 on (the half items)
   // Work items [0, full_tiles) are whole 256x256 output tiles (full_tiles = a multiple of the CU count, or all tiles).
   // The remaining "tail" tiles would occupy only part of the chip for one more full round; each is split into two
   // 128x256 HALF items (rows [0,128) and [128,256) of the tile) that run the same pipeline with quadrant-row 0 only:
@@ -809,10 +813,10 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_8phase_kernel(const bf16_t* __
   // 591 tiles on 256 CUs: 3 rounds -> 2 + ~0.6, with no extra memory traffic.
   const int nk = K >> 6;                         // even, >= 2 (dispatch)
   int t, half = -1;
-  if ((int)blockIdx.x < full_tiles) {
-    t = xcd_remap(blockIdx.x, full_tiles);
+  if (bid < full_tiles) {
+    t = xcd_remap(bid, full_tiles);
   } else {
-    const int idx = blockIdx.x - full_tiles;
+    const int idx = bid - full_tiles;
     t = full_tiles + (idx >> 1);
     half = idx & 1;
   }
@@ -1002,6 +1006,273 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_8phase_kernel(const bf16_t* __
       for (int j = 0; j < 4; ++j) acc2[i][j] = acc[4 + i][j];
   }
   nt_epilogue<EPI, CT>(acc2, C, ldc, M, N, m0 + 128 * wm, n0 + 128 * (wn >> 1), 1, wn & 1, lane, ep);
+}
+
+// ------------------------------------------------------------------------------------------------
+// NT 8-phase kernel, PERSISTENT: one workgroup per CU walks whole interior tiles; stores drain under the next tile
+// ------------------------------------------------------------------------------------------------
+// Ablation of gemm_nt_8phase_kernel (tools/ablate_gemm8.sh): with the epilogue removed it sustains 1.18-1.27 PFLOP/s on
+// EVERY ViT-B shape, K = 768 included; the epilogue is purely additive (qkv: 149 us of main loop + 80 us of output
+// write, all 256 CUs bursting at once while HBM idles during the main loops) = 32-49 % of the K = 768 GEMMs.  Here a
+// workgroup stays on its CU and walks items blockIdx.x, + gridDim.x, ...: when a tile's main loop ends it first issues
+// the NEXT tile's whole prologue, then this tile's epilogue stores, and goes straight on -- the stores drain while the
+// next tile computes.  What makes that legal with an IN-ORDER vmcnt:
+//   * every DMA is issued through inline asm, so hipcc never waits on them and sees only the stores;
+//   * the next tile's prologue is ALL of K-tiles 0 and 1 (16 pieces) + its bias row (1 piece, into LDS: the epilogue
+//     issues no global load), issued BEFORE the S >= 16 epilogue stores of the current tile;
+//   * in a tile's first iteration the waits step over those stores: K-tile 0 landed = vmcnt(8 + 16), K-tile 1 landed
+//     (phase 4) = vmcnt(6 + 16); from phase 8 on the counts are the usual vmcnt(6).  S = 16 is a lower bound of the
+//     stores actually issued (16 or 32): an underestimate only waits longer.  A workgroup's first tile (no stores before
+//     it) uses vmcnt(8) / vmcnt(6).
+// Register discipline (a first version spilled 50 VGPRs through 47-68 spilled SGPRs, and every scratch reload is a
+// vector-memory load the compiler guards with vmcnt(0) -- it ran 35 % slower): the DMA takes ONE SGPR for the wave's LDS
+// base plus an immediate (s_add_u32 m0, base, imm inside the statement), one running SGPR pointer pair per operand that
+// advances by two K-tiles per iteration, the relative K-tile (1, 2, 3) in the instruction's offset: field, and the 8
+// lane-constant byte offsets in VGPRs.
+// Restricted to what makes the store count exact: whole tiles with M % 256 == N % 256 == 0 (every tile interior),
+// K >= 256, epilogues NONE / GELU / GELU_GRAD.  Half items of a tail round run in a second launch of
+// gemm_nt_8phase_kernel.  Phase schedule, slot organisation and wave stagger are those of gemm_nt_8phase_kernel.
+// Measured (same box, alternating runs): in isolation, also with buffer sets rotated beyond the Infinity Cache, the
+// persistent kernel is +3...21 % per GEMM (qkv 818 -> 992 TFLOP/s); inside the ViT-B training step the event-timed NT
+// time does not drop (20.77 vs 20.59 ms) while the unchanged TN kernel and everything else run 2-4 % slower -- the
+// step LOSES 1.7 % (6 584 vs 6 702 img/s): the chip is power-managed and the saving comes back as lower clocks.  So it
+// is selectable (mv_gemm_force_variant 2569) and tested, but not the automatic choice.
+constexpr int PP_AUTO_FORCE = -1;                  // 0: pick the persistent kernel automatically where eligible; -1: only when forced (2569)
+constexpr int PP_BIAS = 24 * 1024;                 // 8 waves x (2 parities + 1 dummy target) x 1 KiB
+constexpr int PP_SMEM = P8_SMEM + PP_BIAS;
+
+// hidden LDS-DMA, 16 B per lane: global address = SGPR pair + 32-bit lane byte offset; LDS destination = SGPR base +
+// immediate.  Two hardware facts found the hard way: (1) the instruction's offset: field is added to the LDS address as
+// well as to the global address, so it is not used (the relative K-tile is added to the SGPR base instead); (2) M0
+// written directly by s_add_u32 gave garbage destinations, so the sum goes through a scratch SGPR and s_mov_b32.  M0 is
+// saved and restored inside the statement; s_add_u32 clobbers SCC.
+#define PP_DMA(sbase_, voff_, ldsbase_, ldsimm_)                                                                 \
+  {                                                                                                              \
+    unsigned keep_, dst_;                                                                                        \
+    asm volatile("s_mov_b32 %0, m0\n\ts_add_u32 %1, %4, %5\n\ts_mov_b32 m0, %1\n\ts_nop 0\n\t"                  \
+                 "global_load_lds_dwordx4 %2, %3\n\ts_mov_b32 m0, %0"                                            \
+                 : "=&s"(keep_), "=&s"(dst_)                                                                     \
+                 : "v"(voff_), "s"(sbase_), "s"(ldsbase_), "i"(ldsimm_)                                          \
+                 : "memory", "scc");                                                                             \
+  }
+
+template <int EPI, typename CT>
+__global__ __launch_bounds__(512, 2) void gemm_nt_8phase_persistent_kernel(const bf16_t* __restrict__ A, int lda,
+                                                                           const bf16_t* __restrict__ B, int ldb,
+                                                                           CT* __restrict__ C, int ldc, int M, int N, int K,
+                                                                           int tiles_n, EpiArgs ep, int n_items) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 2, wn = wave & 3;
+  const int nk = K >> 6;                         // even, >= 4 (dispatch)
+
+  // this lane's staging offsets inside a tile, in BYTES from the tile's first A / B row at the current K-tile
+  unsigned pa00, pa01, pa10, pa11, pb00, pb01, pb10, pb11;     // p{a,b}{q}{i}
+  {
+    const int r0 = 16 * wave + (lane >> 3), r1 = r0 + 8;
+    const int c0 = (lane & 7) ^ (((r0 >> 1) & 3) << 1), c1 = (lane & 7) ^ (((r1 >> 1) & 3) << 1);
+    const int ra = 128 * (wave >> 2) + 16 * (wave & 3) + (lane >> 3), rb = 64 * (wave >> 1) + 16 * (wave & 1) + (lane >> 3);
+    pa00 = 2u * ((unsigned)ra * (unsigned)lda + c0 * 8);
+    pa01 = 2u * ((unsigned)(ra + 8) * (unsigned)lda + c1 * 8);
+    pa10 = 2u * ((unsigned)(ra + 64) * (unsigned)lda + c0 * 8);
+    pa11 = 2u * ((unsigned)(ra + 72) * (unsigned)lda + c1 * 8);
+    pb00 = 2u * ((unsigned)rb * (unsigned)ldb + c0 * 8);
+    pb01 = 2u * ((unsigned)(rb + 8) * (unsigned)ldb + c1 * 8);
+    pb10 = 2u * ((unsigned)(rb + 32) * (unsigned)ldb + c0 * 8);
+    pb11 = 2u * ((unsigned)(rb + 40) * (unsigned)ldb + c1 * 8);
+  }
+  const unsigned lane16 = 16u * lane;
+  const unsigned lds_w = (unsigned)__builtin_amdgcn_readfirstlane((unsigned)(size_t)(smem + wave * 2048));          // staging base
+  const unsigned lds_b = (unsigned)__builtin_amdgcn_readfirstlane((unsigned)(size_t)(smem + P8_SMEM + wave * 1024)); // bias areas
+  char* const bias_lds = smem + P8_SMEM + wave * 1024;          // + parity * 8192; + 16384: dummy target
+  const bool has_bias = ep.bias != nullptr;
+  if (!has_bias) {                               // no bias: both parities hold zeros for good
+    reinterpret_cast<float4*>(bias_lds)[lane] = make_float4(0.f, 0.f, 0.f, 0.f);
+    reinterpret_cast<float4*>(bias_lds + 8192)[lane] = make_float4(0.f, 0.f, 0.f, 0.f);
+  }
+// stage one slot of buffer buf_ from K-tile (current + REL_): 2 pieces per wave
+#define PP_STAGE(buf_, slot_, REL_)                                                                              \
+  {                                                                                                              \
+    if ((slot_) == P8_AQ0) { PP_DMA(a_cur + (REL_) * 128, pa00, lds_w, ((buf_) * 4 + (slot_)) * P8_SLOT)          \
+                             PP_DMA(a_cur + (REL_) * 128, pa01, lds_w, ((buf_) * 4 + (slot_)) * P8_SLOT + 1024) } \
+    if ((slot_) == P8_AQ1) { PP_DMA(a_cur + (REL_) * 128, pa10, lds_w, ((buf_) * 4 + (slot_)) * P8_SLOT)          \
+                             PP_DMA(a_cur + (REL_) * 128, pa11, lds_w, ((buf_) * 4 + (slot_)) * P8_SLOT + 1024) } \
+    if ((slot_) == P8_BQ0) { PP_DMA(b_cur + (REL_) * 128, pb00, lds_w, ((buf_) * 4 + (slot_)) * P8_SLOT)          \
+                             PP_DMA(b_cur + (REL_) * 128, pb01, lds_w, ((buf_) * 4 + (slot_)) * P8_SLOT + 1024) } \
+    if ((slot_) == P8_BQ1) { PP_DMA(b_cur + (REL_) * 128, pb10, lds_w, ((buf_) * 4 + (slot_)) * P8_SLOT)          \
+                             PP_DMA(b_cur + (REL_) * 128, pb11, lds_w, ((buf_) * 4 + (slot_)) * P8_SLOT + 1024) } \
+  }
+// the whole prologue of a tile (a_cur / b_cur at its K-tile 0): bias row (1 piece; without a bias a harmless read of A into
+// the dummy area, so that the count is always 17 and the parity areas keep their zeros), then K-tiles 0 and 1
+#define PP_PROLOGUE(bias_src_, bias_dst_)                                                                        \
+  {                                                                                                              \
+    PP_DMA(bias_src_, lane16, bias_dst_, 0)                                                                      \
+    PP_STAGE(0, P8_BQ0, 0) PP_STAGE(0, P8_AQ0, 0) PP_STAGE(0, P8_BQ1, 0) PP_STAGE(0, P8_AQ1, 0)                  \
+    PP_STAGE(1, P8_BQ0, 1) PP_STAGE(1, P8_AQ0, 1) PP_STAGE(1, P8_BQ1, 1) PP_STAGE(1, P8_AQ1, 1)                  \
+  }
+
+  const int fr = (((lane & 15) >> 1) & 3) << 1;
+  const int rf0 = (lane & 15) * 128 + (((lane >> 4) ^ fr) << 4);
+  const int rf1 = (lane & 15) * 128 + (((4 + (lane >> 4)) ^ fr) << 4);
+  const char* const a_rd = smem + 64 * wm * 128;
+  const char* const b_rd = smem + 32 * wn * 128;
+  bf16x8 af[4][2], bf0[2][2], bf1[2][2];
+  f32x4 acc[8][4];
+#define PP_READ_A(buf_, slot_)                                                                               \
+  {                                                                                                          \
+    const char* s_ = a_rd + ((buf_) * 4 + (slot_)) * P8_SLOT;                                                \
+    _Pragma("unroll") for (int i = 0; i < 4; ++i) {                                                          \
+      af[i][0] = *reinterpret_cast<const bf16x8*>(s_ + i * 2048 + rf0);                                      \
+      af[i][1] = *reinterpret_cast<const bf16x8*>(s_ + i * 2048 + rf1);                                      \
+    }                                                                                                        \
+  }
+#define PP_READ_B(dst_, buf_, slot_)                                                                         \
+  {                                                                                                          \
+    const char* s_ = b_rd + ((buf_) * 4 + (slot_)) * P8_SLOT;                                                \
+    _Pragma("unroll") for (int j = 0; j < 2; ++j) {                                                          \
+      dst_[j][0] = *reinterpret_cast<const bf16x8*>(s_ + j * 2048 + rf0);                                    \
+      dst_[j][1] = *reinterpret_cast<const bf16x8*>(s_ + j * 2048 + rf1);                                    \
+    }                                                                                                        \
+  }
+#define PP_MFMA(mb_, nb_, bfx_)                                                                              \
+  {                                                                                                          \
+    __builtin_amdgcn_s_setprio(1);                                                                           \
+    _Pragma("unroll") for (int ks = 0; ks < 2; ++ks)                                                         \
+      _Pragma("unroll") for (int i = 0; i < 4; ++i)                                                          \
+        _Pragma("unroll") for (int j = 0; j < 2; ++j)                                                        \
+          acc[(mb_) + i][(nb_) + j] =                                                                        \
+              __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfx_[j][ks], af[i][ks], acc[(mb_) + i][(nb_) + j], 0, 0, 0); \
+    __builtin_amdgcn_s_setprio(0);                                                                           \
+  }
+#define PP_BAR()                                  \
+  {                                               \
+    __builtin_amdgcn_sched_barrier(0);            \
+    __builtin_amdgcn_s_barrier();                 \
+    asm volatile("" ::: "memory");                \
+    __builtin_amdgcn_sched_barrier(0);            \
+  }
+#define PP_LGKM0()                                          \
+  {                                                         \
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      \
+    __builtin_amdgcn_sched_barrier(0);                      \
+  }
+// one K-tile (4 phases) out of buffer d_.  ST_: stage the next contents per the schedule (relative K-tile NEXT_REL_ into
+// buffer next_buf_); STAGE_FIRST_: phase 1/5 stages A_q1 of relative K-tile FIRST_REL_ into buffer first_buf_.
+#define PP_KTILE(d_, ST_, first_buf_, FIRST_REL_, next_buf_, NEXT_REL_, WAIT_, STAGE_FIRST_)                 \
+  {                                                                                                          \
+    PP_READ_B(bf0, d_, P8_BQ0)                                                                               \
+    __builtin_amdgcn_sched_barrier(0);                                                                       \
+    PP_READ_A(d_, P8_AQ0)                                                                                    \
+    __builtin_amdgcn_sched_barrier(0);                                                                       \
+    if (STAGE_FIRST_) PP_STAGE(first_buf_, P8_AQ1, FIRST_REL_)                                               \
+    asm volatile("s_waitcnt lgkmcnt(8)" ::: "memory");                                                       \
+    PP_BAR()                                                                                                 \
+    PP_LGKM0()                                                                                               \
+    PP_MFMA(0, 0, bf0)                                                                                       \
+    PP_BAR()                                                                                                 \
+    PP_READ_B(bf1, d_, P8_BQ1)                                                                               \
+    __builtin_amdgcn_sched_barrier(0);                                                                       \
+    if (ST_) PP_STAGE(next_buf_, P8_BQ0, NEXT_REL_)                                                          \
+    PP_BAR()                                                                                                 \
+    PP_LGKM0()                                                                                               \
+    PP_MFMA(0, 2, bf1)                                                                                       \
+    PP_BAR()                                                                                                 \
+    PP_READ_A(d_, P8_AQ1)                                                                                    \
+    __builtin_amdgcn_sched_barrier(0);                                                                       \
+    if (ST_) PP_STAGE(next_buf_, P8_AQ0, NEXT_REL_)                                                          \
+    PP_BAR()                                                                                                 \
+    PP_LGKM0()                                                                                               \
+    PP_MFMA(4, 2, bf1)                                                                                       \
+    PP_BAR()                                                                                                 \
+    if (ST_) PP_STAGE(next_buf_, P8_BQ1, NEXT_REL_)                                                          \
+    WAIT_;                                                                                                   \
+    PP_BAR()                                                                                                 \
+    PP_MFMA(4, 0, bf0)                                                                                       \
+    PP_BAR()                                                                                                 \
+  }
+#define PP_WAIT(n_) asm volatile("s_waitcnt vmcnt(" #n_ ")" ::: "memory")
+// wave-uniform 64-bit pointer -> SGPR pair
+// (readfirstlane returns a SIGNED int: each half is cast to unsigned before widening, or a low word with bit 31 set
+// sign-extends over the high word -- that produced a wild address in the first run of this kernel)
+#define PP_UNIFORM64(p_)                                                                                                      \
+  (((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((unsigned)((unsigned long long)(size_t)(p_) >> 32)) << 32) | \
+   (unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((unsigned)(size_t)(p_)))
+
+  int item = blockIdx.x;                         // < n_items (grid <= n_items)
+  int t = xcd_remap(item, n_items);
+  int m0 = (t / tiles_n) * BM2, n0 = (t % tiles_n) * BN2;
+  unsigned long long a_cur = PP_UNIFORM64(A + (long)m0 * lda), b_cur = PP_UNIFORM64(B + (long)n0 * ldb);
+  int par = 0;
+  bool first = true;
+  __syncthreads();                               // the zero-filled bias areas (no-bias case)
+  {
+    const unsigned long long bsrc = has_bias ? PP_UNIFORM64(ep.bias + n0) : a_cur;
+    const unsigned bdst = has_bias ? lds_b : lds_b + 16384;
+    PP_PROLOGUE(bsrc, bdst)
+  }
+  for (;;) {
+    // ---- tile start: K-tile 0 (and, older, the bias row) landed; the 8 pieces of K-tile 1 and, after the first tile,
+    // the previous tile's >= 16 stores may still be outstanding
+    if (first) { PP_WAIT(8); } else { PP_WAIT(24); }
+    PP_BAR()
+    if (__builtin_amdgcn_readfirstlane(wave) >= 4) PP_BAR()      // waves 4-7 run one barrier behind
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    // first iteration: K-tile 1 is already staged (nothing in phase 1); its phase-4 wait steps over the stores too
+    if (first) {
+      PP_KTILE(0, 1, 0, 0, 0, 2, PP_WAIT(6), 0)
+    } else {
+      PP_KTILE(0, 1, 0, 0, 0, 2, PP_WAIT(22), 0)
+    }
+    PP_KTILE(1, 1, 0, 2, 1, 3, PP_WAIT(6), 1)
+    a_cur += 256;                                                // two K-tiles of 64 bf16
+    b_cur += 256;
+    for (int kt = 2; kt < nk - 2; kt += 2) {
+      PP_KTILE(0, 1, 1, 1, 0, 2, PP_WAIT(6), 1)
+      PP_KTILE(1, 1, 0, 2, 1, 3, PP_WAIT(6), 1)
+      a_cur += 256;
+      b_cur += 256;
+    }
+    PP_KTILE(0, 0, 1, 1, 0, 0, PP_WAIT(0), 1)                    // peeled last iteration: only A_q1 of K-tile nk-1 is staged
+    PP_KTILE(1, 0, 0, 0, 0, 0, , 0)
+    if (__builtin_amdgcn_readfirstlane(wave) < 4) PP_BAR()       // groups re-aligned; every wave is done reading LDS
+    // ---- next tile's prologue BEFORE this tile's stores
+    const int nitem = item + gridDim.x;
+    const bool has_next = nitem < n_items;
+    const int m0c = m0, n0c = n0;
+    if (has_next) {
+      t = xcd_remap(nitem, n_items);
+      m0 = (t / tiles_n) * BM2;
+      n0 = (t % tiles_n) * BN2;
+      a_cur = PP_UNIFORM64(A + (long)m0 * lda);
+      b_cur = PP_UNIFORM64(B + (long)n0 * ldb);
+      const unsigned long long bsrc = has_bias ? PP_UNIFORM64(ep.bias + n0) : a_cur;
+      const unsigned bdst = has_bias ? lds_b + (par ^ 1) * 8192 : lds_b + 16384;
+      PP_PROLOGUE(bsrc, bdst)
+    }
+    // ---- epilogue (bias from LDS: staged with this tile's prologue, waited for at its start)
+    const float* bl = reinterpret_cast<const float*>(bias_lds + par * 8192) + 128 * (wn >> 1);
+#pragma unroll
+    for (int h = 0; h < 2; ++h)
+      nt_epilogue<EPI, CT>(*reinterpret_cast<f32x4(*)[4][4]>(&acc[4 * h]), C, ldc, M, N, m0c + 128 * wm, n0c + 128 * (wn >> 1), h,
+                           wn & 1, lane, ep, bl);
+    if (!has_next) break;
+    item = nitem;
+    par ^= 1;
+    first = false;
+  }
+#undef PP_UNIFORM64
+#undef PP_WAIT
+#undef PP_KTILE
+#undef PP_LGKM0
+#undef PP_BAR
+#undef PP_MFMA
+#undef PP_READ_A
+#undef PP_READ_B
+#undef PP_PROLOGUE
+#undef PP_STAGE
 }
 
 __device__ __forceinline__ void tn_store(f32x4 (&acc)[4][4], float* __restrict__ Cs, long ldc, int M, int N, int m0, int n0,
@@ -1492,13 +1763,32 @@ int launch_nt(const void* A, int lda, const void* B, int ldb, void* C, int ldc, 
   const bool p8_ok = K >= 128 && K % 128 == 0 && (long)M * lda < (1L << 31) && (long)N * ldb < (1L << 31);
   // 8-phase kernel: wherever the ring would be picked, and from one full round of the chip on (half-item tail)
   const bool p8_pick = p8_ok && (ring_pick || (long)t2m * t2n >= NT_CUS);
-  if (((force == 2568 || force == 25680) && p8_ok) || (force == 0 && p8_pick)) {
+  if (((force == 2568 || force == 25680 || force == 2569) && p8_ok) || (force == 0 && p8_pick)) {
     static const int a8 = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_nt_8phase_kernel<EPI, CT>),
                                               hipFuncAttributeMaxDynamicSharedMemorySize, P8_SMEM) == hipSuccess ? 0 : -1;
     if (a8) return MV_ERR_LAUNCH;
     const int tiles = t2m * t2n, full = force == 25680 ? tiles : nt_full_tiles(tiles);     // 25680: whole tiles only (A/B)
+    // persistent variant (stores drain under the next tile): interior whole tiles, bias-only epilogues; 2569 forces it
+    constexpr bool pp_epi = EPI == MV_EPI_NONE || EPI == MV_EPI_GELU || EPI == MV_EPI_GELU_GRAD;
+    const bool pp_ok = pp_epi && M % BM2 == 0 && N % BN2 == 0 && K >= 256 && (long)BM2 * lda < (1L << 30) &&
+                       (long)BN2 * ldb < (1L << 30) && (ldc % 8) == 0 && (ep.ld_out2 % 8) == 0 &&
+                       (reinterpret_cast<uintptr_t>(ep.bias) & 15) == 0 && ep.alpha == 1.0f;
+    if (pp_ok && (force == PP_AUTO_FORCE || force == 2569)) {
+      if constexpr (pp_epi) {
+        static const int ap = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_nt_8phase_persistent_kernel<EPI, CT>),
+                                                  hipFuncAttributeMaxDynamicSharedMemorySize, PP_SMEM) == hipSuccess ? 0 : -1;
+        if (ap) return MV_ERR_LAUNCH;
+        gemm_nt_8phase_persistent_kernel<EPI, CT><<<full < NT_CUS ? full : NT_CUS, 512, PP_SMEM, s>>>(
+            (const bf16_t*)A, lda, (const bf16_t*)B, ldb, (CT*)C, ldc, M, N, K, t2n, ep, full);
+        if (tiles > full)                       // the tail round's half items: the one-item-per-workgroup kernel
+          gemm_nt_8phase_kernel<EPI, CT><<<2 * (tiles - full), 512, P8_SMEM, s>>>(
+              (const bf16_t*)A, lda, (const bf16_t*)B, ldb, (CT*)C, ldc, M, N, K, t2n, ep, full, full);
+        MV_CHECK_LAUNCH();
+        return MV_OK;
+      }
+    }
     gemm_nt_8phase_kernel<EPI, CT><<<full + 2 * (tiles - full), 512, P8_SMEM, s>>>(
-        (const bf16_t*)A, lda, (const bf16_t*)B, ldb, (CT*)C, ldc, M, N, K, t2n, ep, full);
+        (const bf16_t*)A, lda, (const bf16_t*)B, ldb, (CT*)C, ldc, M, N, K, t2n, ep, full, 0);
     MV_CHECK_LAUNCH();
     return MV_OK;
   }
@@ -1572,7 +1862,7 @@ extern "C" int mv_gemm_nt_bf16_scaled(const void* A, int lda, const void* B, int
 
 extern "C" int mv_gemm_force_variant(int nt_variant, int tn_variant) {
   const bool nt_ok = nt_variant == 0 || nt_variant == 128 || nt_variant == 256 || nt_variant == 2564 || nt_variant == 2568 ||
-                     nt_variant == 25680;
+                     nt_variant == 25680 || nt_variant == 2569;
   const bool tn_ok = tn_variant == 0 || tn_variant == 128 || tn_variant == 256;
   MV_REQUIRE(nt_ok && tn_ok, MV_ERR_UNSUPPORTED);
   g_force_nt.store(nt_variant, std::memory_order_relaxed);

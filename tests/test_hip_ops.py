@@ -144,6 +144,45 @@ def test_gemm_nt_every_variant(ops, variant, M, N, K):
         check(lib().mv_gemm_force_variant(0, 0), "force_variant")
 
 
+@pytest.mark.parametrize("M,N,K", [(2816, 768, 256), (8192, 768, 768), (2048, 2304, 3072), (67584, 768, 256)])
+def test_gemm_nt_persistent_variant(ops, M, N, K):
+    """gemm_nt_8phase_persistent_kernel (one workgroup per CU walking whole tiles, stores draining under the next tile;
+    interior tiles only): NONE fp32/bf16 with and without bias, GELU and GELU_GRAD, against the one-item kernel and a
+    reference.  Grids from 33 tiles (fewer items than CUs) to 792 tiles (3+ tiles per workgroup, half-item tail)."""
+    from myrtle_vision.hip.lib import lib, check
+    a, w, b = bf(torch.randn(M, K, generator=g(1))), bf(torch.randn(N, K, generator=g(2)) * K ** -0.5), torch.randn(N, generator=g(3)) * 0.1
+    ad, wd = a.cuda(), w.float().cuda()
+    pre = (ad.float() @ wd.t()).double().cpu() + b.double()
+    outs = {}
+    for variant in (2569, 2568):
+        check(lib().mv_gemm_force_variant(variant, 0), "force_variant")
+        try:
+            o32 = torch.empty(M, N, device="cuda")
+            ops.linear_fwd(ad, M, K, wd, b.cuda(), o32, N)
+            o16 = torch.empty(M, N, device="cuda", dtype=torch.bfloat16)
+            ops.linear_fwd(ad, M, K, wd, None, o16, N)
+            act = torch.empty(M, N, device="cuda", dtype=torch.bfloat16)
+            gd = torch.empty(M, N, device="cuda", dtype=torch.bfloat16)
+            ops.linear_fwd(ad, M, K, wd, b.cuda(), act, N, epi=ops.EPI_GELU_GRAD, out2=gd, ld_out2=N)
+            act2 = torch.empty(M, N, device="cuda", dtype=torch.bfloat16)
+            h2 = torch.empty(M, N, device="cuda", dtype=torch.bfloat16)
+            ops.linear_fwd(ad, M, K, wd, b.cuda(), act2, N, epi=ops.EPI_GELU, out2=h2, ld_out2=N)
+            for _ in range(2):                                             # repeat launches: bit-identical (no race)
+                o32b = torch.empty(M, N, device="cuda")
+                ops.linear_fwd(ad, M, K, wd, b.cuda(), o32b, N)
+                assert torch.equal(o32, o32b)
+            outs[variant] = (o32, o16, act, gd, act2, h2)
+        finally:
+            check(lib().mv_gemm_force_variant(0, 0), "force_variant")
+    o32, o16, act, gd, act2, h2 = outs[2569]
+    assert relerr(o32, pre) < 1e-5
+    assert relerr(o16.float(), pre - b.double()) < 2.0 ** -8
+    assert relerr(act.float(), gelu_erf(pre)) < 2.0 ** -8 and relerr(gd.float(), dgelu64(pre)) < 2.0 ** -8
+    assert relerr(h2.float(), pre) < 2.0 ** -8
+    for x, y in zip(outs[2569], outs[2568]):                               # same arithmetic, same order: identical bits
+        assert torch.equal(x, y)
+
+
 @pytest.mark.parametrize("M,N,K", [(4859, 3584, 512), (4864, 3584, 768)])
 def test_gemm_nt_tail_split(ops, M, N, K):
     """266 tiles of 256x256 on 256 CUs: the 10 tail tiles run as 20 half items (128x256, quadrant-row 0 of the pipeline

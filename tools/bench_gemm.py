@@ -7,8 +7,18 @@ import torch
 from myrtle_vision.hip import ops
 
 M = int(os.environ.get("M", 50432))
+ROT = int(os.environ.get("ROTATE", "1"))       # ROTATE=4: cycle through 4 buffer sets (> Infinity Cache), as inside a real step
 dev = "cuda"
 def rnd(*s, dt=torch.bfloat16): return (torch.randn(*s, device=dev) * 0.5).to(dt)
+
+class Rot:
+    """fn factory over ROT independent buffer sets: call i uses set i % ROT."""
+    def __init__(self, make):
+        self.fns = [make() for _ in range(ROT)]
+        self.i = 0
+    def __call__(self):
+        self.fns[self.i % ROT]()
+        self.i += 1
 
 def timeit(fn, iters=10):
     for _ in range(3): fn()
@@ -36,17 +46,19 @@ rows = []
 for name, N, K, epi in [("qkv fwd", 2304, 768, "none"), ("proj fwd +res", 768, 768, "res"), ("fc1 fwd +gelu", 3072, 768, "gelu"),
                         ("fc1 fwd +gelu+grad", 3072, 768, "gelugrad"),
                         ("fc2 fwd +res", 768, 3072, "res"), ("plain bf16 out N=3072", 3072, 768, "none"), ("plain K=3072", 768, 3072, "none")]:
-    x, w, b = rnd(M, K), torch.randn(N, K, device=dev) * K ** -0.5, torch.randn(N, device=dev)
-    if epi == "none":
-        out = torch.empty(M, N, device=dev, dtype=torch.bfloat16)
-        f = lambda: ops.linear_fwd(x, M, K, w, b, out, N)
-    elif epi == "res":
-        out, res = torch.empty(M, N, device=dev), torch.randn(M, N, device=dev)
-        f = lambda: ops.linear_fwd(x, M, K, w, b, out, N, epi=ops.EPI_RESIDUAL, aux=res, ld_aux=N)
-    else:
+    w, b = torch.randn(N, K, device=dev) * K ** -0.5, torch.randn(N, device=dev)
+    def make(N=N, K=K, epi=epi, w=w, b=b):
+        x = rnd(M, K)
+        if epi == "none":
+            out = torch.empty(M, N, device=dev, dtype=torch.bfloat16)
+            return lambda: ops.linear_fwd(x, M, K, w, b, out, N)
+        if epi == "res":
+            out, res = torch.empty(M, N, device=dev), torch.randn(M, N, device=dev)
+            return lambda: ops.linear_fwd(x, M, K, w, b, out, N, epi=ops.EPI_RESIDUAL, aux=res, ld_aux=N)
         out, h = torch.empty(M, N, device=dev, dtype=torch.bfloat16), torch.empty(M, N, device=dev, dtype=torch.bfloat16)
         code = ops.EPI_GELU if epi == "gelu" else ops.EPI_GELU_GRAD
-        f = lambda: ops.linear_fwd(x, M, K, w, b, out, N, epi=code, out2=h, ld_out2=N)
+        return lambda: ops.linear_fwd(x, M, K, w, b, out, N, epi=code, out2=h, ld_out2=N)
+    f = Rot(make)
     tv = timeit_variants(f); rows.append((f"NT {name}", [2.0 * M * N * K / tv[v] / 1e12 for v in VARIANTS], tv[VARIANTS[-1]] * 1e6))
 for name, N, K, epi in [("dX qkv (N=768,K=2304)", 2304, 768, "none"), ("dX fc2 +dgelu (->3072)", 768, 3072, "dgelu"),
                         ("dX fc2 +mul   (->3072)", 768, 3072, "mul"), ("dX fc1 (K=3072)", 3072, 768, "none")]:
