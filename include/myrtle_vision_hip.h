@@ -57,7 +57,7 @@ int mv_version(void);
 const char* mv_error_string(int code);
 /* number of bytes of workspace mv_gemm_tn_bf16 / mv_layernorm_bwd want for these sizes */
 size_t mv_gemm_tn_workspace_bytes(int M, int N, int Kc);
-/* Tuning / test hook: force a kernel variant for the following mv_gemm_nt_bf16 (0 auto | 128 | 256 | 2564 ring | 2568
+/* Tuning / test hook (no reference counterpart): force a kernel variant for the following mv_gemm_nt_bf16 (0 auto | 128 | 256 | 2564 ring | 2568
  * 8-phase | 2569 persistent 8-phase) and mv_gemm_tn_bf16 (0 auto | 128 | 256 ring) calls of this process; a forced variant that cannot run a
  * shape (alignment of K) falls back to the automatic choice.  Results are identical up to fp32 summation order. */
 int mv_gemm_force_variant(int nt_variant, int tn_variant);
@@ -88,7 +88,9 @@ int mv_gemm_nt_bf16(const void* A, int lda, const void* B, int ldb, void* C, int
                     int K, const float* bias, int epilogue, const void* aux, int ld_aux, int aux_i, void* out2,
                     int ld_out2, mv_stream_t stream);
 /* the same with C = alpha * (A . B^T) (+ bias, epilogue): the integer-code products of the converted int8 path
- * (mv_quant_affine_codes), where alpha = scale_activation * scale_weight. */
+ * (mv_quant_affine_codes), where alpha = scale_activation * scale_weight.  Serves QFormat.PyTorchINT8 after convert()
+ * (utils/quantize.py:230-251, 329-338: torch.quantization.convert -> quantized::linear, which does not run in the
+ * reference; classification/test_quantize.py:26-34,145-156 is the caller). */
 int mv_gemm_nt_bf16_scaled(const void* A, int lda, const void* B, int ldb, void* C, int ldc, int c_dtype, int M, int N,
                            int K, float alpha, const float* bias, int epilogue, const void* aux, int ld_aux, int aux_i,
                            void* out2, int ld_out2, mv_stream_t stream);
@@ -153,7 +155,8 @@ int mv_quant_fixed(const float* x, float* y, long n, int wl, int fl, int clamp, 
 /* per-tensor affine fake-quant (MinMaxObserver qparams, utils/quantize.py:242-249) */
 int mv_quant_affine(const float* x, float* y, long n, float scale, int zero_point, int qmin, int qmax,
                     mv_stream_t stream);
-/* integer codes of the affine quantiser, re-centred: codes[r, c] = clamp(rint(x / scale) + zp, qmin, qmax) - zp as bf16
+/* (utils/quantize.py:242-249: MinMaxObserver quint8 affine activations / qint8 symmetric weights)
+ * integer codes of the affine quantiser, re-centred: codes[r, c] = clamp(rint(x / scale) + zp, qmin, qmax) - zp as bf16
  * (exact: |code| <= 256), rows ld elements apart with zeroed padding -- an MFMA operand whose products with another
  * code tensor, accumulated in fp32, are the exact integer dot products of real int8 inference. */
 int mv_quant_affine_codes(const float* x, void* codes, long rows, int cols, int ld, float scale, int zero_point, int qmin,
