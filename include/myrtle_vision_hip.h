@@ -139,6 +139,18 @@ int mv_cast(const void* src, int src_dtype, void* dst, int dst_dtype, long n, mv
 /* weight prep for the MFMA path: w fp32 [R, C] -> w_bf16 [R, ldw] and wt_bf16 [C, ldt] (transposed), pads zeroed;
  * either output may be NULL */
 int mv_weight_prep(const float* w, void* w_bf16, int ldw, void* wt_bf16, int ldt, int R, int C, mv_stream_t stream);
+/* the same for many weights in one launch (after an optimizer step every nn.Linear weight of the model is stale:
+ * vit.py:72-74,86,48-51 x depth).  ``items_device``: DEVICE array of ``count`` items sorted by first_block; item i covers
+ * blocks [first_block, first_block + tiles_x * tiles_y) with tiles_x = ceil(max(C, ldw) / 32), tiles_y = ceil(max(R, ldt)
+ * / 32); first_block of item 0 is 0 and total_blocks is the sum.  Both outputs of every item are required. */
+typedef struct mv_weight_prep_item {
+  const float* w;
+  void* w_bf16;
+  void* wt_bf16;
+  int ldw, ldt, R, C;
+  int tiles_x, first_block;
+} mv_weight_prep_item;
+int mv_weight_prep_batch(const mv_weight_prep_item* items_device, int count, int total_blocks, mv_stream_t stream);
 /* column sums (bias gradient): out[c] (+)= sum_r x[r, c]; x dtype x_dtype [rows, ld] */
 int mv_colsum(const void* x, int x_dtype, long ld, float* out, int accumulate, long rows, int cols, float* workspace,
               size_t workspace_bytes, mv_stream_t stream);

@@ -124,10 +124,8 @@ __global__ void cast_kernel(const S* __restrict__ src, T* __restrict__ dst, long
 }
 
 // w fp32 [R][C] -> wb bf16 [R][ldw] (pad columns zero) and wt bf16 [C][ldt] (pad zero).  32x32 tile through LDS.
-__global__ __launch_bounds__(256) void weight_prep_kernel(const float* __restrict__ w, bf16_t* wb, int ldw, bf16_t* wt,
-                                                          int ldt, int R, int C) {
-  __shared__ float tile[32][33];
-  const int r0 = blockIdx.y * 32, c0 = blockIdx.x * 32;
+__device__ __forceinline__ void weight_prep_tile(const float* __restrict__ w, bf16_t* wb, int ldw, bf16_t* wt, int ldt, int R,
+                                                 int C, int r0, int c0, float (*tile)[33]) {
   const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;  // 32 x 8
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
@@ -144,6 +142,25 @@ __global__ __launch_bounds__(256) void weight_prep_kernel(const float* __restric
       if (c < C && r < ldt) wt[(long)c * ldt + r] = (bf16_t)tile[tx][ty + 8 * i];
     }
   }
+}
+__global__ __launch_bounds__(256) void weight_prep_kernel(const float* __restrict__ w, bf16_t* wb, int ldw, bf16_t* wt,
+                                                          int ldt, int R, int C) {
+  __shared__ float tile[32][33];
+  weight_prep_tile(w, wb, ldw, wt, ldt, R, C, blockIdx.y * 32, blockIdx.x * 32, tile);
+}
+// All the Linear weights of a model in ONE launch (50 launches of ~7 us each per training step otherwise): block b
+// belongs to the item with the largest first_block <= b (binary search over the table, which is a few KB and L2-hot).
+__global__ __launch_bounds__(256) void weight_prep_batch_kernel(const mv_weight_prep_item* __restrict__ items, int count) {
+  __shared__ float tile[32][33];
+  const int b = blockIdx.x;
+  int lo = 0, hi = count - 1;
+  while (lo < hi) {
+    const int mid = (lo + hi + 1) >> 1;
+    if (items[mid].first_block <= b) lo = mid; else hi = mid - 1;
+  }
+  const mv_weight_prep_item it = items[lo];
+  const int t = b - it.first_block, ty = t / it.tiles_x, tx = t - ty * it.tiles_x;
+  weight_prep_tile(it.w, (bf16_t*)it.w_bf16, it.ldw, (bf16_t*)it.wt_bf16, it.ldt, it.R, it.C, ty * 32, tx * 32, tile);
 }
 
 template <typename T>
@@ -574,6 +591,16 @@ extern "C" int mv_weight_prep(const float* w, void* w_bf16, int ldw, void* wt_bf
   const int cols = (w_bf16 && ldw > C) ? ldw : C, rows = (wt_bf16 && ldt > R) ? ldt : R;
   dim3 grid(mv_cdiv(cols, 32), mv_cdiv(rows, 32));
   weight_prep_kernel<<<grid, 256, 0, S_>>>(w, (bf16_t*)w_bf16, ldw, (bf16_t*)wt_bf16, ldt, R, C);
+  MV_CHECK_LAUNCH();
+  return MV_OK;
+}
+
+extern "C" int mv_weight_prep_batch(const mv_weight_prep_item* items_device, int count, int total_blocks,
+                                    mv_stream_t stream) {
+  MV_REQUIRE(count >= 0 && total_blocks >= 0 && (count == 0) == (total_blocks == 0), MV_ERR_SHAPE);
+  if (count == 0) return MV_OK;
+  MV_REQUIRE(items_device != nullptr, MV_ERR_SHAPE);
+  weight_prep_batch_kernel<<<total_blocks, 256, 0, S_>>>(items_device, count);
   MV_CHECK_LAUNCH();
   return MV_OK;
 }

@@ -41,6 +41,7 @@ SIGNATURES = {
     "mv_gather_patch_rows": ("ppi" "iii" "p", _I),
     "mv_cast": ("pipi" "l" "p", _I),
     "mv_weight_prep": ("ppipi" "ii" "p", _I),
+    "mv_weight_prep_batch": ("pii" "p", _I),
     "mv_colsum": ("pil" "pi" "li" "pz" "p", _I),
     "mv_gelu_fwd": ("ppi" "l" "p", _I),
     "mv_gelu_bwd": ("pppi" "l" "p", _I),

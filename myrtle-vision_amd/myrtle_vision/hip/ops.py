@@ -7,6 +7,7 @@ streams.  CPU tensors are rejected: there is no CPU compute path in this package
 Precision: ``"bf16"`` = bf16 activations and weights on MFMA with fp32 accumulation and an fp32 residual stream
 (the benchmark configuration); ``"fp32"`` = every contraction in fp32 FMA chains (exact-parity mode).
 """
+import ctypes
 import weakref
 
 import torch
@@ -151,10 +152,48 @@ class PreparedWeight:
     """bf16 copies of one nn.Linear weight [N_out, K_in]: ``w`` [N_out, pad8(K_in)] for the forward product and
     ``wt`` [K_in, pad8(N_out)] (transposed) for the input-gradient product; pads are zero."""
 
-    __slots__ = ("w", "wt", "ldw", "ldt", "n_out", "k_in", "version", "ptr")
+    __slots__ = ("w", "wt", "ldw", "ldt", "n_out", "k_in", "version", "ptr", "ref")
+
+
+class _WeightPrepItem(ctypes.Structure):          # mv_weight_prep_item (include/myrtle_vision_hip.h)
+    _fields_ = [("w", ctypes.c_void_p), ("w_bf16", ctypes.c_void_p), ("wt_bf16", ctypes.c_void_p), ("ldw", ctypes.c_int),
+                ("ldt", ctypes.c_int), ("R", ctypes.c_int), ("C", ctypes.c_int), ("tiles_x", ctypes.c_int),
+                ("first_block", ctypes.c_int)]
 
 
 _prepared = {}   # id(parameter) -> PreparedWeight (identity-keyed: tensors define == elementwise); entries die with the tensor
+_prep_table = {}  # the last batch's item table on the device: key (ids, pointers) -> (uint8 tensor, count, total_blocks)
+
+
+def _refresh_stale(device):
+    """After an optimizer step EVERY prepared weight is stale: refresh them all in one launch (mv_weight_prep_batch)
+    instead of one ~7 us launch per nn.Linear at its first use."""
+    stale = []
+    for pw in _prepared.values():
+        w = pw.ref() if pw.ref is not None else None
+        if w is None or pw.w.device != device or not w.is_contiguous():
+            continue
+        if pw.version != w._version or pw.ptr != w.data_ptr():
+            stale.append((pw, w))
+    if not stale:
+        return
+    key = tuple((id(w), w.data_ptr(), pw.w.data_ptr()) for pw, w in stale)
+    ent = _prep_table.get(key)
+    if ent is None:
+        items = (_WeightPrepItem * len(stale))()
+        first = 0
+        for it, (pw, w) in zip(items, stale):
+            it.w, it.w_bf16, it.wt_bf16 = w.data_ptr(), pw.w.data_ptr(), pw.wt.data_ptr()
+            it.ldw, it.ldt, it.R, it.C = pw.ldw, pw.ldt, pw.n_out, pw.k_in
+            it.tiles_x, it.first_block = (max(pw.k_in, pw.ldw) + 31) // 32, first
+            first += it.tiles_x * ((max(pw.n_out, pw.ldt) + 31) // 32)
+        table = torch.frombuffer(bytearray(bytes(items)), dtype=torch.uint8).to(device)
+        _prep_table.clear()
+        ent = _prep_table[key] = (table, len(stale), first)
+    table, count, total = ent
+    check(lib().mv_weight_prep_batch(_p(table), count, total, _s()), "weight_prep_batch", count=count)
+    for pw, w in stale:
+        pw.version, pw.ptr = w._version, w.data_ptr()
 
 
 def prepared_weight(weight: torch.Tensor) -> PreparedWeight:
@@ -165,12 +204,17 @@ def prepared_weight(weight: torch.Tensor) -> PreparedWeight:
         return pw
     require_cuda(weight)
     n_out, k_in = weight.shape
+    if pw is not None and pw.n_out == n_out and pw.k_in == k_in and pw.w.device == weight.device and weight.is_contiguous():
+        _refresh_stale(weight.device)                       # this weight and every other stale one
+        if pw.version == weight._version and pw.ptr == weight.data_ptr():
+            return pw
     if pw is None or pw.n_out != n_out or pw.k_in != k_in or pw.w.device != weight.device:
         pw = PreparedWeight()
         pw.n_out, pw.k_in = n_out, k_in
         pw.ldw, pw.ldt = pad8(k_in), pad8(n_out)
         pw.w = torch.empty(n_out, pw.ldw, dtype=torch.bfloat16, device=weight.device)
         pw.wt = torch.empty(k_in, pw.ldt, dtype=torch.bfloat16, device=weight.device)
+        pw.ref = weakref.ref(weight)
         if key not in _prepared:
             weakref.finalize(weight, _prepared.pop, key, None)
         _prepared[key] = pw

@@ -410,6 +410,26 @@ def test_cast_weightprep_gelu_add(ops):
     assert torch.equal(ops.add_f32(h.cuda(), dy.cuda()).cpu(), h + dy)
 
 
+def test_weight_prep_batch_refreshes_every_stale_weight_in_one_launch(ops):
+    shapes = [(45, 192), (768, 768), (10, 3072), (1000, 71)]          # odd sizes: zero pads on either copy
+    ws = [torch.randn(r, c, generator=g(20 + i)).cuda() for i, (r, c) in enumerate(shapes)]
+    pws = [ops.prepared_weight(w) for w in ws]                        # first use: one mv_weight_prep each
+    for pw in pws:
+        pw.w.fill_(7.0)
+        pw.wt.fill_(7.0)                                              # poison, pads included
+    new = [torch.randn(r, c, generator=g(40 + i)) for i, (r, c) in enumerate(shapes)]
+    for w, n in zip(ws, new):
+        w.copy_(n)                                                    # in-place update bumps _version -> all stale
+    assert ops.prepared_weight(ws[2]) is pws[2]                       # one mv_weight_prep_batch over all four
+    for pw, w, n in zip(pws, ws, new):
+        assert pw.version == w._version                               # ... so the others are already fresh
+        r, c = n.shape
+        assert torch.equal(pw.w[:, :c].cpu(), bf(n)) and (pw.w[:, c:] == 0).all()
+        assert torch.equal(pw.wt[:, :r].cpu(), bf(n.t())) and (pw.wt[:, r:] == 0).all()
+    before = [pw.version for pw in pws]
+    assert ops.prepared_weight(ws[0]) is pws[0] and [pw.version for pw in pws] == before      # nothing stale: no work
+
+
 # ---------------------------------------------------------------- quantisers: bit-exact vs the oracle restatement
 def test_quant_float_bit_exact(ops):
     gg = g(7)
