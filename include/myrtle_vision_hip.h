@@ -141,8 +141,9 @@ int mv_cast(const void* src, int src_dtype, void* dst, int dst_dtype, long n, mv
 int mv_weight_prep(const float* w, void* w_bf16, int ldw, void* wt_bf16, int ldt, int R, int C, mv_stream_t stream);
 /* the same for many weights in one launch (after an optimizer step every nn.Linear weight of the model is stale:
  * vit.py:72-74,86,48-51 x depth).  ``items_device``: DEVICE array of ``count`` items sorted by first_block; item i covers
- * blocks [first_block, first_block + tiles_x * tiles_y) with tiles_x = ceil(max(C, ldw) / 32), tiles_y = ceil(max(R, ldt)
- * / 32); first_block of item 0 is 0 and total_blocks is the sum.  Both outputs of every item are required. */
+ * blocks [first_block, first_block + tiles_x * tiles_y) with tiles_x = ceil(max(C, ldw) / 64), tiles_y = ceil(max(R, ldt)
+ * / 64); first_block of item 0 is 0 and total_blocks is the sum.  Both outputs of every item are required; ldw and
+ * ldt even, w 8-byte and the outputs 4-byte aligned. */
 typedef struct mv_weight_prep_item {
   const float* w;
   void* w_bf16;

@@ -148,10 +148,52 @@ __global__ __launch_bounds__(256) void weight_prep_kernel(const float* __restric
   __shared__ float tile[32][33];
   weight_prep_tile(w, wb, ldw, wt, ldt, R, C, blockIdx.y * 32, blockIdx.x * 32, tile);
 }
+// 64x64 tile, two adjacent elements per lane: 8-byte loads (when the rows of w are 8-byte aligned, i.e. C even) and 4-byte
+// stores into both copies.  Needs ldw and ldt even (pad8 makes them multiples of 8).
+__device__ __forceinline__ void weight_prep_tile64(const float* __restrict__ w, bf16_t* __restrict__ wb, int ldw,
+                                                   bf16_t* __restrict__ wt, int ldt, int R, int C, int r0, int c0,
+                                                   float (*tile)[65]) {
+  typedef __attribute__((ext_vector_type(2))) bf16_t bf16x2;
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;  // 32 x 8
+  const bool v2 = (C & 1) == 0;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    const int r = r0 + ty + 8 * i, c = c0 + 2 * tx;
+    float a = 0.f, b = 0.f;
+    if (r < R) {
+      const float* p = w + (long)r * C + c;
+      if (v2 && c + 1 < C) {
+        const float2 v = *reinterpret_cast<const float2*>(p);
+        a = v.x;
+        b = v.y;
+      } else {
+        if (c < C) a = p[0];
+        if (c + 1 < C) b = p[1];
+      }
+    }
+    tile[ty + 8 * i][2 * tx] = a;
+    tile[ty + 8 * i][2 * tx + 1] = b;
+    if (wb && r < R && c < ldw) *reinterpret_cast<bf16x2*>(wb + (long)r * ldw + c) = bf16x2{(bf16_t)a, (bf16_t)b};
+  }
+  __syncthreads();
+  if (wt) {
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const int c = c0 + ty + 8 * i, r = r0 + 2 * tx;      // wt[c][r], wt[c][r + 1]
+      if (c < C && r < ldt)
+        *reinterpret_cast<bf16x2*>(wt + (long)c * ldt + r) = bf16x2{(bf16_t)tile[2 * tx][ty + 8 * i], (bf16_t)tile[2 * tx + 1][ty + 8 * i]};
+    }
+  }
+}
+__global__ __launch_bounds__(256) void weight_prep64_kernel(const float* __restrict__ w, bf16_t* wb, int ldw, bf16_t* wt,
+                                                            int ldt, int R, int C) {
+  __shared__ float tile[64][65];
+  weight_prep_tile64(w, wb, ldw, wt, ldt, R, C, blockIdx.y * 64, blockIdx.x * 64, tile);
+}
 // All the Linear weights of a model in ONE launch (50 launches of ~7 us each per training step otherwise): block b
 // belongs to the item with the largest first_block <= b (binary search over the table, which is a few KB and L2-hot).
 __global__ __launch_bounds__(256) void weight_prep_batch_kernel(const mv_weight_prep_item* __restrict__ items, int count) {
-  __shared__ float tile[32][33];
+  __shared__ float tile[64][65];
   const int b = blockIdx.x;
   int lo = 0, hi = count - 1;
   while (lo < hi) {
@@ -160,7 +202,7 @@ __global__ __launch_bounds__(256) void weight_prep_batch_kernel(const mv_weight_
   }
   const mv_weight_prep_item it = items[lo];
   const int t = b - it.first_block, ty = t / it.tiles_x, tx = t - ty * it.tiles_x;
-  weight_prep_tile(it.w, (bf16_t*)it.w_bf16, it.ldw, (bf16_t*)it.wt_bf16, it.ldt, it.R, it.C, ty * 32, tx * 32, tile);
+  weight_prep_tile64(it.w, (bf16_t*)it.w_bf16, it.ldw, (bf16_t*)it.wt_bf16, it.ldt, it.R, it.C, ty * 64, tx * 64, tile);
 }
 
 template <typename T>
@@ -589,8 +631,16 @@ extern "C" int mv_weight_prep(const float* w, void* w_bf16, int ldw, void* wt_bf
                               mv_stream_t stream) {
   MV_REQUIRE(R > 0 && C > 0 && (!w_bf16 || ldw >= C) && (!wt_bf16 || ldt >= R), MV_ERR_SHAPE);
   const int cols = (w_bf16 && ldw > C) ? ldw : C, rows = (wt_bf16 && ldt > R) ? ldt : R;
-  dim3 grid(mv_cdiv(cols, 32), mv_cdiv(rows, 32));
-  weight_prep_kernel<<<grid, 256, 0, S_>>>(w, (bf16_t*)w_bf16, ldw, (bf16_t*)wt_bf16, ldt, R, C);
+  const bool pairs = (!w_bf16 || ((ldw & 1) == 0 && (reinterpret_cast<uintptr_t>(w_bf16) & 3) == 0)) &&
+                     (!wt_bf16 || ((ldt & 1) == 0 && (reinterpret_cast<uintptr_t>(wt_bf16) & 3) == 0)) &&
+                     (reinterpret_cast<uintptr_t>(w) & 7) == 0;
+  if (pairs) {
+    dim3 grid(mv_cdiv(cols, 64), mv_cdiv(rows, 64));
+    weight_prep64_kernel<<<grid, 256, 0, S_>>>(w, (bf16_t*)w_bf16, ldw, (bf16_t*)wt_bf16, ldt, R, C);
+  } else {
+    dim3 grid(mv_cdiv(cols, 32), mv_cdiv(rows, 32));
+    weight_prep_kernel<<<grid, 256, 0, S_>>>(w, (bf16_t*)w_bf16, ldw, (bf16_t*)wt_bf16, ldt, R, C);
+  }
   MV_CHECK_LAUNCH();
   return MV_OK;
 }

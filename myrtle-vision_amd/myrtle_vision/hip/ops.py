@@ -185,8 +185,8 @@ def _refresh_stale(device):
         for it, (pw, w) in zip(items, stale):
             it.w, it.w_bf16, it.wt_bf16 = w.data_ptr(), pw.w.data_ptr(), pw.wt.data_ptr()
             it.ldw, it.ldt, it.R, it.C = pw.ldw, pw.ldt, pw.n_out, pw.k_in
-            it.tiles_x, it.first_block = (max(pw.k_in, pw.ldw) + 31) // 32, first
-            first += it.tiles_x * ((max(pw.n_out, pw.ldt) + 31) // 32)
+            it.tiles_x, it.first_block = (max(pw.k_in, pw.ldw) + 63) // 64, first
+            first += it.tiles_x * ((max(pw.n_out, pw.ldt) + 63) // 64)
         table = torch.frombuffer(bytearray(bytes(items)), dtype=torch.uint8).to(device)
         _prep_table.clear()
         ent = _prep_table[key] = (table, len(stale), first)
