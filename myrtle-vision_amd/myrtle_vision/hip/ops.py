@@ -169,7 +169,7 @@ def _refresh_stale(device):
     """After an optimizer step EVERY prepared weight is stale: refresh them all in one launch (mv_weight_prep_batch)
     instead of one ~7 us launch per nn.Linear at its first use."""
     stale = []
-    for pw in _prepared.values():
+    for pw in list(_prepared.values()):                      # a finalizer may pop entries while we look
         w = pw.ref() if pw.ref is not None else None
         if w is None or pw.w.device != device or not w.is_contiguous():
             continue
