@@ -99,6 +99,8 @@ def main():
                          "affine fake-quant at the Q8 sites after a 10-batch min/max calibration)")
     ap.add_argument("--seg-unfused", action="store_true", help="seg: vit(img) + cross_entropy instead of the fused tail")
     ap.add_argument("--no-optimizer", action="store_true", help="fwd+bwd only (section 8d: report with and without)")
+    ap.add_argument("--int8-bf16-attention", action="store_true",
+                    help="infer-int8: ViT.convert(bf16_attention=True) -- fused bf16 attention core instead of exact fp32")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timer", action="store_true")
     ap.add_argument("--timer-every", type=int, default=4,
@@ -166,7 +168,7 @@ def main():
         with torch.no_grad():
             for i in range(10):                                  # min/max calibration (test_quantize.py:26-34)
                 vit(torch.randn(64, 3, size, size, generator=g).to(dev))
-        vit.convert()
+        vit.convert(bf16_attention=args.int8_bf16_attention)
 
         def step():
             with torch.no_grad():
@@ -216,7 +218,8 @@ def main():
             "vs_baseline": None,
             "dtype": "int8 codes on bf16 MFMA, fp32 accumulate" if args.workload == "infer-int8" else args.precision,
             "data": "synthetic",
-            "config": {"workload": WORKLOAD[args.workload] + ("" if not args.no_optimizer else " [optimizer step OFF]"),
+            "config": {"workload": WORKLOAD[args.workload] + ("" if not args.no_optimizer else " [optimizer step OFF]")
+                       + (" [attention core: fused bf16 kernel]" if args.int8_bf16_attention else ""),
                        "per_gpu_batch": args.batch, "global_batch": args.batch * world,
                        "parallelism": f"dp{world}", "final_loss": round(final_loss, 4)},
         }

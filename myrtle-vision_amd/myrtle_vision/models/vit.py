@@ -162,6 +162,7 @@ class Attention(nn.Module):
 
         self.dequant_qkv = DeQuantStub()
         self.quant_out = QuantStub()
+        self.bf16_core = False             # set by ViT.convert(bf16_attention=True) (PyTorchINT8 only)
         # Identity layer kept so that a forward hook can collect attention maps (reference vit.py:80-82)
         self.attn_output = nn.Identity()
 
@@ -176,7 +177,13 @@ class Attention(nn.Module):
         # attention kernels (qkv stays [B, N, 3, H, dh])
         qkv = self.dequant_qkv(self.to_qkv(x))
         hook = self.attn_output if self.attn_output._forward_hooks else None
-        out = F.attention_core(qkv, self.heads, self.scale, hook)
+        if self.bf16_core and hook is None and qkv.dtype == torch.float32:
+            # converted PyTorchINT8 model, opted in by ViT.convert(bf16_attention=True): q, k, v come out of an 8-bit
+            # Linear and the result goes straight into the next 8-bit quantiser, so the fused bf16 kernel (fp32 softmax
+            # statistics) is finer than either neighbour; the exact fp32 products it replaces are 45 % of the forward pass
+            out = F.cast(F.attention_core(F.cast(qkv, torch.bfloat16), self.heads, self.scale, None), torch.float32)
+        else:
+            out = F.attention_core(qkv, self.heads, self.scale, hook)
         out = self.quant_out(out)
         out = self.to_out(out)
         return out
@@ -381,8 +388,17 @@ class ViT(nn.Module):
         pos = self.pos_embedding_cat.post(self._pos_embedding(gh, gw))   # the reference's cat of (cls slot, grid)
         return self.pos_embedding_add.add(x, self.quant_pos_embedding(pos.repeat(b_dim, 1, 1)))
 
-    def convert(self) -> None:
+    def convert(self, bf16_attention: bool = False) -> None:
+        """reference vit.py ``convert()``.  Extension (off by default, PyTorchINT8 only): ``bf16_attention=True`` runs the
+        attention core of the converted model on the fused bf16 kernel instead of the exact fp32 products -- a bf16-mode
+        approximation (2^-9 relative on q, k, v and P) between two 8-bit quantisers, 1.6x faster end to end."""
         self.quantizer.convert()
+        if bf16_attention:
+            if not any(type(m).__name__ == "Int8Linear" for m in self.modules()):
+                raise ValueError("bf16_attention applies to converted PyTorchINT8 models only")
+            for m in self.modules():
+                if isinstance(m, Attention):
+                    m.bf16_core = True
 
 
 # ---- reference vit.py:325-342 -------------------------------------------------------------------------------

@@ -611,3 +611,11 @@ def test_int8_converted_model_fast_path_equals_fake_quant_path():
     assert slow.requires_grad and not fast.requires_grad
     assert relerr(fast, slow.detach().double().cpu()) < 1e-4
     assert torch.equal(fast.argmax(1), slow.argmax(1))
+    # opt-in: attention core on the fused bf16 kernel (ViT.convert(bf16_attention=True)); bf16-mode envelope
+    from myrtle_vision.models.vit import Attention
+    for m in vit.modules():
+        if isinstance(m, Attention):
+            m.bf16_core = True
+    with torch.no_grad():
+        approx = vit(img)
+    assert approx.dtype == torch.float32 and 0 < relerr(approx, fast.double().cpu()) < 3e-2
