@@ -171,9 +171,11 @@ int mv_quant_affine(const float* x, float* y, long n, float scale, int zero_poin
 /* (utils/quantize.py:242-249: MinMaxObserver quint8 affine activations / qint8 symmetric weights)
  * integer codes of the affine quantiser, re-centred: codes[r, c] = clamp(rint(x / scale) + zp, qmin, qmax) - zp as bf16
  * (exact: |code| <= 256), rows ld elements apart with zeroed padding -- an MFMA operand whose products with another
- * code tensor, accumulated in fp32, are the exact integer dot products of real int8 inference. */
+ * code tensor, accumulated in fp32, are the exact integer dot products of real int8 inference.
+ * pre_op 1: x is passed through GELU (erf form) first -- FeedForward's nn.GELU between its two quantised Linears
+ * (vit.py:48-51) without the fp32 round trip; 0: none. */
 int mv_quant_affine_codes(const float* x, void* codes, long rows, int cols, int ld, float scale, int zero_point, int qmin,
-                          int qmax, mv_stream_t stream);
+                          int qmax, int pre_op, mv_stream_t stream);
 /* running min/max observer: minmax[0] = min(minmax[0], min x), minmax[1] = max(minmax[1], max x);
  * minmax points at FOUR floats: [2..3] are scratch for the reduction */
 int mv_minmax(const float* x, long n, float* minmax, mv_stream_t stream);

@@ -287,19 +287,42 @@ __global__ void quant_affine_kernel(const float* __restrict__ x, float* __restri
 // [qmin - zp, qmax - zp] (|c| <= 255 for 8-bit), written as bf16 -- exactly representable, so a bf16 MFMA GEMM of two
 // code tensors with fp32 accumulation IS the integer dot product (mv_gemm_nt_bf16_scaled applies scale_x * scale_w).
 // Rows are written with leading dimension ld (>= cols, padding zeroed) so the result is a valid MFMA operand.
+template <int PRE>  // PRE = 1: GELU (erf form, the unfused gelu kernel's function) applied to x first
+__device__ __forceinline__ float affine_code_one(float x, float inv, float zp, float qmin, float qmax) {
+  if (PRE == 1) x = gelu_f(x);
+  float q = rintf(x * inv) + zp;
+  q = fminf(fmaxf(q, qmin), qmax);
+  return q - zp;
+}
+template <int PRE>
 __global__ void quant_affine_codes_kernel(const float* __restrict__ x, bf16_t* __restrict__ y, long rows, int cols, int ld,
                                           float inv, int zp, int qmin, int qmax) {
   const long n = rows * ld;
   for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
     const long r = i / ld;
     const int c = (int)(i - r * ld);
-    float v = 0.f;
-    if (c < cols) {
-      float q = rintf(x[r * cols + c] * inv) + (float)zp;
-      q = fminf(fmaxf(q, (float)qmin), (float)qmax);
-      v = q - (float)zp;
+    y[i] = (bf16_t)(c < cols ? affine_code_one<PRE>(x[r * cols + c], inv, (float)zp, (float)qmin, (float)qmax) : 0.f);
+  }
+}
+// cols % 4 == 0 and ld % 4 == 0: one row per block iteration, 16-byte loads and 8-byte stores, no division
+template <int PRE>
+__global__ __launch_bounds__(256) void quant_affine_codes_vec_kernel(const float* __restrict__ x, bf16_t* __restrict__ y,
+                                                                     long rows, int cols, int ld, float inv, int zp,
+                                                                     int qmin, int qmax) {
+  const float fz = (float)zp, lo = (float)qmin, hi = (float)qmax;
+  const int c4 = cols >> 2, l4 = ld >> 2;
+  for (long r = blockIdx.x; r < rows; r += gridDim.x) {
+    const float4* xr = reinterpret_cast<const float4*>(x + r * cols);
+    bf16x4* yr = reinterpret_cast<bf16x4*>(y + r * ld);
+    for (int j = threadIdx.x; j < l4; j += 256) {
+      bf16x4 o = {(bf16_t)0.f, (bf16_t)0.f, (bf16_t)0.f, (bf16_t)0.f};
+      if (j < c4) {
+        const float4 v = xr[j];
+        o = bf16x4{(bf16_t)affine_code_one<PRE>(v.x, inv, fz, lo, hi), (bf16_t)affine_code_one<PRE>(v.y, inv, fz, lo, hi),
+                   (bf16_t)affine_code_one<PRE>(v.z, inv, fz, lo, hi), (bf16_t)affine_code_one<PRE>(v.w, inv, fz, lo, hi)};
+      }
+      yr[j] = o;
     }
-    y[i] = (bf16_t)v;
   }
 }
 
@@ -721,12 +744,24 @@ extern "C" int mv_quant_affine(const float* x, float* y, long n, float scale, in
 }
 
 extern "C" int mv_quant_affine_codes(const float* x, void* codes, long rows, int cols, int ld, float scale, int zero_point,
-                                     int qmin, int qmax, mv_stream_t stream) {
+                                     int qmin, int qmax, int pre_op, mv_stream_t stream) {
   MV_REQUIRE(rows >= 0 && cols > 0 && ld >= cols && scale > 0.f && qmin < qmax, MV_ERR_SHAPE);
   MV_REQUIRE(qmax - zero_point <= 256 && zero_point - qmin <= 256, MV_ERR_UNSUPPORTED);     // exact in bf16
+  MV_REQUIRE(pre_op == 0 || pre_op == 1, MV_ERR_UNSUPPORTED);
   if (rows == 0) return MV_OK;
-  quant_affine_codes_kernel<<<ew_grid(rows * ld), 256, 0, S_>>>(x, (bf16_t*)codes, rows, cols, ld, 1.0f / scale, zero_point,
-                                                                qmin, qmax);
+  const float inv = 1.0f / scale;
+  const bool vec = (cols & 3) == 0 && (ld & 3) == 0 && mv_aligned16(x) && (reinterpret_cast<uintptr_t>(codes) & 7) == 0;
+  if (vec) {
+    const int grid = rows < 65536 ? (int)rows : 65536;
+    if (pre_op)
+      quant_affine_codes_vec_kernel<1><<<grid, 256, 0, S_>>>(x, (bf16_t*)codes, rows, cols, ld, inv, zero_point, qmin, qmax);
+    else
+      quant_affine_codes_vec_kernel<0><<<grid, 256, 0, S_>>>(x, (bf16_t*)codes, rows, cols, ld, inv, zero_point, qmin, qmax);
+  } else if (pre_op) {
+    quant_affine_codes_kernel<1><<<ew_grid(rows * ld), 256, 0, S_>>>(x, (bf16_t*)codes, rows, cols, ld, inv, zero_point, qmin, qmax);
+  } else {
+    quant_affine_codes_kernel<0><<<ew_grid(rows * ld), 256, 0, S_>>>(x, (bf16_t*)codes, rows, cols, ld, inv, zero_point, qmin, qmax);
+  }
   MV_CHECK_LAUNCH();
   return MV_OK;
 }

@@ -495,13 +495,15 @@ def quant_affine(x, scale, zero_point, qmin, qmax):
     return y
 
 
-def quant_affine_codes(x, rows, cols, scale, zero_point, qmin, qmax):
-    """fp32 [rows, cols] -> bf16 [rows, pad8(cols)] integer codes (q - zero_point) of the affine quantiser (exact)."""
+def quant_affine_codes(x, rows, cols, scale, zero_point, qmin, qmax, pre_gelu=False):
+    """fp32 [rows, cols] -> bf16 [rows, pad8(cols)] integer codes (q - zero_point) of the affine quantiser (exact);
+    ``pre_gelu``: of gelu(x)."""
     require_cuda(x)
     xf = x.detach().float().contiguous()
     ld = pad8(cols)
     codes = torch.empty(rows, ld, dtype=torch.bfloat16, device=x.device)
-    check(lib().mv_quant_affine_codes(_p(xf), _p(codes), rows, cols, ld, float(scale), int(zero_point), qmin, qmax, _s()),
+    check(lib().mv_quant_affine_codes(_p(xf), _p(codes), rows, cols, ld, float(scale), int(zero_point), qmin, qmax,
+                                      1 if pre_gelu else 0, _s()),
           "quant_affine_codes", rows=rows, cols=cols)
     return codes
 

@@ -143,6 +143,14 @@ class FeedForward(nn.Module):
                                                  and not n[i]._forward_hooks for i in (2, 4)))
 
     def forward(self, x: torch.Tensor):
+        n = self.net
+        if (type(n[0]).__name__ == "Int8Linear" and type(n[3]).__name__ == "Int8Linear" and _plain(n[1], GELU)
+                and not any(m._forward_hooks or m._forward_pre_hooks for m in (n, n[0], n[3]))
+                and all(type(n[i]) is Dropout and (n[i].p == 0.0 or not n[i].training) and not n[i]._forward_hooks
+                        for i in (2, 4))):
+            # converted PyTorchINT8 MLP: nn.GELU is applied inside fc2's input quantiser (one pass over the hidden
+            # activations instead of GELU fp32 -> fp32 followed by quantise fp32 -> codes); same numbers
+            return n[3](n[0](x), pre_gelu=True)
         return self.net(x)
 
 

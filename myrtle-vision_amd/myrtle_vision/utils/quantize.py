@@ -264,16 +264,19 @@ class Int8Linear(nn.Linear):
         lin.weight_codes = codes
         return lin
 
-    def forward(self, x):
+    def forward(self, x, pre_gelu=False):
+        """``pre_gelu``: the input is gelu(x) -- FeedForward folds its nn.GELU into this layer's input quantiser."""
         s_x, z_x = self.act_observer.frozen
         if torch.is_grad_enabled() and (x.requires_grad or self.weight.requires_grad):
+            if pre_gelu:
+                x = F.gelu(x)
             return _hip_linear(self.act_observer(x), self.weight, self.bias, torch.float32)     # fake-quant STE path
         ops.require_cuda(x)
         K = x.shape[-1]
         N = self.weight.shape[0]
         x2 = x.reshape(-1, K)
         M = x2.shape[0]
-        xc = ops.quant_affine_codes(x2, M, K, s_x, z_x, self.act_observer.qmin, self.act_observer.qmax)
+        xc = ops.quant_affine_codes(x2, M, K, s_x, z_x, self.act_observer.qmin, self.act_observer.qmax, pre_gelu=pre_gelu)
         out = torch.empty(M, N, dtype=torch.float32, device=x.device)
         ops.linear_codes(xc, self.weight_codes, M, N, K, s_x * self.weight_scale, self.bias, out)
         return out.view(*x.shape[:-1], N)

@@ -576,6 +576,9 @@ def test_int8_codes_gemm_equals_fake_quant_linear(ops, M, N, K):
     wq = torch.fake_quantize_per_tensor_affine(w, s_w, 0, -128, 127)
     want = torch.nn.functional.linear(xq.double(), wq.double(), b.double())
     xc = ops.quant_affine_codes(x.cuda(), M, K, s_x, z_x, 0, 255)
+    # the GELU pre-op is the unfused gelu followed by the same quantiser, bit for bit
+    assert torch.equal(ops.quant_affine_codes(x.cuda(), M, K, s_x, z_x, 0, 255, pre_gelu=True),
+                       ops.quant_affine_codes(ops.gelu_fwd(x.cuda()), M, K, s_x, z_x, 0, 255))
     assert xc.shape == (M, (K + 7) & ~7) and xc.dtype == torch.bfloat16
     codes = xc[:, :K].float().cpu()
     assert torch.equal(codes, torch.round(xq / s_x))                     # the integer (q - z), exactly
