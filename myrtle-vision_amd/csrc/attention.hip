@@ -95,7 +95,7 @@ __device__ __forceinline__ void stage_kv_dma(const bf16_t* base, long D, int N, 
 // forward: one 256-thread workgroup per (image, head); waves take 16-query tiles round-robin
 // ------------------------------------------------------------------------------------------------
 template <int NKT>
-__global__ __launch_bounds__(256, (NKT <= 14 ? 2 : 1)) void attn_fwd_kernel(const bf16_t* __restrict__ qkv, bf16_t* __restrict__ out,
+__global__ __launch_bounds__(256, (NKT <= 18 ? 2 : 1)) void attn_fwd_kernel(const bf16_t* __restrict__ qkv, bf16_t* __restrict__ out,
                                                           float* __restrict__ lse, int N, int H, float scale_log2e) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr int NP = NKT * 16;
@@ -647,6 +647,10 @@ extern "C" int mv_attention_fwd(const void* qkv, void* out, float* lse, int B, i
     static const int a = set_smem(attn_fwd_kernel<14>, fwd_smem(14));
     if (a) return MV_ERR_LAUNCH;
     attn_fwd_kernel<14><<<B * H, 256, fwd_smem(14), s>>>((const bf16_t*)qkv, (bf16_t*)out, lse, N, H, sl);
+  } else if (N <= 288) {                   // 257 tokens at 256^2: 18 key tiles = 73.7 KB of K/V, still two workgroups per CU
+    static const int a = set_smem(attn_fwd_kernel<18>, fwd_smem(18));
+    if (a) return MV_ERR_LAUNCH;
+    attn_fwd_kernel<18><<<B * H, 256, fwd_smem(18), s>>>((const bf16_t*)qkv, (bf16_t*)out, lse, N, H, sl);
   } else {
     static const int a = set_smem(attn_fwd_kernel<20>, fwd_smem(20));
     if (a) return MV_ERR_LAUNCH;

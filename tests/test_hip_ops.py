@@ -330,7 +330,7 @@ def attn_ref(qkv, H, scale):
     return (p @ v).transpose(1, 2).reshape(B, N, H * dh), p
 
 
-@pytest.mark.parametrize("B,N,H", [(2, 197, 3), (1, 257, 2), (3, 50, 1), (1, 17, 12), (2, 216, 2), (1, 208, 1)])
+@pytest.mark.parametrize("B,N,H", [(2, 197, 3), (1, 257, 2), (3, 50, 1), (1, 17, 12), (2, 216, 2), (1, 208, 1), (1, 288, 1), (1, 300, 2)])
 def test_attention_fused_fwd_bwd(ops, B, N, H):
     scale = 64 ** -0.5
     qkv = bf(torch.randn(B, N, 3 * H * 64, generator=g(1)) * 1.5)
