@@ -234,7 +234,10 @@ def main():
                                    "frac": round(k["tflops"] / BF16_DENSE_PEAK_TFLOPS, 4), "traffic": pmc_traffic("gemm_nt"),
                                    "launches": k["launches"], "timed_steps": f"every {args.timer_every}th of {args.steps}",
                                    "avg_launch_us": round(k["avg_us"], 1),
-                                   "gflop_per_launch": round(k["flops_per_launch"] / 1e9, 2)}
+                                   "gflop_per_launch": round(k["flops_per_launch"] / 1e9, 2),
+                                   # measured on this board class (profiles/r01_clock_power.md): what the 1400 W cap lets
+                                   # an MFMA stream on random bf16 operands sustain -- context for frac, not its denominator
+                                   "power_capped_tflops": {"mfma_from_registers": 1930, "mfma_fed_from_lds": 1600}}
             nt_steps = len(range(0, args.steps, max(args.timer_every, 1)))
             out["kernels"] = {n: {"launches": v["launches"], "avg_us": round(v["avg_us"], 1), "tflops": round(v["tflops"], 1),
                                   "ms_per_step": round(v["total_ms"] / nt_steps, 3)} for n, v in summ.items()}
