@@ -79,6 +79,18 @@ def _plain(module, cls):
     return type(module) is cls and not module._forward_hooks and not module._forward_pre_hooks
 
 
+def _int8_linear(m):
+    """The converted PyTorchINT8 Linear behind ``m`` -- ``Int8Linear`` itself or ModelQuantizer's
+    ``Sequential(QuantStub [passthrough], Int8Linear)`` wrapper -- if nothing hooks into it; else None."""
+    if isinstance(m, nn.Sequential) and len(m) == 2 and getattr(m[0], "passthrough", False):
+        if m._forward_hooks or m._forward_pre_hooks or m[0]._forward_hooks or m[0]._forward_pre_hooks:
+            return None
+        m = m[1]
+    if type(m).__name__ != "Int8Linear" or m._forward_hooks or m._forward_pre_hooks:
+        return None
+    return m
+
+
 # ---- reference vit.py:17-27 ---------------------------------------------------------------------------------
 class Residual(nn.Module):
     def __init__(self, fn: nn.Module):
@@ -144,13 +156,13 @@ class FeedForward(nn.Module):
 
     def forward(self, x: torch.Tensor):
         n = self.net
-        if (type(n[0]).__name__ == "Int8Linear" and type(n[3]).__name__ == "Int8Linear" and _plain(n[1], GELU)
-                and not any(m._forward_hooks or m._forward_pre_hooks for m in (n, n[0], n[3]))
+        fc1, fc2 = _int8_linear(n[0]), _int8_linear(n[3])
+        if (fc1 is not None and fc2 is not None and _plain(n[1], GELU) and not n._forward_hooks and not n._forward_pre_hooks
                 and all(type(n[i]) is Dropout and (n[i].p == 0.0 or not n[i].training) and not n[i]._forward_hooks
                         for i in (2, 4))):
             # converted PyTorchINT8 MLP: nn.GELU is applied inside fc2's input quantiser (one pass over the hidden
             # activations instead of GELU fp32 -> fp32 followed by quantise fp32 -> codes); same numbers
-            return n[3](n[0](x), pre_gelu=True)
+            return fc2(fc1(x), pre_gelu=True)
         return self.net(x)
 
 

@@ -614,6 +614,23 @@ def test_int8_converted_model_fast_path_equals_fake_quant_path():
     assert slow.requires_grad and not fast.requires_grad
     assert relerr(fast, slow.detach().double().cpu()) < 1e-4
     assert torch.equal(fast.argmax(1), slow.argmax(1))
+    # FeedForward folds nn.GELU into fc2's input quantiser: taken (2 blocks), and bit-identical to the unfolded path
+    from myrtle_vision.hip import ops as _ops
+    from myrtle_vision.models.vit import GELU
+    seen, orig = [], _ops.quant_affine_codes
+    _ops.quant_affine_codes = lambda *a, **k: (seen.append(k.get("pre_gelu", False)), orig(*a, **k))[1]
+    try:
+        with torch.no_grad():
+            assert torch.equal(vit(img), fast) and sum(seen) == 2
+        hooks = [m.register_forward_hook(lambda mod, i, o: None) for m in vit.modules() if isinstance(m, GELU)]
+        seen.clear()
+        with torch.no_grad():
+            unfolded = vit(img)
+        assert sum(seen) == 0 and torch.equal(unfolded, fast)
+        for h in hooks:
+            h.remove()
+    finally:
+        _ops.quant_affine_codes = orig
     # opt-in: attention core on the fused bf16 kernel (ViT.convert(bf16_attention=True)); bf16-mode envelope
     from myrtle_vision.models.vit import Attention
     for m in vit.modules():
