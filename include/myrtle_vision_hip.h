@@ -172,10 +172,10 @@ int mv_quant_affine(const float* x, float* y, long n, float scale, int zero_poin
  * integer codes of the affine quantiser, re-centred: codes[r, c] = clamp(rint(x / scale) + zp, qmin, qmax) - zp as bf16
  * (exact: |code| <= 256), rows ld elements apart with zeroed padding -- an MFMA operand whose products with another
  * code tensor, accumulated in fp32, are the exact integer dot products of real int8 inference.
- * pre_op 1: x is passed through GELU (erf form) first -- FeedForward's nn.GELU between its two quantised Linears
+ * x_dtype: MV_F32 or MV_BF16 (the fused attention kernel's output).  pre_op 1: x is passed through GELU (erf form) first -- FeedForward's nn.GELU between its two quantised Linears
  * (vit.py:48-51) without the fp32 round trip; 0: none. */
-int mv_quant_affine_codes(const float* x, void* codes, long rows, int cols, int ld, float scale, int zero_point, int qmin,
-                          int qmax, int pre_op, mv_stream_t stream);
+int mv_quant_affine_codes(const void* x, int x_dtype, void* codes, long rows, int cols, int ld, float scale, int zero_point,
+                          int qmin, int qmax, int pre_op, mv_stream_t stream);
 /* running min/max observer: minmax[0] = min(minmax[0], min x), minmax[1] = max(minmax[1], max x);
  * minmax points at FOUR floats: [2..3] are scratch for the reduction */
 int mv_minmax(const float* x, long n, float* minmax, mv_stream_t stream);

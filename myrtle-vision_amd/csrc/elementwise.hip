@@ -294,30 +294,36 @@ __device__ __forceinline__ float affine_code_one(float x, float inv, float zp, f
   q = fminf(fmaxf(q, qmin), qmax);
   return q - zp;
 }
-template <int PRE>
-__global__ void quant_affine_codes_kernel(const float* __restrict__ x, bf16_t* __restrict__ y, long rows, int cols, int ld,
+template <int PRE, typename XT>
+__global__ void quant_affine_codes_kernel(const XT* __restrict__ x, bf16_t* __restrict__ y, long rows, int cols, int ld,
                                           float inv, int zp, int qmin, int qmax) {
   const long n = rows * ld;
   for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
     const long r = i / ld;
     const int c = (int)(i - r * ld);
-    y[i] = (bf16_t)(c < cols ? affine_code_one<PRE>(x[r * cols + c], inv, (float)zp, (float)qmin, (float)qmax) : 0.f);
+    y[i] = (bf16_t)(c < cols ? affine_code_one<PRE>((float)x[r * cols + c], inv, (float)zp, (float)qmin, (float)qmax) : 0.f);
   }
 }
 // cols % 4 == 0 and ld % 4 == 0: one row per block iteration, 16-byte loads and 8-byte stores, no division
-template <int PRE>
-__global__ __launch_bounds__(256) void quant_affine_codes_vec_kernel(const float* __restrict__ x, bf16_t* __restrict__ y,
+template <int PRE, typename XT>
+__global__ __launch_bounds__(256) void quant_affine_codes_vec_kernel(const XT* __restrict__ x, bf16_t* __restrict__ y,
                                                                      long rows, int cols, int ld, float inv, int zp,
                                                                      int qmin, int qmax) {
   const float fz = (float)zp, lo = (float)qmin, hi = (float)qmax;
   const int c4 = cols >> 2, l4 = ld >> 2;
   for (long r = blockIdx.x; r < rows; r += gridDim.x) {
-    const float4* xr = reinterpret_cast<const float4*>(x + r * cols);
+    const XT* xr = x + r * cols;
     bf16x4* yr = reinterpret_cast<bf16x4*>(y + r * ld);
     for (int j = threadIdx.x; j < l4; j += 256) {
       bf16x4 o = {(bf16_t)0.f, (bf16_t)0.f, (bf16_t)0.f, (bf16_t)0.f};
       if (j < c4) {
-        const float4 v = xr[j];
+        float4 v;
+        if constexpr (sizeof(XT) == 4) {
+          v = reinterpret_cast<const float4*>(xr)[j];
+        } else {
+          const bf16x4 h = reinterpret_cast<const bf16x4*>(xr)[j];
+          v = make_float4((float)h[0], (float)h[1], (float)h[2], (float)h[3]);
+        }
         o = bf16x4{(bf16_t)affine_code_one<PRE>(v.x, inv, fz, lo, hi), (bf16_t)affine_code_one<PRE>(v.y, inv, fz, lo, hi),
                    (bf16_t)affine_code_one<PRE>(v.z, inv, fz, lo, hi), (bf16_t)affine_code_one<PRE>(v.w, inv, fz, lo, hi)};
       }
@@ -743,27 +749,35 @@ extern "C" int mv_quant_affine(const float* x, float* y, long n, float scale, in
   return MV_OK;
 }
 
-extern "C" int mv_quant_affine_codes(const float* x, void* codes, long rows, int cols, int ld, float scale, int zero_point,
-                                     int qmin, int qmax, int pre_op, mv_stream_t stream) {
-  MV_REQUIRE(rows >= 0 && cols > 0 && ld >= cols && scale > 0.f && qmin < qmax, MV_ERR_SHAPE);
-  MV_REQUIRE(qmax - zero_point <= 256 && zero_point - qmin <= 256, MV_ERR_UNSUPPORTED);     // exact in bf16
-  MV_REQUIRE(pre_op == 0 || pre_op == 1, MV_ERR_UNSUPPORTED);
-  if (rows == 0) return MV_OK;
-  const float inv = 1.0f / scale;
+template <typename XT>
+static int launch_quant_codes(const XT* x, void* codes, long rows, int cols, int ld, float inv, int zero_point, int qmin,
+                              int qmax, int pre_op, hipStream_t s) {
   const bool vec = (cols & 3) == 0 && (ld & 3) == 0 && mv_aligned16(x) && (reinterpret_cast<uintptr_t>(codes) & 7) == 0;
   if (vec) {
     const int grid = rows < 65536 ? (int)rows : 65536;
     if (pre_op)
-      quant_affine_codes_vec_kernel<1><<<grid, 256, 0, S_>>>(x, (bf16_t*)codes, rows, cols, ld, inv, zero_point, qmin, qmax);
+      quant_affine_codes_vec_kernel<1, XT><<<grid, 256, 0, s>>>(x, (bf16_t*)codes, rows, cols, ld, inv, zero_point, qmin, qmax);
     else
-      quant_affine_codes_vec_kernel<0><<<grid, 256, 0, S_>>>(x, (bf16_t*)codes, rows, cols, ld, inv, zero_point, qmin, qmax);
+      quant_affine_codes_vec_kernel<0, XT><<<grid, 256, 0, s>>>(x, (bf16_t*)codes, rows, cols, ld, inv, zero_point, qmin, qmax);
   } else if (pre_op) {
-    quant_affine_codes_kernel<1><<<ew_grid(rows * ld), 256, 0, S_>>>(x, (bf16_t*)codes, rows, cols, ld, inv, zero_point, qmin, qmax);
+    quant_affine_codes_kernel<1, XT><<<ew_grid(rows * ld), 256, 0, s>>>(x, (bf16_t*)codes, rows, cols, ld, inv, zero_point, qmin, qmax);
   } else {
-    quant_affine_codes_kernel<0><<<ew_grid(rows * ld), 256, 0, S_>>>(x, (bf16_t*)codes, rows, cols, ld, inv, zero_point, qmin, qmax);
+    quant_affine_codes_kernel<0, XT><<<ew_grid(rows * ld), 256, 0, s>>>(x, (bf16_t*)codes, rows, cols, ld, inv, zero_point, qmin, qmax);
   }
   MV_CHECK_LAUNCH();
   return MV_OK;
+}
+
+extern "C" int mv_quant_affine_codes(const void* x, int x_dtype, void* codes, long rows, int cols, int ld, float scale,
+                                     int zero_point, int qmin, int qmax, int pre_op, mv_stream_t stream) {
+  MV_REQUIRE(rows >= 0 && cols > 0 && ld >= cols && scale > 0.f && qmin < qmax, MV_ERR_SHAPE);
+  MV_REQUIRE(qmax - zero_point <= 256 && zero_point - qmin <= 256, MV_ERR_UNSUPPORTED);     // exact in bf16
+  MV_REQUIRE((pre_op == 0 || pre_op == 1) && (x_dtype == MV_F32 || x_dtype == MV_BF16), MV_ERR_UNSUPPORTED);
+  if (rows == 0) return MV_OK;
+  const float inv = 1.0f / scale;
+  if (x_dtype == MV_F32)
+    return launch_quant_codes((const float*)x, codes, rows, cols, ld, inv, zero_point, qmin, qmax, pre_op, S_);
+  return launch_quant_codes((const bf16_t*)x, codes, rows, cols, ld, inv, zero_point, qmin, qmax, pre_op, S_);
 }
 
 extern "C" int mv_minmax(const float* x, long n, float* minmax, mv_stream_t stream) {

@@ -28,7 +28,7 @@ SIGNATURES = {
     "mv_layernorm_bwd": ("pi" "plp" "pp" "ppl" "ppi" "pz" "ii" "pp" "p", _I),
     "mv_gemm_nt_bf16": ("pipipii" "iii" "pi" "pii" "pi" "p", _I),
     "mv_gemm_nt_bf16_scaled": ("pipipii" "iii" "f" "pi" "pii" "pi" "p", _I),
-    "mv_quant_affine_codes": ("pp" "lii" "f" "iiii" "p", _I),
+    "mv_quant_affine_codes": ("pip" "lii" "f" "iiii" "p", _I),
     "mv_gemm_tn_bf16": ("pipipi" "iii" "i" "p" "pz" "p", _I),
     "mv_gemm_f32": ("pllll" "pllll" "pllll" "iii" "ii" "fi" "pi" "pli" "pl" "p", _I),
     "mv_attention_fwd": ("ppp" "iii" "f" "p", _I),

@@ -496,24 +496,28 @@ def quant_affine(x, scale, zero_point, qmin, qmax):
 
 
 def quant_affine_codes(x, rows, cols, scale, zero_point, qmin, qmax, pre_gelu=False):
-    """fp32 [rows, cols] -> bf16 [rows, pad8(cols)] integer codes (q - zero_point) of the affine quantiser (exact);
-    ``pre_gelu``: of gelu(x)."""
+    """fp32 or bf16 [rows, cols] -> bf16 [rows, pad8(cols)] integer codes (q - zero_point) of the affine quantiser
+    (exact); ``pre_gelu``: of gelu(x)."""
     require_cuda(x)
-    xf = x.detach().float().contiguous()
+    xf = x.detach()
+    if xf.dtype not in (torch.float32, torch.bfloat16):
+        xf = xf.float()
+    xf = xf.contiguous()
     ld = pad8(cols)
     codes = torch.empty(rows, ld, dtype=torch.bfloat16, device=x.device)
-    check(lib().mv_quant_affine_codes(_p(xf), _p(codes), rows, cols, ld, float(scale), int(zero_point), qmin, qmax,
-                                      1 if pre_gelu else 0, _s()),
+    check(lib().mv_quant_affine_codes(_p(xf), _DT[xf.dtype], _p(codes), rows, cols, ld, float(scale), int(zero_point), qmin,
+                                      qmax, 1 if pre_gelu else 0, _s()),
           "quant_affine_codes", rows=rows, cols=cols)
     return codes
 
 
-def linear_codes(xc, wc, M, N, K, alpha, bias, out):
-    """out fp32 [M, N] = alpha * (xc [M, pad8(K)] . wc [N, pad8(K)]^T) + bias: integer-code operands on the bf16 MFMA
-    path = exact int8 arithmetic (|codes| <= 256, fp32 accumulation)."""
+def linear_codes(xc, wc, M, N, K, alpha, bias, out, residual=None):
+    """out (fp32 or bf16) [M, N] = alpha * (xc [M, pad8(K)] . wc [N, pad8(K)]^T) + bias (+ residual fp32 [M, N]):
+    integer-code operands on the bf16 MFMA path = exact int8 arithmetic (|codes| <= 256, fp32 accumulation)."""
     t0 = _timer.begin() if _timer is not None else None
+    epi, aux, ld_aux = (EPI_RESIDUAL, _p(residual), N) if residual is not None else (EPI_NONE, None, 0)
     check(lib().mv_gemm_nt_bf16_scaled(_p(xc), xc.shape[1], _p(wc), wc.shape[1], _p(out), N, _DT[out.dtype], M, N, K,
-                                       float(alpha), _p(bias), EPI_NONE, None, 0, 0, None, 0, _s()),
+                                       float(alpha), _p(bias), epi, aux, ld_aux, 0, None, 0, _s()),
           "gemm_nt_bf16_scaled", M=M, N=N, K=K)
     if t0 is not None:
         _timer.end("gemm_nt_bf16", t0, 2.0 * M * N * K)

@@ -122,6 +122,12 @@ class Residual(nn.Module):
         if type(inner) is FeedForward and inner.fusable():
             fc1, fc2 = inner.net[0], inner.net[3]
             return F.mlp_block(x, pn.norm.weight, pn.norm.bias, fc1.weight, fc1.bias, fc2.weight, fc2.bias, prec)
+        # converted PyTorchINT8 blocks: the residual add rides in the second GEMM's epilogue
+        if type(inner) is Attention and inner.int8_pair() is not None:
+            return inner.int8_forward(pn.norm(x), residual=x)
+        if type(inner) is FeedForward and inner.int8_pair() is not None:
+            fc1, fc2 = inner.int8_pair()
+            return fc2(fc1(pn.norm(x)), pre_gelu=True, residual=x)
         return None
 
 
@@ -154,15 +160,23 @@ class FeedForward(nn.Module):
                 and _plain(n[3], Linear) and all(type(n[i]) is Dropout and (n[i].p == 0.0 or not n[i].training)
                                                  and not n[i]._forward_hooks for i in (2, 4)))
 
-    def forward(self, x: torch.Tensor):
+    def int8_pair(self):
+        """(fc1, fc2) when this is a converted PyTorchINT8 MLP nothing hooks into, else None."""
         n = self.net
         fc1, fc2 = _int8_linear(n[0]), _int8_linear(n[3])
-        if (fc1 is not None and fc2 is not None and _plain(n[1], GELU) and not n._forward_hooks and not n._forward_pre_hooks
+        if (fc1 is not None and fc2 is not None and _plain(n[1], GELU) and not self._forward_hooks
+                and not n._forward_hooks and not n._forward_pre_hooks
                 and all(type(n[i]) is Dropout and (n[i].p == 0.0 or not n[i].training) and not n[i]._forward_hooks
                         for i in (2, 4))):
+            return fc1, fc2
+        return None
+
+    def forward(self, x: torch.Tensor):
+        pair = self.int8_pair()
+        if pair is not None:
             # converted PyTorchINT8 MLP: nn.GELU is applied inside fc2's input quantiser (one pass over the hidden
             # activations instead of GELU fp32 -> fp32 followed by quantise fp32 -> codes); same numbers
-            return fc2(fc1(x), pre_gelu=True)
+            return pair[1](pair[0](x), pre_gelu=True)
         return self.net(x)
 
 
@@ -192,9 +206,29 @@ class Attention(nn.Module):
                 and not self.to_out._forward_hooks and type(d) is Dropout and (d.p == 0.0 or not d.training)
                 and not self.attn_output._forward_hooks and self.dequant_qkv.plain() and self.quant_out.plain())
 
+    def int8_pair(self):
+        """(to_qkv, to_out) when this is a converted PyTorchINT8 attention nothing hooks into, else None."""
+        lq, lo = _int8_linear(self.to_qkv), _int8_linear(self.to_out[0])
+        d = self.to_out[1]
+        if (lq is not None and lo is not None and not self._forward_hooks and not self.to_out._forward_hooks
+                and type(d) is Dropout and (d.p == 0.0 or not d.training) and not d._forward_hooks
+                and not self.attn_output._forward_hooks and self.dequant_qkv.plain() and self.quant_out.plain()):
+            return lq, lo
+        return None
+
+    def int8_forward(self, x, residual=None):
+        """Converted PyTorchINT8 attention in three GEMM-side fusions: to_qkv writes bf16 directly when the bf16 core is
+        opted in, to_out's quantiser reads the attention output in whatever dtype it has, and the Residual add rides in
+        to_out's epilogue.  Same numbers as the module-by-module path."""
+        lq, lo = self.int8_pair()
+        qkv = lq(x, out_dtype=torch.bfloat16 if self.bf16_core else torch.float32)
+        return lo(F.attention_core(qkv, self.heads, self.scale, None), residual=residual)
+
     def forward(self, x: torch.Tensor):
         # reference vit.py:85-99; the reshape/permute/transpose of the reference are index arithmetic inside the
         # attention kernels (qkv stays [B, N, 3, H, dh])
+        if self.int8_pair() is not None:
+            return self.int8_forward(x)
         qkv = self.dequant_qkv(self.to_qkv(x))
         hook = self.attn_output if self.attn_output._forward_hooks else None
         if self.bf16_core and hook is None and qkv.dtype == torch.float32:

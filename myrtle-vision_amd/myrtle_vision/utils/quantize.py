@@ -264,21 +264,31 @@ class Int8Linear(nn.Linear):
         lin.weight_codes = codes
         return lin
 
-    def forward(self, x, pre_gelu=False):
-        """``pre_gelu``: the input is gelu(x) -- FeedForward folds its nn.GELU into this layer's input quantiser."""
+    def forward(self, x, pre_gelu=False, residual=None, out_dtype=torch.float32):
+        """``pre_gelu``: the input is gelu(x) -- FeedForward folds its nn.GELU into this layer's input quantiser.
+        ``residual`` (fp32, output shape): added in the GEMM epilogue (Residual's FloatFunctional.add, vit.py:27).
+        ``out_dtype``: bf16 only for the opt-in bf16 attention core (ViT.convert(bf16_attention=True))."""
         s_x, z_x = self.act_observer.frozen
         if torch.is_grad_enabled() and (x.requires_grad or self.weight.requires_grad):
             if pre_gelu:
                 x = F.gelu(x)
-            return _hip_linear(self.act_observer(x), self.weight, self.bias, torch.float32)     # fake-quant STE path
+            y = _hip_linear(self.act_observer(x), self.weight, self.bias, torch.float32)       # fake-quant STE path
+            if residual is not None:
+                y = F.add(y, residual)
+            return F.cast(y, out_dtype)
         ops.require_cuda(x)
         K = x.shape[-1]
         N = self.weight.shape[0]
         x2 = x.reshape(-1, K)
         M = x2.shape[0]
         xc = ops.quant_affine_codes(x2, M, K, s_x, z_x, self.act_observer.qmin, self.act_observer.qmax, pre_gelu=pre_gelu)
-        out = torch.empty(M, N, dtype=torch.float32, device=x.device)
-        ops.linear_codes(xc, self.weight_codes, M, N, K, s_x * self.weight_scale, self.bias, out)
+        out = torch.empty(M, N, dtype=out_dtype, device=x.device)
+        res = None
+        if residual is not None:
+            if out_dtype != torch.float32:
+                raise ValueError("a fused residual needs an fp32 output")
+            res = residual.detach().float().contiguous().view(M, N)
+        ops.linear_codes(xc, self.weight_codes, M, N, K, s_x * self.weight_scale, self.bias, out, residual=res)
         return out.view(*x.shape[:-1], N)
 
 

@@ -622,7 +622,12 @@ def test_int8_converted_model_fast_path_equals_fake_quant_path():
     try:
         with torch.no_grad():
             assert torch.equal(vit(img), fast) and sum(seen) == 2
+        # hooks on GELU and on the attention output Dropout switch every int8 block fusion off (GELU fold, residual in the
+        # GEMM epilogue, direct to_qkv -> attention -> to_out chaining): the module-by-module path gives the same bits
+        from myrtle_vision.models.vit import Attention as _Att
         hooks = [m.register_forward_hook(lambda mod, i, o: None) for m in vit.modules() if isinstance(m, GELU)]
+        hooks += [m.to_out[1].register_forward_hook(lambda mod, i, o: None) for m in vit.modules() if isinstance(m, _Att)]
+        assert all(m.int8_pair() is None for m in vit.modules() if isinstance(m, _Att))
         seen.clear()
         with torch.no_grad():
             unfolded = vit(img)
@@ -639,3 +644,9 @@ def test_int8_converted_model_fast_path_equals_fake_quant_path():
     with torch.no_grad():
         approx = vit(img)
     assert approx.dtype == torch.float32 and 0 < relerr(approx, fast.double().cpu()) < 3e-2
+    # ... and its fused chaining (bf16 to_qkv output, bf16-input quantiser) equals the cast-based module path bit for bit
+    hooks = [m.to_out[1].register_forward_hook(lambda mod, i, o: None) for m in vit.modules() if isinstance(m, Attention)]
+    with torch.no_grad():
+        assert torch.equal(vit(img), approx)
+    for h in hooks:
+        h.remove()
