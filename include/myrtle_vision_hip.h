@@ -229,6 +229,15 @@ int mv_image_prepare(const uint8_t* src, long img_stride, int Hs, int Ws, const 
  * (DLRSD labels are PNG value - 1, datasets/dlrsd.py:80). */
 int mv_mask_prepare(const uint8_t* src, long img_stride, int Hs, int Ws, const int32_t* yi, const int32_t* xi,
                     const uint8_t* flip, int add, int64_t* out, int B, int out_h, int out_w, mv_stream_t stream);
+/* stage one of a Resize -> RandomResizedCrop chain (segmentation/data_configs/data_config.json transform_ops_train, built
+ * by datasets/dlrsd.py:39-66): the same resampling with the result kept as uint8 -- out [B, out_h, out_w, 3] (frames) /
+ * [B, out_h, out_w] (masks, NEAREST) -- because every Pillow resize rounds to uint8, so the second resize must start
+ * from that image.  Tables as for mv_image_prepare / mv_mask_prepare; no flip, no normalisation. */
+int mv_image_resize_u8(const uint8_t* src, long img_stride, int Hs, int Ws, const int32_t* kh, const int32_t* bh,
+                       const int32_t* kv, const int32_t* bv, int ks, uint8_t* out, int B, int out_h, int out_w,
+                       mv_stream_t stream);
+int mv_mask_resize_u8(const uint8_t* src, long img_stride, int Hs, int Ws, const int32_t* yi, const int32_t* xi, uint8_t* out,
+                      int B, int out_h, int out_w, mv_stream_t stream);
 
 /* ---- optimizer: AdamW step (timm create_optimizer 'adamw' -> torch.optim.AdamW), classification/train.py:161-166,274-277 ----
  * flat fp32 arrays of n elements; decoupled weight decay; bias corrections passed in (host computes from step) */

@@ -23,12 +23,15 @@ __device__ __forceinline__ int clip8(int v) {
   return v < 0 ? 0 : (v > 255 ? 255 : v);
 }
 
+// U8 = true: the resampled frame itself, uint8 HWC, no flip / ToTensor / Normalize -- stage one of a
+// Resize -> RandomResizedCrop chain (each Pillow resize rounds to uint8, so the two resamplings cannot be merged)
+template <bool U8>
 __global__ __launch_bounds__(256) void image_prepare_kernel(const uint8_t* __restrict__ src, long img_stride, int Hs, int Ws,
                                                             const int* __restrict__ kh, const int* __restrict__ bh,
                                                             const int* __restrict__ kv, const int* __restrict__ bv, int ks,
                                                             const uint8_t* __restrict__ flip, float m0, float m1, float m2,
-                                                            float s0, float s1, float s2, float* __restrict__ out, int oh,
-                                                            int ow) {
+                                                            float s0, float s1, float s2, float* __restrict__ out,
+                                                            uint8_t* __restrict__ out_u8, int oh, int ow) {
   const int b = blockIdx.z;
   const int X = blockIdx.x * 64 + (threadIdx.x & 63), Y = blockIdx.y * 4 + (threadIdx.x >> 6);
   if (X >= ow || Y >= oh) return;
@@ -53,6 +56,13 @@ __global__ __launch_bounds__(256) void image_prepare_kernel(const uint8_t* __res
     a1 += clip8(h1) * k;
     a2 += clip8(h2) * k;
   }
+  if constexpr (U8) {
+    uint8_t* o = out_u8 + (((long)b * oh + Y) * ow + X) * 3;
+    o[0] = (uint8_t)clip8(a0);
+    o[1] = (uint8_t)clip8(a1);
+    o[2] = (uint8_t)clip8(a2);
+    return;
+  }
   const int Xo = flip[b] ? ow - 1 - X : X;                       // RandomHorizontalFlip acts on the resized image
   const long plane = (long)oh * ow;
   float* o = out + (long)b * 3 * plane + (long)Y * ow + Xo;
@@ -63,14 +73,20 @@ __global__ __launch_bounds__(256) void image_prepare_kernel(const uint8_t* __res
 }
 
 // masks: Image.resize(NEAREST) = a gather through per-axis index tables (Geometry.c ImagingScaleAffine), + label offset
+template <bool U8>
 __global__ __launch_bounds__(256) void mask_prepare_kernel(const uint8_t* __restrict__ src, long img_stride, int Ws,
                                                            const int* __restrict__ yi, const int* __restrict__ xi,
                                                            const uint8_t* __restrict__ flip, int add,
-                                                           int64_t* __restrict__ out, int oh, int ow) {
+                                                           int64_t* __restrict__ out, uint8_t* __restrict__ out_u8, int oh,
+                                                           int ow) {
   const int b = blockIdx.z;
   const int X = blockIdx.x * 64 + (threadIdx.x & 63), Y = blockIdx.y * 4 + (threadIdx.x >> 6);
   if (X >= ow || Y >= oh) return;
   const int sy = yi[(long)b * oh + Y], sx = xi[(long)b * ow + X];
+  if constexpr (U8) {
+    out_u8[((long)b * oh + Y) * ow + X] = src[(long)b * img_stride + (long)sy * Ws + sx];
+    return;
+  }
   const int Xo = flip[b] ? ow - 1 - X : X;
   out[((long)b * oh + Y) * ow + Xo] = (int64_t)src[(long)b * img_stride + (long)sy * Ws + sx] + add;
 }
@@ -86,8 +102,8 @@ extern "C" int mv_image_prepare(const uint8_t* src, long img_stride, int Hs, int
   MV_REQUIRE(B >= 0 && Hs > 0 && Ws > 0 && out_h > 0 && out_w > 0 && ks > 0 && ks <= 64, MV_ERR_SHAPE);
   MV_REQUIRE(img_stride >= (long)Hs * Ws * 3 && B <= 65535, MV_ERR_SHAPE);
   if (B == 0) return MV_OK;
-  image_prepare_kernel<<<dim3(mv_cdiv(out_w, 64), mv_cdiv(out_h, 4), B), 256, 0, S_>>>(
-      src, img_stride, Hs, Ws, kh, bh, kv, bv, ks, flip, mean0, mean1, mean2, std0, std1, std2, out, out_h, out_w);
+  image_prepare_kernel<false><<<dim3(mv_cdiv(out_w, 64), mv_cdiv(out_h, 4), B), 256, 0, S_>>>(
+      src, img_stride, Hs, Ws, kh, bh, kv, bv, ks, flip, mean0, mean1, mean2, std0, std1, std2, out, nullptr, out_h, out_w);
   MV_CHECK_LAUNCH();
   return MV_OK;
 }
@@ -97,8 +113,31 @@ extern "C" int mv_mask_prepare(const uint8_t* src, long img_stride, int Hs, int 
   MV_REQUIRE(B >= 0 && Hs > 0 && Ws > 0 && out_h > 0 && out_w > 0, MV_ERR_SHAPE);
   MV_REQUIRE(img_stride >= (long)Hs * Ws && B <= 65535, MV_ERR_SHAPE);
   if (B == 0) return MV_OK;
-  mask_prepare_kernel<<<dim3(mv_cdiv(out_w, 64), mv_cdiv(out_h, 4), B), 256, 0, S_>>>(src, img_stride, Ws, yi, xi, flip, add, out,
-                                                                                     out_h, out_w);
+  mask_prepare_kernel<false><<<dim3(mv_cdiv(out_w, 64), mv_cdiv(out_h, 4), B), 256, 0, S_>>>(src, img_stride, Ws, yi, xi, flip, add,
+                                                                                            out, nullptr, out_h, out_w);
+  MV_CHECK_LAUNCH();
+  return MV_OK;
+}
+
+extern "C" int mv_image_resize_u8(const uint8_t* src, long img_stride, int Hs, int Ws, const int32_t* kh, const int32_t* bh,
+                                  const int32_t* kv, const int32_t* bv, int ks, uint8_t* out, int B, int out_h, int out_w,
+                                  mv_stream_t stream) {
+  MV_REQUIRE(B >= 0 && Hs > 0 && Ws > 0 && out_h > 0 && out_w > 0 && ks > 0 && ks <= 64, MV_ERR_SHAPE);
+  MV_REQUIRE(img_stride >= (long)Hs * Ws * 3 && B <= 65535, MV_ERR_SHAPE);
+  if (B == 0) return MV_OK;
+  image_prepare_kernel<true><<<dim3(mv_cdiv(out_w, 64), mv_cdiv(out_h, 4), B), 256, 0, S_>>>(
+      src, img_stride, Hs, Ws, kh, bh, kv, bv, ks, nullptr, 0.f, 0.f, 0.f, 1.f, 1.f, 1.f, nullptr, out, out_h, out_w);
+  MV_CHECK_LAUNCH();
+  return MV_OK;
+}
+
+extern "C" int mv_mask_resize_u8(const uint8_t* src, long img_stride, int Hs, int Ws, const int32_t* yi, const int32_t* xi,
+                                 uint8_t* out, int B, int out_h, int out_w, mv_stream_t stream) {
+  MV_REQUIRE(B >= 0 && Hs > 0 && Ws > 0 && out_h > 0 && out_w > 0, MV_ERR_SHAPE);
+  MV_REQUIRE(img_stride >= (long)Hs * Ws && B <= 65535, MV_ERR_SHAPE);
+  if (B == 0) return MV_OK;
+  mask_prepare_kernel<true><<<dim3(mv_cdiv(out_w, 64), mv_cdiv(out_h, 4), B), 256, 0, S_>>>(src, img_stride, Ws, yi, xi, nullptr, 0,
+                                                                                           nullptr, out, out_h, out_w);
   MV_CHECK_LAUNCH();
   return MV_OK;
 }

@@ -9,8 +9,10 @@ Here the worker only DECODES the file and draws the random parameters; it hands 
 
 and one HIP kernel (``mv_image_prepare``; ``mv_mask_prepare`` for segmentation masks) does crop + antialiased bilinear
 resize + flip + ToTensor + Normalize for the whole batch, bit-exact to the Pillow path in ``datasets/transforms.py``
-(tests/test_image_prep.py).  Supported chains (all the reference's configs): [Resize | RandomResizedCrop] ->
-[CenterCrop] -> [RandomHorizontalFlip] -> ToTensor -> [Normalize].
+(tests/test_image_prep.py).  Supported chains (all the reference's configs): [Resize] -> [RandomResizedCrop] ->
+[CenterCrop] -> [RandomHorizontalFlip] -> ToTensor -> [Normalize].  Resize FOLLOWED BY RandomResizedCrop (the
+segmentation training config) is two resamplings, each rounded to uint8 by Pillow: the GPU runs them as two kernels
+(``mv_image_resize_u8`` / ``mv_mask_resize_u8`` keep the intermediate uint8 image), with a second set of tables.
 """
 import math
 import random
@@ -72,7 +74,7 @@ class DevicePlan:
 
     def __init__(self, transform_config):
         unknown = set(transform_config) - {"Resize", "RandomResizedCrop", "CenterCrop", "RandomHorizontalFlip", "Normalize"}
-        if unknown or ("Resize" in transform_config and "RandomResizedCrop" in transform_config):
+        if unknown:
             raise ValueError(f"transform chain not supported on the device path: {sorted(transform_config)}")
         self.resize = transform_config.get("Resize")
         self.rrc = RandomResizedCrop(transform_config["RandomResizedCrop"]) if "RandomResizedCrop" in transform_config else None
@@ -95,6 +97,14 @@ class DevicePlan:
     def __call__(self, img, mask=None):
         a = np.asarray(img.convert("RGB"), dtype=np.uint8)
         H, W = a.shape[:2]
+        first = None
+        if self.rrc is not None and self.resize is not None:
+            # stage one: Resize((S, S)) of the whole frame; the crop below then lives on that S x S uint8 image
+            S = int(self.resize)
+            b1v, k1v, y1 = self._tables(H, S)
+            b1h, k1h, x1 = self._tables(W, S)
+            first = (b1v, k1v, y1, b1h, k1h, x1)
+            H = W = S
         # same draws, in the same order, as transforms.RandomResizedCrop / RandomHorizontalFlip
         if self.rrc is not None:
             top, left, ch, cw = self.rrc._params(W, H)
@@ -117,10 +127,15 @@ class DevicePlan:
         s = {"raw": torch.from_numpy(a.copy()), "kh": torch.from_numpy(np.ascontiguousarray(kh)),
              "bh": torch.from_numpy(np.ascontiguousarray(bh)), "kv": torch.from_numpy(np.ascontiguousarray(kv)),
              "bv": torch.from_numpy(np.ascontiguousarray(bv)), "flip": flip}
+        if first is not None:
+            s.update(kv1=torch.from_numpy(np.ascontiguousarray(first[1])), bv1=torch.from_numpy(np.ascontiguousarray(first[0])),
+                     kh1=torch.from_numpy(np.ascontiguousarray(first[4])), bh1=torch.from_numpy(np.ascontiguousarray(first[3])))
         if mask is not None:
             m = np.asarray(mask, dtype=np.uint8)
-            if m.shape != (H, W):
-                raise ValueError(f"mask {m.shape} does not match image {(H, W)}")
+            if m.shape != a.shape[:2]:
+                raise ValueError(f"mask {m.shape} does not match image {a.shape[:2]}")
+            if first is not None:
+                s.update(yi1=torch.from_numpy(np.ascontiguousarray(first[2])), xi1=torch.from_numpy(np.ascontiguousarray(first[5])))
             s.update(mask=torch.from_numpy(m.copy()), yi=torch.from_numpy(np.ascontiguousarray(yi)),
                      xi=torch.from_numpy(np.ascontiguousarray(xi)))
         return s
@@ -164,6 +179,18 @@ class DevicePlan:
                "flip": torch.tensor([s["flip"] for s in samples], dtype=torch.uint8)}
         if has_mask:
             out.update(mask=mask, yi=torch.stack([s["yi"] for s in samples]), xi=torch.stack([s["xi"] for s in samples]))
+        if "kh1" in samples[0]:                                              # Resize -> RandomResizedCrop: stage-one tables
+            k1 = max(max(s["kh1"].shape[1], s["kv1"].shape[1]) for s in samples)
+            if k1 > MAX_TAPS:
+                raise ValueError(f"downscale factor too large for the device path ({k1} taps)")
+            S = samples[0]["kv1"].shape[0]
+            kh1, kv1 = torch.zeros(B, S, k1, dtype=torch.int32), torch.zeros(B, S, k1, dtype=torch.int32)
+            for i, s in enumerate(samples):
+                kh1[i, :, :s["kh1"].shape[1]] = s["kh1"]
+                kv1[i, :, :s["kv1"].shape[1]] = s["kv1"]
+            out.update(kh1=kh1, kv1=kv1, bh1=torch.stack([s["bh1"] for s in samples]), bv1=torch.stack([s["bv1"] for s in samples]))
+            if has_mask:
+                out.update(yi1=torch.stack([s["yi1"] for s in samples]), xi1=torch.stack([s["xi1"] for s in samples]))
         return out, labels
 
     # ---- GPU side ---------------------------------------------------------------------------------------------
@@ -172,8 +199,13 @@ class DevicePlan:
         ``device``; the copies are asynchronous and the kernels run on the current stream."""
         from myrtle_vision.hip import ops
         d = {k: v.to(device, non_blocking=True) for k, v in packed.items()}
-        imgs = ops.image_prepare(d["raw"], d["kh"], d["bh"], d["kv"], d["bv"], d["flip"], self.mean, self.std)
+        raw, mask = d["raw"], d.get("mask")
+        if "kh1" in d:                                                       # Resize first, as its own uint8 image
+            raw = ops.image_resize_u8(raw, d["kh1"], d["bh1"], d["kv1"], d["bv1"])
+            if mask is not None:
+                mask = ops.mask_resize_u8(mask, d["yi1"], d["xi1"])
+        imgs = ops.image_prepare(raw, d["kh"], d["bh"], d["kv"], d["bv"], d["flip"], self.mean, self.std)
         masks = None
-        if "mask" in d:
-            masks = ops.mask_prepare(d["mask"], d["yi"], d["xi"], d["flip"], mask_add)
+        if mask is not None:
+            masks = ops.mask_prepare(mask, d["yi"], d["xi"], d["flip"], mask_add)
         return imgs, masks

@@ -59,6 +59,8 @@ SIGNATURES = {
     "mv_seg_ce_bwd": ("pppp" "ii" "f" "iiiiii" "p", _I),
     "mv_image_prepare": ("plii" "pppp" "i" "p" "ffffff" "p" "iii" "p", _I),
     "mv_mask_prepare": ("plii" "pp" "p" "i" "p" "iii" "p", _I),
+    "mv_image_resize_u8": ("plii" "pppp" "i" "p" "iii" "p", _I),
+    "mv_mask_resize_u8": ("plii" "pp" "p" "iii" "p", _I),
     "mv_adamw": ("pppp" "l" "ffffffff" "p", _I),
 }
 

@@ -619,6 +619,29 @@ def image_prepare(raw, kh, bh, kv, bv, flip, mean, std):
     return out
 
 
+def image_resize_u8(raw, kh, bh, kv, bv):
+    """uint8 [B, Hs, Ws, 3] + Pillow resampling tables -> uint8 [B, oh, ow, 3]: a plain Image.resize(BILINEAR), kept as
+    the uint8 image a following RandomResizedCrop resamples again."""
+    require_cuda(raw, kh, bh, kv, bv)
+    B, Hs, Ws, _ = raw.shape
+    oh, ow, ks = kv.shape[1], kh.shape[1], kh.shape[2]
+    out = torch.empty(B, oh, ow, 3, dtype=torch.uint8, device=raw.device)
+    check(lib().mv_image_resize_u8(_p(raw), Hs * Ws * 3, Hs, Ws, _p(kh), _p(bh), _p(kv), _p(bv), ks, _p(out), B, oh, ow, _s()),
+          "image_resize_u8", B=B, Hs=Hs, Ws=Ws, oh=oh, ow=ow, ks=ks)
+    return out
+
+
+def mask_resize_u8(mask, yi, xi):
+    """uint8 [B, Hs, Ws] + NEAREST index tables -> uint8 [B, oh, ow]."""
+    require_cuda(mask, yi, xi)
+    B, Hs, Ws = mask.shape
+    oh, ow = yi.shape[1], xi.shape[1]
+    out = torch.empty(B, oh, ow, dtype=torch.uint8, device=mask.device)
+    check(lib().mv_mask_resize_u8(_p(mask), Hs * Ws, Hs, Ws, _p(yi), _p(xi), _p(out), B, oh, ow, _s()),
+          "mask_resize_u8", B=B, Hs=Hs, Ws=Ws, oh=oh, ow=ow)
+    return out
+
+
 def mask_prepare(mask, yi, xi, flip, add=0):
     """uint8 [B, Hs, Ws] + NEAREST index tables -> int64 [B, oh, ow] (+ add)."""
     require_cuda(mask, yi, xi, flip)

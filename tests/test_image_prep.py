@@ -40,7 +40,28 @@ def _cfg(kind):
             "val": {"Resize": 224, "Normalize": norm},
             "crop": {"Resize": 256, "CenterCrop": 224, "RandomHorizontalFlip": None, "Normalize": {"Mean": [0.485, 0.456, 0.406],
                                                                                                 "Std": [0.229, 0.224, 0.225]}},
-            "plain": {"RandomHorizontalFlip": None}}[kind]
+            "plain": {"RandomHorizontalFlip": None},
+            # segmentation/data_configs/data_config.json transform_ops_train: TWO resamplings (Resize, then the crop's)
+            "seg_train": {"Resize": 224, "RandomResizedCrop": 224, "RandomHorizontalFlip": None, "Normalize": norm}}[kind]
+
+
+def _resample(raw, kh, bh, kv, bv):
+    """Pillow's two-pass 8-bit resize through the plan's tables (int64 arithmetic): uint8 HWC -> uint8 [oh, ow, 3]."""
+    oh, ow = kv.shape[0], kh.shape[0]
+    half = 1 << 21
+    tmp = np.zeros((raw.shape[0], ow, 3), np.int64)                          # horizontal pass, rounded to uint8
+    for X in range(ow):
+        acc = np.full((raw.shape[0], 3), half, np.int64)
+        for x in range(bh[X, 1]):
+            acc += raw[:, bh[X, 0] + x] * int(kh[X, x])
+        tmp[:, X] = np.clip(acc >> 22, 0, 255)
+    out = np.zeros((oh, ow, 3), np.int64)
+    for Y in range(oh):
+        acc = np.full((ow, 3), half, np.int64)
+        for y in range(bv[Y, 1]):
+            acc += tmp[bv[Y, 0] + y] * int(kv[Y, y])
+        out[Y] = np.clip(acc >> 22, 0, 255)
+    return out
 
 
 def _pil_batch(n, h, w, seed, masks):
@@ -51,7 +72,8 @@ def _pil_batch(n, h, w, seed, masks):
 
 
 @pytest.mark.parametrize("kind,h,w,masks", [("train", 256, 256, False), ("val", 256, 256, True), ("train", 200, 333, True),
-                                             ("crop", 300, 280, False), ("plain", 96, 96, True)])
+                                             ("crop", 300, 280, False), ("plain", 96, 96, True), ("seg_train", 256, 256, True),
+                                             ("seg_train", 300, 180, True)])
 def test_device_plan_equals_pillow_pipeline_via_oracle(kind, h, w, masks):
     """CPU: the plan's tables + the oracle's arithmetic reproduce datasets/transforms.py (Pillow) exactly, with the same
     random draws -- i.e. what mv_image_prepare is asked to compute IS the reference pipeline."""
@@ -66,28 +88,19 @@ def test_device_plan_equals_pillow_pipeline_via_oracle(kind, h, w, masks):
         random.seed(1234)
         s = plan(img, m)
         raw = s["raw"].numpy().astype(np.int64)
-        kh, bh, kv, bv = (s[k].numpy() for k in ("kh", "bh", "kv", "bv"))
-        oh, ow = kv.shape[0], kh.shape[0]
-        half = 1 << 21
-        tmp = np.zeros((raw.shape[0], ow, 3), np.int64)                      # horizontal pass, rounded to uint8
-        for X in range(ow):
-            acc = np.full((raw.shape[0], 3), half, np.int64)
-            for x in range(bh[X, 1]):
-                acc += raw[:, bh[X, 0] + x] * int(kh[X, x])
-            tmp[:, X] = np.clip(acc >> 22, 0, 255)
-        out = np.zeros((oh, ow, 3), np.uint8)
-        for Y in range(oh):
-            acc = np.full((ow, 3), half, np.int64)
-            for y in range(bv[Y, 1]):
-                acc += tmp[bv[Y, 0] + y] * int(kv[Y, y])
-            out[Y] = np.clip(acc >> 22, 0, 255)
+        if "kh1" in s:                                                        # Resize first, as its own uint8 image
+            raw = _resample(raw, *(s[k].numpy() for k in ("kh1", "bh1", "kv1", "bv1")))
+        out = _resample(raw, *(s[k].numpy() for k in ("kh", "bh", "kv", "bv"))).astype(np.uint8)
         if s["flip"]:
             out = out[:, ::-1]
         t = out.astype(np.float32).transpose(2, 0, 1) / np.float32(255.0)
         t = (t - np.asarray(plan.mean, np.float32).reshape(3, 1, 1)) / np.asarray(plan.std, np.float32).reshape(3, 1, 1)
         assert np.array_equal(t, want_img.numpy())
         if masks:
-            mm = s["mask"].numpy()[s["yi"].numpy()][:, s["xi"].numpy()]
+            mm = s["mask"].numpy()
+            if "yi1" in s:
+                mm = mm[s["yi1"].numpy()][:, s["xi1"].numpy()]
+            mm = mm[s["yi"].numpy()][:, s["xi"].numpy()]
             if s["flip"]:
                 mm = mm[:, ::-1]
             assert np.array_equal(mm.astype(np.int64), want_mask.numpy())
@@ -95,7 +108,8 @@ def test_device_plan_equals_pillow_pipeline_via_oracle(kind, h, w, masks):
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("kind,h,w,masks", [("train", 256, 256, False), ("val", 256, 256, True), ("train", 200, 333, True),
-                                             ("crop", 300, 280, False), ("plain", 96, 96, True), ("train", 1024, 900, False)])
+                                             ("crop", 300, 280, False), ("plain", 96, 96, True), ("train", 1024, 900, False),
+                                             ("seg_train", 256, 256, True), ("seg_train", 500, 380, True)])
 def test_gpu_image_prepare_is_bit_exact(kind, h, w, masks):
     """mv_image_prepare / mv_mask_prepare == the Pillow pipeline, bit for bit, for a collated batch (mixed frame sizes)."""
     from myrtle_vision.datasets.device_transforms import DevicePlan
