@@ -161,7 +161,7 @@ def _fused_seg_tail(task, criterion):
 @torch.no_grad()
 def validation(val_loader, device, criterion, vit, task, num_classes):
     total_loss, total_acc, n = 0.0, 0.0, max(len(val_loader), 1)
-    miou = MIoU(num_classes, "cpu") if task == "segmentation" else None
+    miou = MIoU(num_classes, device) if task == "segmentation" else None     # counted where the predictions are
     vit.eval()
     for imgs, labels in val_loader:                            # a BatchFeed: both already on the device
         if _fused_seg_tail(task, criterion):
@@ -174,7 +174,7 @@ def validation(val_loader, device, criterion, vit, task, num_classes):
             pred = outputs.argmax(dim=1)
             total_acc += float((pred == labels).float().mean()) / n
         if miou is not None:
-            miou.add_img(pred.cpu(), labels.cpu())
+            miou.add_img(pred, labels)                         # three bincounts on the device; 17 numbers leave it
     vit.train()
     return total_loss, total_acc, (miou.get_miou() if miou is not None else None)
 
@@ -336,16 +336,28 @@ def evaluate(config, task, quantize=False, calib_steps=0, quantized_ckpt=False):
     testset = mk("eval" if task == "classification" else "test", "test_files", "transform_ops_val", plan)
     loader = BatchFeed(testset, plan, task, dev, collate, batch_size=train_config["local_batch_size"])
     vit.eval()
-    preds, gts = [], []
-    miou = MIoU(data_config["number_of_classes"], "cpu") if task == "segmentation" else None
-    for imgs, labels in loader:
-        out, labels = vit(imgs).argmax(dim=1).cpu(), labels.cpu()
-        preds.append(out.reshape(-1))
-        gts.append(labels.reshape(-1))
-        if miou is not None:
-            miou.add_img(out, labels)
-    preds, gts = torch.cat(preds), torch.cat(gts)
-    acc = float((preds == gts).float().mean())
+    # predictions, the hit count and the mIoU histograms stay on the device (the reference concatenates int64 predictions and
+    # labels of the whole test set on the host: 206 MB per batch of 256 masks); the segmentation decoder goes through the
+    # fused tail, which yields the arg-max without the [B, C, H, W] logits
+    miou = MIoU(data_config["number_of_classes"], dev) if task == "segmentation" else None
+    correct, total = torch.zeros((), dtype=torch.float64, device=dev), 0
+    preds, gts = [], []                                    # classification only (one label per image): for the report
+    with torch.no_grad():
+        for imgs, labels in loader:
+            if task == "segmentation" and hasattr(vit, "segmentation_loss"):
+                pred = vit.segmentation_loss(imgs, labels)[2]
+            else:
+                pred = vit(imgs).argmax(dim=1)
+            correct += (pred == labels).sum()
+            total += labels.numel()
+            if miou is not None:
+                miou.add_img(pred, labels)
+            else:
+                preds.append(pred.reshape(-1).cpu())
+                gts.append(labels.reshape(-1).cpu())
+    acc = float(correct) / max(total, 1)
+    if miou is None:
+        preds, gts = torch.cat(preds), torch.cat(gts)
     result = {"accuracy": acc}
     if miou is not None:
         result["miou"] = miou.get_miou()
