@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Headline benchmark: ViT-B/16 224^2 bf16 training step, images/sec (BASELINE.json `metric`).
 
-    python bench.py --gpus N --steps K --warmup W
+    python bench.py --gpus N --steps K --warmup W          (N > 1: starts N fresh children itself, see self_launch)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
         bench.py --gpus N --steps K --warmup W
 
@@ -86,6 +86,51 @@ def cpu_baseline(seconds_budget=25.0):
                       f"(oracle/vit_oracle.py on {os.cpu_count()} host cpus)"}
 
 
+def self_launch(n_gpus):
+    """``python bench.py --gpus N`` started plainly (no WORLD_SIZE): become the launcher, as the reference scripts do with
+    mp.spawn (classification/train.py:349-356).  N fresh children are started through torch.distributed.run BEFORE this
+    process touches the GPU (nothing here has: no HIP call, no torch.cuda.is_available()), this process only waits and
+    passes on their exit code -- a failed rank fails the command, and no GPU-initialised process is ever re-exec'd."""
+    import socket
+    import subprocess
+    with socket.socket() as sock:
+        sock.bind(("127.0.0.1", 0))
+        port = sock.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")           # dmabuf IPC: what RCCL needs on this host driver
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n_gpus}", "--master-addr",
+           "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.run(cmd, env=env).returncode
+
+
+def dry_run(args, rank, world):
+    """``--dry-run``: the launch / rendezvous / barrier / max-over-ranks / JSON plumbing with NO compute (a sleep stands in
+    for the step), runnable without a GPU (gloo): what the CPU test of the multi-process path exercises.  Its JSON line
+    says so and carries no throughput."""
+    backend = os.environ.get("MV_DIST_BACKEND", "gloo")
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("gloo" if backend != "nccl" or not torch.cuda.is_available() else "nccl", rank=rank,
+                                world_size=world)
+        dist.barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        time.sleep(0.001 * (1 + rank))
+    if world > 1:
+        dist.barrier()
+    t = torch.tensor([time.perf_counter() - t0], dtype=torch.float64)
+    if world > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    if rank == 0:
+        print(json.dumps({"metric": METRIC[args.workload], "value": None, "unit": "images/sec", "n_gpus": world,
+                          "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1e3 * float(t) / args.steps, 3),
+                          "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.precision,
+                          "data": "dry-run: no compute, launch and collective plumbing only",
+                          "config": {"workload": "dry-run", "global_batch": args.batch * world, "parallelism": f"dp{world}"}}))
+    if world > 1:
+        dist.destroy_process_group()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -102,11 +147,19 @@ def main():
     ap.add_argument("--int8-bf16-attention", action="store_true",
                     help="infer-int8: ViT.convert(bf16_attention=True) -- fused bf16 attention core instead of exact fp32")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--per-shape", action="store_true", help="add the event-timed GEMM launches split by product shape")
     ap.add_argument("--no-kernel-timer", action="store_true")
     ap.add_argument("--timer-every", type=int, default=4,
                     help="bracket the GEMM launches with events on every k-th timed step only (event packets between "
                          "kernels cost ~3 %% of the step when every launch of every step is timed)")
+    ap.add_argument("--dry-run", action="store_true",
+                    help="no compute: only the multi-process launch, rendezvous, barriers and the JSON line (CPU test)")
     args = ap.parse_args()
+
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        raise SystemExit(self_launch(args.gpus))         # one fresh process per GPU; this one never initialises a GPU
+    if args.dry_run:
+        return dry_run(args, int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1")))
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -241,6 +294,9 @@ def main():
             nt_steps = len(range(0, args.steps, max(args.timer_every, 1)))
             out["kernels"] = {n: {"launches": v["launches"], "avg_us": round(v["avg_us"], 1), "tflops": round(v["tflops"], 1),
                                   "ms_per_step": round(v["total_ms"] / nt_steps, 3)} for n, v in summ.items()}
+            if args.per_shape:
+                out["per_shape"] = {k: {"launches": v["launches"], "avg_us": round(v["avg_us"], 1), "tflops": round(v["tflops"], 1)}
+                                    for k, v in sorted(timer.shape_summary().items())}
         if world == 1 and not args.no_cpu_baseline and args.workload == "cls":
             out["cpu_baseline"] = cpu_baseline()
         print(json.dumps(out))

@@ -9,7 +9,9 @@
  *   - plain pointers + sizes; no torch types; device pointers unless stated
  *   - return 0 on success, a negative MV_ERR_* otherwise; never throw, never synchronise,
  *     never allocate (callers pass workspaces); work is enqueued on `stream`
- *   - re-entrant, no global or thread-local state (autograd calls backward from a worker thread)
+ *   - re-entrant, no thread-local state (autograd calls backward from a worker thread); the ONLY process-global
+ *     state is the kernel-variant override of mv_gemm_force_variant (a tuning / test hook, atomic, default 0 =
+ *     automatic): it changes which kernel computes a product, never what is computed
  *   - "rows x dim" tensors are row-major; `ld*` are leading dimensions in ELEMENTS
  *   - dtype codes: MV_F32 / MV_BF16
  *   - MFMA entry points (mv_gemm_*_bf16, mv_attention_*) need 16-byte aligned pointers and
@@ -182,9 +184,12 @@ int mv_minmax(const float* x, long n, float* minmax, mv_stream_t stream);
 
 /* ---- loss: nn.CrossEntropyLoss() mean reduction -- classification/train.py:170,250; segmentation/train.py:188,261 ----
  * logits fp32 viewed as [outer, C, inner] (classification: inner = 1; segmentation: outer = B, inner = H*W);
- * labels int64 [outer*inner];  loss_sum: fp32 [1], zeroed by this call, receives sum of per-sample losses / count;
+ * labels int64 [outer*inner]: torch semantics -- ignore_index -100 gives no loss / gradient and is left out of the mean;
+ *   any other label outside [0, C) is never dereferenced and turns the loss into NaN (torch device-asserts there);
+ * loss_sum: fp32 [4], zeroed by this call: [0] = sum of per-sample losses / count (NaN when count = 0, as torch),
+ *   [1] = count of non-ignored labels, [2] = number of out-of-range labels, [3] unused;
  * dlogits (optional, dl_dtype, same layout, row length ld_dl >= C when inner == 1 with zeroed padding)
- *   = (softmax - onehot) * grad_scale / count.  argmax (optional int64 [outer*inner]). */
+ *   = (softmax - onehot) * grad_scale / count, zero rows for ignored labels.  argmax (optional int64 [outer*inner]). */
 int mv_cross_entropy(const float* logits, const int64_t* labels, float* loss_sum, void* dlogits, int dl_dtype,
                      int ld_dl, int64_t* argmax, long outer, int C, long inner, float grad_scale,
                      mv_stream_t stream);
@@ -201,17 +206,20 @@ int mv_upsample_bilinear_bwd(const float* dbig, float* dsmall, long sb, long sc,
 /* ---- fused segmentation tail: CrossEntropyLoss()(Upsample(size=(H,W),'bilinear')(small), labels) ----
  * replaces vit.py:355,371 (SegmentationDecoder.upsample) + segmentation/train.py:188,261-265 (criterion, argmax, accuracy)
  * in one pass that never materialises the [B, C, H, W] logits.
- * small: fp32 [B, h*w, C] (the decoder GEMM output, consumed in place); labels: int64 [B, H, W] in [0, C).
+ * small: fp32 [B, h*w, C] (the decoder GEMM output, consumed in place); labels: int64 [B, H, W] in [0, C), or -100
+ *      (ignore_index: no loss, no gradient, not counted in the mean); other out-of-range labels make the loss NaN.
  * fwd: lse fp32 [B,H,W] (log-sum-exp per pixel, kept for the backward), pred uint8 [B,H,W] (first-index arg-max),
- *      partials fp32 [2 * mv_seg_ce_partials(B,H,W)] scratch, stats[0] = mean loss, stats[1] = pixel accuracy.
- * bwd: dsmall (ds_dtype, [B*h*w, ld_ds], columns [C, ld_ds) zeroed) = d(mean loss)/d(small) * grad_scale; gather form,
+ *      partials fp32 [4 * mv_seg_ce_partials(B,H,W)] scratch, stats fp32 [4]: [0] = mean loss over the counted labels,
+ *      [1] = pixel accuracy over all pixels, [2] = counted labels, [3] = out-of-range labels.
+ * bwd: stats = the forward's (its count is the mean's denominator; NULL: every pixel counts);
+ *      dsmall (ds_dtype, [B*h*w, ld_ds], columns [C, ld_ds) zeroed) = d(mean loss)/d(small) * grad_scale; gather form,
  *      deterministic.  MV_ERR_UNSUPPORTED when C > 32 (bwd) or the per-image map does not fit 64 KB of LDS: compose
  *      mv_upsample_bilinear_* with mv_cross_entropy instead. */
 long mv_seg_ce_partials(int B, int H, int W);
 int mv_seg_ce_fwd(const float* small, const int64_t* labels, float* lse, uint8_t* pred, float* partials, float* stats,
                   int B, int C, int h, int w, int H, int W, mv_stream_t stream);
-int mv_seg_ce_bwd(const float* small, const int64_t* labels, const float* lse, void* dsmall, int ds_dtype, int ld_ds,
-                  float grad_scale, int B, int C, int h, int w, int H, int W, mv_stream_t stream);
+int mv_seg_ce_bwd(const float* small, const int64_t* labels, const float* lse, const float* stats, void* dsmall,
+                  int ds_dtype, int ld_ds, float grad_scale, int B, int C, int h, int w, int H, int W, mv_stream_t stream);
 
 /* ---- image batch preparation: Normalize(ToTensor(hflip?(resize(crop(img, box), size, BILINEAR)))) ----
  * replaces the per-image torchvision/Pillow pipeline of the DataLoader worker (datasets/resisc45.py:40-69,
@@ -242,7 +250,21 @@ int mv_mask_resize_u8(const uint8_t* src, long img_stride, int Hs, int Ws, const
 /* ---- optimizer: AdamW step (timm create_optimizer 'adamw' -> torch.optim.AdamW), classification/train.py:161-166,274-277 ----
  * flat fp32 arrays of n elements; decoupled weight decay; bias corrections passed in (host computes from step) */
 int mv_adamw(float* p, const float* g, float* m, float* v, long n, float lr, float beta1, float beta2, float eps,
-             float weight_decay, float bias_corr1, float bias_corr2, float grad_scale, mv_stream_t stream);
+             float weight_decay, float bias_corr1, float bias_corr2, float grad_scale, const float* clip_coef,
+             mv_stream_t stream);
+/* ---- gradient clipping: torch.nn.utils.clip_grad_norm_(vit.parameters(), clip_grad), classification/train.py:265-270 ----
+ * over the flat gradient array g[n]: out[0] = total_norm = ||g * grad_scale||_2, out[1] = min(1, max_norm / (total_norm + 1e-6)).
+ * out stays on the device; pass out + 1 as mv_adamw's clip_coef (it multiplies every gradient there: no extra pass).
+ * workspace: mv_grad_norm_workspace_bytes() bytes, 16-byte aligned.  Deterministic (fixed summation order). */
+size_t mv_grad_norm_workspace_bytes(void);
+int mv_grad_norm_clip(const float* g, long n, float grad_scale, float max_norm, float* out, void* workspace,
+                      size_t workspace_bytes, mv_stream_t stream);
+
+/* ---- dropout: nn.Dropout(p) in training mode -- vit.py:50,52 (FeedForward), :75 (Attention.to_out), :311 (embedding) ----
+ * y[i] = x[i] * keep_i / (1 - p), keep_i = (word (i & 3) of Philox4x32-10(counter = (i >> 2, offset), key = seed) >= p * 2^32).
+ * The same call with (seed, offset) on the output gradient IS the backward: no mask is stored.  x == y allowed.
+ * (The reference draws its mask from torch's generator: same distribution, different stream -- parity is statistical.) */
+int mv_dropout(const void* x, void* y, int dtype, long n, float p, uint64_t seed, uint64_t offset, mv_stream_t stream);
 
 #ifdef __cplusplus
 }

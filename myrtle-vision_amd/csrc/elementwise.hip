@@ -364,13 +364,41 @@ __global__ void minmax_end_kernel(float* minmax, const unsigned* ord) {
 }
 
 // ---- cross entropy, mean reduction.  One wave per sample; classes strided by `inner` -------------------
+// ---- labels: torch.nn.CrossEntropyLoss() semantics.  ignore_index = -100 contributes no loss and no gradient and is left
+// out of the mean's denominator; any OTHER label outside [0, C) is an error (torch device-asserts): it is never used as an
+// index, and it poisons the returned loss with NaN (no host synchronisation needed to notice).
+// stat[4] = {mean loss, number of counted labels, number of bad labels, unused}; stat[1..2] are filled by ce_label_scan_kernel
+// before the loss kernel runs on the same stream.
+constexpr long MV_IGNORE_INDEX = -100;
+__global__ __launch_bounds__(256) void ce_label_scan_kernel(const int64_t* __restrict__ labels, long total, int C,
+                                                            float* __restrict__ stat) {
+  float ok = 0.f, bad = 0.f;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+    const int64_t y = labels[i];
+    if (y >= 0 && y < C) ok += 1.f;
+    else if (y != MV_IGNORE_INDEX) bad += 1.f;
+  }
+  ok = wave_sum(ok);
+  bad = wave_sum(bad);
+  if ((threadIdx.x & 63) == 0) {                 // counts are integers below 2^24 per wave: fp32 atomics are exact and
+    if (ok != 0.f) atomicAdd(stat + 1, ok);      // order-independent up to 2^24 labels in total (12.8 M at 256 x 224^2)
+    if (bad != 0.f) atomicAdd(stat + 2, bad);
+  }
+}
+__device__ __forceinline__ float ce_inv_count(const float* stat) {
+  const float n = stat[1];
+  return n > 0.f ? 1.0f / n : __builtin_nanf("");      // every label ignored: torch returns nan as well
+}
+__device__ __forceinline__ float ce_poison(const float* stat, float v) { return stat[2] > 0.f ? __builtin_nanf("") : v; }
+
 template <typename DT>
 __global__ __launch_bounds__(256) void cross_entropy_kernel(const float* __restrict__ logits,
                                                             const int64_t* __restrict__ labels, float* loss_sum,
                                                             DT* dlogits, int ld_dl, int64_t* argmax, long outer, int C,
-                                                            long inner, float inv_count, float gscale) {
+                                                            long inner, float gscale) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const long total = outer * inner;
+  const float inv_count = ce_inv_count(loss_sum);
   float block_loss = 0.f;
   for (long smp = (long)blockIdx.x * 4 + wave; smp < total; smp += (long)gridDim.x * 4) {
     const long o = smp / inner, in = smp - o * inner;
@@ -391,10 +419,12 @@ __global__ __launch_bounds__(256) void cross_entropy_kernel(const float* __restr
     float s = 0.f;
     for (int c = lane; c < C; c += 64) s += expf(lp[(long)c * inner] - mx);
     s = wave_sum(s);
-    const int64_t y = labels[smp];
+    const int64_t yl = labels[smp];
+    const bool valid = yl >= 0 && yl < C;         // ignore_index (-100) and out-of-range labels: no loss, no gradient
+    const int y = valid ? (int)yl : -1;
     const float lse = mx + logf(s);
     if (lane == 0) {
-      block_loss += lse - lp[(long)y * inner];
+      if (valid) block_loss += lse - lp[(long)y * inner];
       if (argmax) argmax[smp] = am;
     }
     if (dlogits) {
@@ -403,20 +433,21 @@ __global__ __launch_bounds__(256) void cross_entropy_kernel(const float* __restr
         DT* dp = dlogits + o * ld_dl;
         for (int c = lane; c < ld_dl; c += 64) {
           float gq = 0.f;
-          if (c < C) gq = (expf(lp[c] - mx) * inv - (c == (int)y ? 1.f : 0.f)) * inv_count * gscale;
+          if (c < C && valid) gq = (expf(lp[c] - mx) * inv - (c == y ? 1.f : 0.f)) * inv_count * gscale;
           dp[c] = (DT)gq;
         }
       } else {
         DT* dp = dlogits + o * C * inner + in;
         for (int c = lane; c < C; c += 64)
-          dp[(long)c * inner] = (DT)((expf(lp[(long)c * inner] - mx) * inv - (c == (int)y ? 1.f : 0.f)) * inv_count * gscale);
+          dp[(long)c * inner] =
+              (DT)(valid ? (expf(lp[(long)c * inner] - mx) * inv - (c == y ? 1.f : 0.f)) * inv_count * gscale : 0.f);
       }
     }
   }
   __shared__ float red[4];
   if (lane == 0) red[wave] = block_loss;
   __syncthreads();
-  if (threadIdx.x == 0) atomicAdd(loss_sum, ((red[0] + red[1]) + (red[2] + red[3])) * inv_count);
+  if (threadIdx.x == 0) atomicAdd(loss_sum, ce_poison(loss_sum, ((red[0] + red[1]) + (red[2] + red[3])) * inv_count));
 }
 
 // segmentation layout (inner > 1): one THREAD per pixel, classes in a register loop, so that consecutive lanes
@@ -425,8 +456,9 @@ template <typename DT>
 __global__ __launch_bounds__(256) void cross_entropy_pixel_kernel(const float* __restrict__ logits,
                                                                   const int64_t* __restrict__ labels, float* loss_sum,
                                                                   DT* dlogits, int64_t* argmax, long outer, int C,
-                                                                  long inner, float inv_count, float gscale) {
+                                                                  long inner, float gscale) {
   const long total = outer * inner;
+  const float inv_count = ce_inv_count(loss_sum);
   float my_loss = 0.f;
   for (long smp = (long)blockIdx.x * 256 + threadIdx.x; smp < total; smp += (long)gridDim.x * 256) {
     const long o = smp / inner, in = smp - o * inner;
@@ -439,21 +471,24 @@ __global__ __launch_bounds__(256) void cross_entropy_pixel_kernel(const float* _
     }
     float s = 0.f;
     for (int c = 0; c < C; ++c) s += expf(lp[(long)c * inner] - mx);
-    const int y = (int)labels[smp];
-    my_loss += mx + logf(s) - lp[(long)y * inner];
+    const int64_t yl = labels[smp];
+    const bool valid = yl >= 0 && yl < C;
+    const int y = valid ? (int)yl : -1;
+    if (valid) my_loss += mx + logf(s) - lp[(long)y * inner];
     if (argmax) argmax[smp] = am;
     if (dlogits) {
       const float inv = 1.0f / s;
       DT* dp = dlogits + o * C * inner + in;
       for (int c = 0; c < C; ++c)
-        dp[(long)c * inner] = (DT)((expf(lp[(long)c * inner] - mx) * inv - (c == y ? 1.f : 0.f)) * inv_count * gscale);
+        dp[(long)c * inner] =
+            (DT)(valid ? (expf(lp[(long)c * inner] - mx) * inv - (c == y ? 1.f : 0.f)) * inv_count * gscale : 0.f);
     }
   }
   my_loss = wave_sum(my_loss);
   __shared__ float red[4];
   if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = my_loss;
   __syncthreads();
-  if (threadIdx.x == 0) atomicAdd(loss_sum, ((red[0] + red[1]) + (red[2] + red[3])) * inv_count);
+  if (threadIdx.x == 0) atomicAdd(loss_sum, ce_poison(loss_sum, ((red[0] + red[1]) + (red[2] + red[3])) * inv_count));
 }
 
 // ---- bilinear upsample, align_corners=False (ATen upsample_bilinear2d): src = (dst + 0.5) * scale - 0.5, clamped at 0
@@ -537,10 +572,81 @@ __global__ void upsample_bwd_kernel(const float* __restrict__ dout, float* __res
   }
 }
 
+// ---- gradient clipping (torch.nn.utils.clip_grad_norm_, classification/train.py:265-270) over the flat gradient arena:
+// two-stage deterministic sum of squares (fp32 per thread, fp64 across threads and blocks), then
+// out[0] = total_norm = sqrt(sum) * grad_scale, out[1] = clip coefficient = min(1, max_norm / (total_norm + 1e-6)).
+// The coefficient stays on the device and is folded into the AdamW kernel (no pass over the gradients, no host sync).
+constexpr int GN_PARTS = 1024;
+__global__ __launch_bounds__(256) void sumsq_partial_kernel(const float* __restrict__ g, long n, double* __restrict__ part) {
+  const long n4 = n >> 2;
+  float s = 0.f;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long)gridDim.x * 256) {
+    const float4 v = reinterpret_cast<const float4*>(g)[i];
+    s += v.x * v.x + v.y * v.y + v.z * v.z + v.w * v.w;
+  }
+  for (long i = (n4 << 2) + (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) s += g[i] * g[i];
+  __shared__ double red[256];
+  red[threadIdx.x] = (double)s;
+  __syncthreads();
+  for (int o = 128; o > 0; o >>= 1) {
+    if (threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) part[blockIdx.x] = red[0];
+}
+__global__ __launch_bounds__(256) void grad_norm_finish_kernel(const double* __restrict__ part, float gscale, float max_norm,
+                                                               float* __restrict__ out) {
+  __shared__ double red[256];
+  double s = 0.0;
+  for (int i = threadIdx.x; i < GN_PARTS; i += 256) s += part[i];
+  red[threadIdx.x] = s;
+  __syncthreads();
+  for (int o = 128; o > 0; o >>= 1) {
+    if (threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) {
+    const float total = (float)sqrt(red[0]) * gscale;
+    const float coef = max_norm / (total + 1e-6f);
+    out[0] = total;
+    out[1] = coef < 1.f ? coef : 1.f;
+  }
+}
+
+// ---- dropout (nn.Dropout, vit.py:50,52,75,311): y = x * keep / (1 - p), keep ~ Bernoulli(1 - p) from Philox4x32-10.
+// Element i takes word i & 3 of the Philox block with counter (i >> 2, offset) and key seed: the mask is a pure function of
+// (seed, offset, i), so the backward regenerates it from the same two numbers instead of storing it.
+__device__ __forceinline__ void philox4x32_10(unsigned c0, unsigned c1, unsigned c2, unsigned c3, unsigned k0, unsigned k1,
+                                              unsigned (&r)[4]) {
+#pragma unroll
+  for (int i = 0; i < 10; ++i) {
+    const unsigned hi0 = __umulhi(0xD2511F53u, c0), lo0 = 0xD2511F53u * c0;
+    const unsigned hi1 = __umulhi(0xCD9E8D57u, c2), lo1 = 0xCD9E8D57u * c2;
+    c0 = hi1 ^ c1 ^ k0; c1 = lo1; c2 = hi0 ^ c3 ^ k1; c3 = lo0;
+    k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+  }
+  r[0] = c0; r[1] = c1; r[2] = c2; r[3] = c3;
+}
+template <typename T>
+__global__ __launch_bounds__(256) void dropout_kernel(const T* __restrict__ x, T* __restrict__ y, long n, unsigned thr,
+                                                      float scale, uint64_t seed, uint64_t offset) {
+  const long n4 = (n + 3) >> 2;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long)gridDim.x * 256) {
+    unsigned r[4];
+    philox4x32_10((unsigned)i, (unsigned)((uint64_t)i >> 32), (unsigned)offset, (unsigned)(offset >> 32), (unsigned)seed,
+                  (unsigned)(seed >> 32), r);
+    const long e0 = i << 2;
+#pragma unroll
+    for (int e = 0; e < 4; ++e)
+      if (e0 + e < n) y[e0 + e] = (T)(r[e] >= thr ? (float)x[e0 + e] * scale : 0.f);
+  }
+}
+
 // ---- AdamW (torch.optim.AdamW semantics): p *= 1 - lr*wd; m,v update; p -= lr/bc1 * m / (sqrt(v)/sqrt(bc2) + eps)
 __global__ void adamw_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
                              float* __restrict__ v, long n, float lr, float b1, float b2, float eps, float wd, float bc1,
-                             float bc2, float gscale) {
+                             float bc2, float gscale, const float* __restrict__ clip_coef) {
+  if (clip_coef) gscale *= clip_coef[0];      // clip_grad_norm_'s min(1, max_norm / (norm + 1e-6)), computed on the device
   const float step = lr / bc1, inv_sqrt_bc2 = rsqrtf(bc2);
   const long n4 = n >> 2;
   for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long)gridDim.x * blockDim.x) {
@@ -798,26 +904,26 @@ extern "C" int mv_cross_entropy(const float* logits, const int64_t* labels, floa
   MV_REQUIRE(outer >= 0 && C > 0 && inner >= 1, MV_ERR_SHAPE);
   MV_REQUIRE(!dlogits || dl_dtype == MV_F32 || dl_dtype == MV_BF16, MV_ERR_UNSUPPORTED);
   MV_REQUIRE(!dlogits || inner > 1 || ld_dl >= C, MV_ERR_SHAPE);
-  if (hipMemsetAsync(loss_sum, 0, sizeof(float), S_) != hipSuccess) return MV_ERR_LAUNCH;
+  if (hipMemsetAsync(loss_sum, 0, 4 * sizeof(float), S_) != hipSuccess) return MV_ERR_LAUNCH;
   const long total = outer * inner;
   if (total == 0) return MV_OK;
-  const float inv_count = 1.0f / (float)total;
+  ce_label_scan_kernel<<<ew_grid(total), 256, 0, S_>>>(labels, total, C, loss_sum);
   if (inner == 1) {
     const int grid = ew_grid(total, 4);
     if (dl_dtype == MV_BF16 && dlogits)
       cross_entropy_kernel<bf16_t><<<grid, 256, 0, S_>>>(logits, labels, loss_sum, (bf16_t*)dlogits, ld_dl, argmax, outer,
-                                                         C, inner, inv_count, grad_scale);
+                                                         C, inner, grad_scale);
     else
       cross_entropy_kernel<float><<<grid, 256, 0, S_>>>(logits, labels, loss_sum, (float*)dlogits, ld_dl, argmax, outer, C,
-                                                        inner, inv_count, grad_scale);
+                                                        inner, grad_scale);
   } else {
     const int grid = ew_grid(total);
     if (dl_dtype == MV_BF16 && dlogits)
       cross_entropy_pixel_kernel<bf16_t><<<grid, 256, 0, S_>>>(logits, labels, loss_sum, (bf16_t*)dlogits, argmax, outer,
-                                                               C, inner, inv_count, grad_scale);
+                                                               C, inner, grad_scale);
     else
       cross_entropy_pixel_kernel<float><<<grid, 256, 0, S_>>>(logits, labels, loss_sum, (float*)dlogits, argmax, outer, C,
-                                                              inner, inv_count, grad_scale);
+                                                              inner, grad_scale);
   }
   MV_CHECK_LAUNCH();
   return MV_OK;
@@ -845,12 +951,41 @@ extern "C" int mv_upsample_bilinear_bwd(const float* dbig, float* dsmall, long s
 
 extern "C" int mv_adamw(float* p, const float* g, float* m, float* v, long n, float lr, float beta1, float beta2,
                         float eps, float weight_decay, float bias_corr1, float bias_corr2, float grad_scale,
-                        mv_stream_t stream) {
+                        const float* clip_coef, mv_stream_t stream) {
   MV_REQUIRE(n >= 0, MV_ERR_SHAPE);
   if (n == 0) return MV_OK;
   MV_REQUIRE(mv_aligned16(p) && mv_aligned16(g) && mv_aligned16(m) && mv_aligned16(v), MV_ERR_ALIGN);
   adamw_kernel<<<ew_grid((n + 3) / 4), 256, 0, S_>>>(p, g, m, v, n, lr, beta1, beta2, eps, weight_decay, bias_corr1,
-                                                     bias_corr2, grad_scale);
+                                                     bias_corr2, grad_scale, clip_coef);
+  MV_CHECK_LAUNCH();
+  return MV_OK;
+}
+
+extern "C" size_t mv_grad_norm_workspace_bytes(void) { return GN_PARTS * sizeof(double); }
+
+extern "C" int mv_grad_norm_clip(const float* g, long n, float grad_scale, float max_norm, float* out, void* workspace,
+                                 size_t workspace_bytes, mv_stream_t stream) {
+  MV_REQUIRE(n >= 0 && max_norm >= 0.f, MV_ERR_SHAPE);
+  MV_REQUIRE(mv_aligned16(g) && mv_aligned16(workspace), MV_ERR_ALIGN);
+  MV_REQUIRE(workspace_bytes >= mv_grad_norm_workspace_bytes(), MV_ERR_WORKSPACE);
+  sumsq_partial_kernel<<<GN_PARTS, 256, 0, S_>>>(g, n, (double*)workspace);
+  grad_norm_finish_kernel<<<1, 256, 0, S_>>>((const double*)workspace, grad_scale, max_norm, out);
+  MV_CHECK_LAUNCH();
+  return MV_OK;
+}
+
+extern "C" int mv_dropout(const void* x, void* y, int dtype, long n, float p, uint64_t seed, uint64_t offset,
+                          mv_stream_t stream) {
+  MV_REQUIRE(n >= 0 && p >= 0.f && p < 1.f, MV_ERR_SHAPE);
+  MV_REQUIRE(dtype == MV_F32 || dtype == MV_BF16, MV_ERR_UNSUPPORTED);
+  if (n == 0) return MV_OK;
+  const unsigned thr = (unsigned)((double)p * 4294967296.0);       // keep  <=>  random u32 >= thr
+  const float scale = 1.0f / (1.0f - p);
+  const int grid = ew_grid((n + 3) / 4);
+  if (dtype == MV_F32)
+    dropout_kernel<float><<<grid, 256, 0, S_>>>((const float*)x, (float*)y, n, thr, scale, seed, offset);
+  else
+    dropout_kernel<bf16_t><<<grid, 256, 0, S_>>>((const bf16_t*)x, (bf16_t*)y, n, thr, scale, seed, offset);
   MV_CHECK_LAUNCH();
   return MV_OK;
 }

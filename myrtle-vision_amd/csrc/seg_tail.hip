@@ -53,7 +53,7 @@ __global__ __launch_bounds__(256) void seg_ce_fwd_kernel(const float* __restrict
   __syncthreads();
   const int npix = H * W;
   const int p0 = blockIdx.x * SEG_PX_PER_BLOCK;
-  float my_loss = 0.f, my_hit = 0.f;
+  float my_loss = 0.f, my_hit = 0.f, my_ok = 0.f, my_bad = 0.f;
   for (int p = p0 + threadIdx.x; p < p0 + SEG_PX_PER_BLOCK && p < npix; p += 256) {
     const int Y = p / W, X = p - Y * W;
     int y0, y1, x0, x1;
@@ -62,7 +62,13 @@ __global__ __launch_bounds__(256) void seg_ce_fwd_kernel(const float* __restrict
     seg_src(X, sw, w, x0, x1, lx);
     const float *s00 = smap + (y0 * w + x0) * C, *s01 = smap + (y0 * w + x1) * C;
     const float *s10 = smap + (y1 * w + x0) * C, *s11 = smap + (y1 * w + x1) * C;
-    const int y = (int)labels[b * npix + p];
+    // nn.CrossEntropyLoss() labels: -100 (ignore_index) is skipped and not counted; anything else outside [0, C) is an
+    // error that poisons the loss (never used as an index)
+    const int64_t yl = labels[b * npix + p];
+    const bool valid = yl >= 0 && yl < C;
+    const int y = valid ? (int)yl : -1;
+    my_ok += valid ? 1.f : 0.f;
+    my_bad += (!valid && yl != -100) ? 1.f : 0.f;
     float mx = -INFINITY, vy = 0.f;
     int am = 0;
     for (int c = 0; c < C; ++c) {
@@ -75,43 +81,55 @@ __global__ __launch_bounds__(256) void seg_ce_fwd_kernel(const float* __restrict
     const float l = mx + logf(s);
     lse[b * npix + p] = l;
     pred[b * npix + p] = (uint8_t)am;
-    my_loss += l - vy;
+    my_loss += valid ? l - vy : 0.f;
     my_hit += (am == y) ? 1.f : 0.f;
   }
   my_loss = wave_sum(my_loss);
   my_hit = wave_sum(my_hit);
-  __shared__ float red[8];
+  my_ok = wave_sum(my_ok);
+  my_bad = wave_sum(my_bad);
+  __shared__ float red[16];
   if ((threadIdx.x & 63) == 0) {
     red[threadIdx.x >> 6] = my_loss;
     red[4 + (threadIdx.x >> 6)] = my_hit;
+    red[8 + (threadIdx.x >> 6)] = my_ok;
+    red[12 + (threadIdx.x >> 6)] = my_bad;
   }
   __syncthreads();
   if (threadIdx.x == 0) {
     const long blk = b * gridDim.x + blockIdx.x;
-    partials[2 * blk] = (red[0] + red[1]) + (red[2] + red[3]);
-    partials[2 * blk + 1] = (red[4] + red[5]) + (red[6] + red[7]);
+    partials[4 * blk] = (red[0] + red[1]) + (red[2] + red[3]);
+    partials[4 * blk + 1] = (red[4] + red[5]) + (red[6] + red[7]);
+    partials[4 * blk + 2] = (red[8] + red[9]) + (red[10] + red[11]);
+    partials[4 * blk + 3] = (red[12] + red[13]) + (red[14] + red[15]);
   }
 }
 
-// stats[0] = mean loss, stats[1] = pixel accuracy; fixed summation order
-__global__ __launch_bounds__(256) void seg_ce_finish_kernel(const float* __restrict__ partials, long nblk, float inv_count,
+// stats[0] = mean loss over the counted labels (NaN if a label is out of range, or none is counted), stats[1] = pixel accuracy
+// over ALL pixels (the reference's (argmax == labels).float().mean()), stats[2] = counted labels, stats[3] = bad labels;
+// fixed summation order
+__global__ __launch_bounds__(256) void seg_ce_finish_kernel(const float* __restrict__ partials, long nblk, float inv_pixels,
                                                             float* __restrict__ stats) {
-  float a = 0.f, c = 0.f;
+  float v[4] = {0.f, 0.f, 0.f, 0.f};
   for (long i = threadIdx.x; i < nblk; i += 256) {
-    a += partials[2 * i];
-    c += partials[2 * i + 1];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) v[k] += partials[4 * i + k];
   }
-  a = wave_sum(a);
-  c = wave_sum(c);
-  __shared__ float red[8];
-  if ((threadIdx.x & 63) == 0) {
-    red[threadIdx.x >> 6] = a;
-    red[4 + (threadIdx.x >> 6)] = c;
+  __shared__ float red[16];
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    v[k] = wave_sum(v[k]);
+    if ((threadIdx.x & 63) == 0) red[4 * k + (threadIdx.x >> 6)] = v[k];
   }
   __syncthreads();
   if (threadIdx.x == 0) {
-    stats[0] = ((red[0] + red[1]) + (red[2] + red[3])) * inv_count;
-    stats[1] = ((red[4] + red[5]) + (red[6] + red[7])) * inv_count;
+    float t[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) t[k] = (red[4 * k] + red[4 * k + 1]) + (red[4 * k + 2] + red[4 * k + 3]);
+    stats[0] = (t[3] > 0.f || t[2] <= 0.f) ? __builtin_nanf("") : t[0] / t[2];
+    stats[1] = t[1] * inv_pixels;
+    stats[2] = t[2];
+    stats[3] = t[3];
   }
 }
 
@@ -119,8 +137,8 @@ template <typename DT>
 __global__ __launch_bounds__(256) void seg_ce_bwd_kernel(const float* __restrict__ small,
                                                          const int64_t* __restrict__ labels,
                                                          const float* __restrict__ lse, DT* __restrict__ dsmall, int ld_ds,
-                                                         float gscale, int C, int h, int w, int H, int W, float sh,
-                                                         float sw) {
+                                                         float gscale, const float* __restrict__ stats, int C, int h, int w,
+                                                         int H, int W, float sh, float sw) {
   extern __shared__ float smem[];
   float* smap = smem;                                   // [h*w][C]
   float* colacc = smem + h * w * C;                     // [W][C]
@@ -151,7 +169,9 @@ __global__ __launch_bounds__(256) void seg_ce_bwd_kernel(const float* __restrict
       const float *s00 = smap + (y0 * w + x0) * C, *s01 = smap + (y0 * w + x1) * C;
       const float *s10 = smap + (y1 * w + x0) * C, *s11 = smap + (y1 * w + x1) * C;
       const long pix = b * npix + (long)Y * W + X;
-      const int y = (int)labels[pix];
+      const int64_t yl = labels[pix];
+      if (yl < 0 || yl >= C) continue;                  // ignored (or bad) label: no gradient from this pixel
+      const int y = (int)yl;
       const float l = lse[pix];
 #pragma unroll
       for (int c = 0; c < SEG_CMAX; ++c)
@@ -162,6 +182,9 @@ __global__ __launch_bounds__(256) void seg_ce_bwd_kernel(const float* __restrict
       if (c < C) colacc[X * C + c] = acc[c];
   }
   __syncthreads();
+  // mean over the COUNTED labels (stats[2] of the forward pass); without stats: over every pixel
+  const float cnt = stats ? stats[2] : (float)gridDim.y * (float)npix;
+  const float gs = cnt > 0.f ? gscale / cnt : 0.f;
   for (int i = threadIdx.x; i < w * ld_ds; i += 256) {
     const int sx = i / ld_ds, c = i - sx * ld_ds;
     float s = 0.f;
@@ -179,7 +202,7 @@ __global__ __launch_bounds__(256) void seg_ce_bwd_kernel(const float* __restrict
         if (wx != 0.f) s += wx * colacc[X * C + c];
       }
     }
-    dsmall[(b * h * w + (long)sy * w + sx) * ld_ds + c] = (DT)(s * gscale);
+    dsmall[(b * h * w + (long)sy * w + sx) * ld_ds + c] = (DT)(s * gs);
   }
 }
 
@@ -201,7 +224,7 @@ extern "C" int mv_seg_ce_fwd(const float* small, const int64_t* labels, float* l
   MV_REQUIRE(lds <= SEG_LDS_LIMIT, MV_ERR_UNSUPPORTED);
   MV_REQUIRE(B <= 65535, MV_ERR_SHAPE);
   if (B == 0) {
-    if (hipMemsetAsync(stats, 0, 2 * sizeof(float), S_) != hipSuccess) return MV_ERR_LAUNCH;
+    if (hipMemsetAsync(stats, 0, 4 * sizeof(float), S_) != hipSuccess) return MV_ERR_LAUNCH;
     return MV_OK;
   }
   const int bpi = (int)(((long)H * W + SEG_PX_PER_BLOCK - 1) / SEG_PX_PER_BLOCK);
@@ -212,8 +235,9 @@ extern "C" int mv_seg_ce_fwd(const float* small, const int64_t* labels, float* l
   return MV_OK;
 }
 
-extern "C" int mv_seg_ce_bwd(const float* small, const int64_t* labels, const float* lse, void* dsmall, int ds_dtype,
-                             int ld_ds, float grad_scale, int B, int C, int h, int w, int H, int W, mv_stream_t stream) {
+extern "C" int mv_seg_ce_bwd(const float* small, const int64_t* labels, const float* lse, const float* stats, void* dsmall,
+                             int ds_dtype, int ld_ds, float grad_scale, int B, int C, int h, int w, int H, int W,
+                             mv_stream_t stream) {
   MV_REQUIRE(B >= 0 && C > 0 && h > 0 && w > 0 && H > 0 && W > 0 && ld_ds >= C, MV_ERR_SHAPE);
   MV_REQUIRE(ds_dtype == MV_F32 || ds_dtype == MV_BF16, MV_ERR_UNSUPPORTED);
   MV_REQUIRE(C <= SEG_CMAX, MV_ERR_UNSUPPORTED);
@@ -221,13 +245,12 @@ extern "C" int mv_seg_ce_bwd(const float* small, const int64_t* labels, const fl
   MV_REQUIRE(lds <= SEG_LDS_LIMIT, MV_ERR_UNSUPPORTED);
   MV_REQUIRE(B <= 65535, MV_ERR_SHAPE);
   if (B == 0) return MV_OK;
-  const float gs = grad_scale / ((float)B * (float)H * (float)W);
   if (ds_dtype == MV_BF16)
-    seg_ce_bwd_kernel<bf16_t><<<dim3(h, B), 256, lds, S_>>>(small, labels, lse, (bf16_t*)dsmall, ld_ds, gs, C, h, w, H, W,
-                                                            (float)h / (float)H, (float)w / (float)W);
+    seg_ce_bwd_kernel<bf16_t><<<dim3(h, B), 256, lds, S_>>>(small, labels, lse, (bf16_t*)dsmall, ld_ds, grad_scale, stats, C, h,
+                                                            w, H, W, (float)h / (float)H, (float)w / (float)W);
   else
-    seg_ce_bwd_kernel<float><<<dim3(h, B), 256, lds, S_>>>(small, labels, lse, (float*)dsmall, ld_ds, gs, C, h, w, H, W,
-                                                           (float)h / (float)H, (float)w / (float)W);
+    seg_ce_bwd_kernel<float><<<dim3(h, B), 256, lds, S_>>>(small, labels, lse, (float*)dsmall, ld_ds, grad_scale, stats, C, h, w,
+                                                           H, W, (float)h / (float)H, (float)w / (float)W);
   MV_CHECK_LAUNCH();
   return MV_OK;
 }

@@ -10,6 +10,8 @@ seeding, batch-size solver, one process per GPU, rank-0 checkpoints every ``iter
   accumulation window (the reference's DDP all-reduces every micro-batch; the result is identical);
 * the two detection-only parameters are left out of the optimizer/all-reduce (the reference's DDP dies on them);
 * ``GradScaler`` is dropped (a numerical no-op without autocast, SURVEY 9.5);
+* ``clip_grad`` clips the gradient of the whole optimizer step (after accumulation and all-reduce) rather than after every
+  micro-batch backward: identical when ``n_batch_accum == 1``, the well-defined variant otherwise;
 * ``pretrained_backbone`` must be a local timm-format state dict (no network); a bare timm model NAME that is not a
   file means "random init" with a warning.
 """
@@ -232,8 +234,9 @@ def train_worker(rank, num_gpus, config, task="classification"):
     reducer = GradAllReducer(optimizer.arena)
     broadcast_parameters(optimizer.arena)
     optimizer.grad_scale = reducer.grad_scale
-    if optimizer_args.clip_grad is not None:
-        raise NotImplementedError("clip_grad is null in every reference config; gradient clipping is not implemented")
+    # classification/train.py:265-270 (clip_grad_norm_ after backward): here the norm is taken once per optimizer step over
+    # the flat (all-reduced, accumulated) gradient arena and the coefficient is applied inside the AdamW kernel
+    optimizer.max_grad_norm = optimizer_args.clip_grad
 
     vit.train()
     epoch_offset = max(0, int(batch_size * world * iteration / max(len(trainset), 1)))

@@ -14,6 +14,8 @@ The residual stream and all gradients w.r.t. parameters are fp32; activations ar
 (``prec='fp32'``: exact-parity mode).  Backward runs on autograd's worker thread: everything here is stateless
 apart from caches keyed by tensor identity.
 """
+import weakref
+
 import torch
 from torch.autograd import Function
 
@@ -157,6 +159,33 @@ def add(a, b):
     return _Add.apply(a, b)
 
 
+class _Dropout(Function):
+    """nn.Dropout(p) in training mode (vit.py:50,52,75,311).  The mask is a function of (seed, offset) drawn from torch's
+    CPU generator in forward -- reproducible under ``seed_everything`` -- and regenerated in backward, never stored."""
+
+    @staticmethod
+    def forward(ctx, x, p):
+        ops.require_cuda(x)
+        seed, offset = (int(v) for v in torch.randint(0, 2 ** 62, (2,), dtype=torch.int64).tolist())
+        ctx.rng = (float(p), seed, offset)
+        return ops.dropout(_c(x), p, seed, offset)
+
+    @staticmethod
+    def backward(ctx, dy):
+        p, seed, offset = ctx.rng
+        return ops.dropout(_c(dy), p, seed, offset), None
+
+
+def dropout(x, p, training=True):
+    if p == 0.0 or not training:
+        return x
+    if not 0.0 <= p < 1.0:
+        raise ValueError(f"dropout probability has to be in [0, 1), got {p}")
+    if x.dtype not in (torch.float32, torch.bfloat16):
+        x = x.float()
+    return _Dropout.apply(x, p)
+
+
 class _AttentionFused(Function):
     """softmax(q k^T * scale) v on the fused MFMA kernel.  qkv bf16 [B, N, 3*H*64] -> [B, N, H*64]."""
 
@@ -283,7 +312,7 @@ class _PatchEmbed(Function):
         ctx.dims = (B, T, D, pd, npatch)
         ctx.pos_shape, ctx.cls_shape = pos.shape, cls_token.shape
         ctx.params = (weight, bias, cls_token, pos if pos.shape[-2:] == (T, D) and pos.is_leaf else None)
-        _chain_set(x, None)
+        chain_reset()
         return x
 
     @staticmethod
@@ -342,18 +371,24 @@ def _ln_bwd_with_side(dy, x, D, g, b, mean, rstd, dout, M, adt, up_bias=None):
     return dx, dg, db
 
 
-# Forward-order link between consecutive block functions: (address of the tensor a block returned, the bias of the
-# Linear that produced it).  The next block reads it to learn whose bias gradient the column sums of its dx are.
+# Forward-order link between consecutive block functions: (the tensor OBJECT a block returned, held weakly, and the bias of
+# the Linear that produced it).  The next block reads it to learn whose bias gradient the column sums of its dx are.
+# Identity, not address: a freed-and-reallocated buffer at the same address can never inherit the link.
 _chain = [None]
 
 
 def _chain_set(out, bias):
-    _chain[0] = (out.data_ptr(), bias)
+    _chain[0] = (weakref.ref(out), bias) if bias is not None else None
 
 
 def _chain_take(x):
     c = _chain[0]
-    return c[1] if c is not None and c[0] == x.data_ptr() else None
+    return c[1] if c is not None and c[0]() is x else None
+
+
+def chain_reset():
+    """Forget the link (start of a forward pass, or a block called on its own)."""
+    _chain[0] = None
 
 
 
@@ -561,6 +596,31 @@ def _seg_small_bwd(saved, small_params, dims, dl, ld):
     return dx, dg, db, dw, dbias
 
 
+class _UpsampleBilinear(Function):
+    """Rearrange('b (h w) c -> b c h w') + nn.Upsample(size, 'bilinear') (vit.py:355,367-371) on a decoder output
+    [B, h*w, C] consumed in place -> fp32 [B, C, S, S].  Used when the decoder runs module by module (fake-quantised
+    LayerNorm / Linear); the fused heads below call the same kernels."""
+
+    @staticmethod
+    def forward(ctx, small, grid, size):
+        ops.require_cuda(small)
+        B, hw, C = small.shape
+        small = _c(small.float())
+        ctx.dims = (B, C, grid, size)
+        return ops.upsample_bilinear_fwd(small, hw * C, 1, C, B, C, grid, grid, size, size)
+
+    @staticmethod
+    def backward(ctx, dbig):
+        B, C, grid, size = ctx.dims
+        dsmall = torch.empty(B, grid * grid, C, dtype=torch.float32, device=dbig.device)
+        ops.upsample_bilinear_bwd(_c(dbig.float()), dsmall, grid * grid * C, 1, C, B, C, grid, grid, size, size)
+        return dsmall, None, None
+
+
+def upsample_bilinear(small, grid, size):
+    return _UpsampleBilinear.apply(small, grid, size)
+
+
 class _SegHead(Function):
     """SegmentationDecoder: upsample(rearrange(linear(norm(x[:, 1:])))) (vit.py:359-374) -> fp32 [B, C, S, S]."""
 
@@ -609,7 +669,7 @@ class _SegHeadLoss(Function):
         if ctx.needs:
             ld = ops.pad8(C) if adt == torch.bfloat16 else C
             # the gradient of the mean loss, produced now (labels and lse are hot), scaled by the incoming g in backward
-            dl = ops.seg_ce_bwd(small, labels, lse, B, C, grid, grid, size, size, grad_dtype=adt, ld=ld)
+            dl = ops.seg_ce_bwd(small, labels, lse, B, C, grid, grid, size, size, grad_dtype=adt, ld=ld, stats=stats)
             ctx.save_for_backward(dl, *saved)
             ctx.dims = (B, T, D, C, ld)
         ctx.mark_non_differentiable(pred)

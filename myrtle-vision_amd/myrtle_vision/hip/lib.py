@@ -16,7 +16,7 @@ MV_F32, MV_BF16 = 0, 1
 EPI_NONE, EPI_GELU, EPI_RESIDUAL, EPI_DGELU, EPI_EMBED, EPI_GELU_GRAD, EPI_MUL = 0, 1, 2, 3, 4, 5, 6
 
 _P, _I, _L, _F, _Z = ctypes.c_void_p, ctypes.c_int, ctypes.c_long, ctypes.c_float, ctypes.c_size_t
-_KIND = {"p": _P, "i": _I, "l": _L, "f": _F, "z": _Z}
+_KIND = {"p": _P, "i": _I, "l": _L, "f": _F, "z": _Z, "Q": ctypes.c_uint64}
 
 # name -> (argument kinds, return type); one line per declaration in include/myrtle_vision_hip.h, same order
 SIGNATURES = {
@@ -56,12 +56,15 @@ SIGNATURES = {
     "mv_gemm_force_variant": ("ii", _I),
     "mv_seg_ce_partials": ("iii", _L),
     "mv_seg_ce_fwd": ("pppppp" "iiiiii" "p", _I),
-    "mv_seg_ce_bwd": ("pppp" "ii" "f" "iiiiii" "p", _I),
+    "mv_seg_ce_bwd": ("ppppp" "ii" "f" "iiiiii" "p", _I),
     "mv_image_prepare": ("plii" "pppp" "i" "p" "ffffff" "p" "iii" "p", _I),
     "mv_mask_prepare": ("plii" "pp" "p" "i" "p" "iii" "p", _I),
     "mv_image_resize_u8": ("plii" "pppp" "i" "p" "iii" "p", _I),
     "mv_mask_resize_u8": ("plii" "pp" "p" "iii" "p", _I),
-    "mv_adamw": ("pppp" "l" "ffffffff" "p", _I),
+    "mv_adamw": ("pppp" "l" "ffffffff" "p" "p", _I),
+    "mv_grad_norm_workspace_bytes": ("", _Z),
+    "mv_grad_norm_clip": ("pl" "ff" "p" "pz" "p", _I),
+    "mv_dropout": ("ppi" "l" "f" "QQ" "p", _I),
 }
 
 _lock = threading.Lock()

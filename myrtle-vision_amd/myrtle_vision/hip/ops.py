@@ -57,6 +57,7 @@ class KernelTimer:
         """``sample_every`` = k: only the launches of every k-th step (``next_step()``) are bracketed by events -- the
         event packets between kernels cost ~3 % of a ViT-B step when every launch is timed."""
         self.records = {}          # kernel name -> list of (start_event, end_event, algorithmic_flops)
+        self.by_shape = {}         # shape label -> the same tuples
         self.sample_every = max(int(sample_every), 1)
         self.step = -1
         self.active = True
@@ -72,12 +73,24 @@ class KernelTimer:
         e.record()
         return e
 
-    def end(self, name, start, flops):
+    def end(self, name, start, flops, shape=None):
         if start is None:
             return
         e = torch.cuda.Event(enable_timing=True)
         e.record()
         self.records.setdefault(name, []).append((start, e, flops))
+        if shape is not None:
+            self.by_shape.setdefault(shape, []).append((start, e, flops))
+
+    def shape_summary(self):
+        """-> {shape label: dict(launches, avg_us, tflops)}: the same launches as ``summary`` split by product shape."""
+        torch.cuda.synchronize()
+        out = {}
+        for shape, recs in self.by_shape.items():
+            ms = sum(s.elapsed_time(e) for s, e, _ in recs)
+            out[shape] = dict(launches=len(recs), avg_us=1e3 * ms / len(recs),
+                              tflops=sum(f for _, _, f in recs) / (ms * 1e-3) / 1e12 if ms > 0 else 0.0)
+        return out
 
     def summary(self):
         """-> {name: dict(launches, total_ms, avg_us, flops_per_launch, tflops)} (synchronises)."""
@@ -271,7 +284,7 @@ def linear_fwd(x, M, K, weight, bias, out, ldc, *, lda=None, epi=EPI_NONE, aux=N
                                     _p(aux), ld_aux, aux_i, _p(out2), ld_out2, _s()),
               "gemm_nt_bf16", M=M, N=N, K=K, epi=epi)
         if t0 is not None:
-            _timer.end("gemm_nt_bf16", t0, 2.0 * M * N * K)
+            _timer.end("gemm_nt_bf16", t0, 2.0 * M * N * K, shape=f"fwd N{N} K{K} epi{epi}")
     else:
         w = weight.detach()
         check(lib().mv_gemm_f32(_p(x), lda, 1, 0, 0, _p(w), 1, w.stride(0), 0, 0, _p(out), ldc, 1, 0, 0, M, N, K, 1, 1,
@@ -292,7 +305,7 @@ def linear_dx(dy, M, N, weight, out, ldc, *, ld_dy=None, epi=EPI_NONE, aux=None,
                                     _p(aux), ld_aux, 0, _p(colsum_partial), K if colsum_partial is not None else 0, _s()),
               "gemm_nt_bf16(dx)", M=M, N=K, K=N, epi=epi)
         if t0 is not None:
-            _timer.end("gemm_nt_bf16", t0, 2.0 * M * N * K)
+            _timer.end("gemm_nt_bf16", t0, 2.0 * M * N * K, shape=f"dx N{K} K{N} epi{epi}")
     else:
         w = weight.detach()
         check(lib().mv_gemm_f32(_p(dy), ld_dy, 1, 0, 0, _p(w), w.stride(0), 1, 0, 0, _p(out), ldc, 1, 0, 0, M, K, N, 1,
@@ -315,7 +328,7 @@ def linear_dw(dy, x, M, N, K, *, ld_dy=None, ldx=None, want_bias=True, weight=No
         check(lib().mv_gemm_tn_bf16(_p(dy), ld_dy, _p(x), ldx, _p(dw), K, N, K, M, 0, _p(db), _p(ws), ws.numel(), _s()),
               "gemm_tn_bf16", M=N, N=K, Kc=M)
         if t0 is not None:
-            _timer.end("gemm_tn_bf16(+reduce+colsum)", t0, 2.0 * M * N * K)
+            _timer.end("gemm_tn_bf16(+reduce+colsum)", t0, 2.0 * M * N * K, shape=f"dw N{N} K{K} bias{int(want_bias)}")
     else:
         check(lib().mv_gemm_f32(_p(dy), 1, ld_dy, 0, 0, _p(x), ldx, 1, 0, 0, _p(dw), K, 1, 0, 0, N, K, M, 1, 1, 1.0, 0,
                                 None, EPI_NONE, None, 0, 0, None, 0, _s()), "gemm_f32(dw)", M=N, N=K, K=M)
@@ -526,6 +539,9 @@ def linear_codes(xc, wc, M, N, K, alpha, bias, out, residual=None):
 
 def minmax_update(x, state):
     """state: fp32 [4] on device, [0]=running min, [1]=running max (init +inf/-inf)."""
+    require_cuda(x, state)                     # the kernel updates ``state`` with device atomics: never a host pointer
+    if state.device != x.device or state.dtype != torch.float32 or not state.is_contiguous():
+        raise RuntimeError("minmax_update: state must be a contiguous fp32 tensor on the input's device")
     xf = x.detach().float().contiguous()
     check(lib().mv_minmax(_p(xf), xf.numel(), _p(state), _s()), "minmax", n=xf.numel())
 
@@ -545,7 +561,8 @@ def cross_entropy(logits, labels, *, want_grad, grad_dtype=torch.float32, ld_dl=
     inner = 1
     for s in logits.shape[2:]:
         inner *= s
-    loss = torch.empty(1, dtype=torch.float32, device=logits.device)
+    stat = torch.empty(4, dtype=torch.float32, device=logits.device)   # mean loss, counted labels, bad labels, unused
+    loss = stat[:1]
     dl = None
     if want_grad:
         if inner == 1:
@@ -555,7 +572,7 @@ def cross_entropy(logits, labels, *, want_grad, grad_dtype=torch.float32, ld_dl=
             ld_dl = C
             dl = torch.empty(logits.shape, dtype=grad_dtype, device=logits.device)
     am = torch.empty(labels.shape, dtype=torch.int64, device=logits.device) if want_argmax else None
-    check(lib().mv_cross_entropy(_p(logits), _p(labels), _p(loss), _p(dl), _DT[grad_dtype], ld_dl or C, _p(am), outer, C,
+    check(lib().mv_cross_entropy(_p(logits), _p(labels), _p(stat), _p(dl), _DT[grad_dtype], ld_dl or C, _p(am), outer, C,
                                  inner, 1.0, _s()), "cross_entropy", outer=outer, C=C, inner=inner)
     return loss, dl, am
 
@@ -592,18 +609,19 @@ def seg_ce_fwd(small, labels, B, C, h, w, H, W):
     lse = torch.empty(B, H, W, dtype=torch.float32, device=dev)
     pred = torch.empty(B, H, W, dtype=torch.uint8, device=dev)
     nblk = lib().mv_seg_ce_partials(B, H, W)
-    partials = torch.empty(max(2 * nblk, 2), dtype=torch.float32, device=dev)
-    stats = torch.empty(2, dtype=torch.float32, device=dev)
+    partials = torch.empty(max(4 * nblk, 4), dtype=torch.float32, device=dev)
+    stats = torch.empty(4, dtype=torch.float32, device=dev)      # mean loss, pixel accuracy, counted labels, bad labels
     check(lib().mv_seg_ce_fwd(_p(small), _p(labels), _p(lse), _p(pred), _p(partials), _p(stats), B, C, h, w, H, W, _s()),
           "seg_ce_fwd", B=B, C=C, h=h, w=w, H=H, W=W)
     return stats, lse, pred, labels
 
 
-def seg_ce_bwd(small, labels, lse, B, C, h, w, H, W, *, grad_dtype=torch.float32, ld=None, grad_scale=1.0):
+def seg_ce_bwd(small, labels, lse, B, C, h, w, H, W, *, grad_dtype=torch.float32, ld=None, grad_scale=1.0, stats=None):
+    """``stats``: the forward's (its label count is the mean's denominator); None = every pixel counts."""
     ld = C if ld is None else ld
     ds = torch.empty(B * h * w, ld, dtype=grad_dtype, device=small.device)
-    check(lib().mv_seg_ce_bwd(_p(small), _p(labels), _p(lse), _p(ds), _DT[grad_dtype], ld, grad_scale, B, C, h, w, H, W,
-                              _s()), "seg_ce_bwd", B=B, C=C, h=h, w=w, H=H, W=W, ld=ld)
+    check(lib().mv_seg_ce_bwd(_p(small), _p(labels), _p(lse), _p(stats), _p(ds), _DT[grad_dtype], ld, grad_scale, B, C, h, w,
+                              H, W, _s()), "seg_ce_bwd", B=B, C=C, h=h, w=w, H=H, W=W, ld=ld)
     return ds
 
 
@@ -653,10 +671,32 @@ def mask_prepare(mask, yi, xi, flip, add=0):
     return out
 
 
-def adamw_step(p, g, m, v, *, lr, beta1, beta2, eps, weight_decay, step, grad_scale=1.0):
-    """In-place AdamW on flat fp32 tensors (torch.optim.AdamW semantics)."""
-    require_cuda(p, g, m, v)
+def adamw_step(p, g, m, v, *, lr, beta1, beta2, eps, weight_decay, step, grad_scale=1.0, clip_coef=None):
+    """In-place AdamW on flat fp32 tensors (torch.optim.AdamW semantics).  ``clip_coef``: fp32 device scalar multiplied
+    into every gradient (``grad_norm_clip``)."""
+    require_cuda(p, g, m, v, clip_coef)
     bc1 = 1.0 - beta1 ** step
     bc2 = 1.0 - beta2 ** step
     check(lib().mv_adamw(_p(p), _p(g), _p(m), _p(v), p.numel(), lr, beta1, beta2, eps, weight_decay, bc1, bc2,
-                         grad_scale, _s()), "adamw", n=p.numel())
+                         grad_scale, _p(clip_coef), _s()), "adamw", n=p.numel())
+
+
+def grad_norm_clip(g, max_norm, grad_scale=1.0):
+    """-> fp32 [2] on the device: (total_norm of g * grad_scale, min(1, max_norm / (total_norm + 1e-6))) -- the two numbers
+    of torch.nn.utils.clip_grad_norm_ (classification/train.py:265-270); no host synchronisation."""
+    require_cuda(g)
+    out = torch.empty(2, dtype=torch.float32, device=g.device)
+    ws = workspace(lib().mv_grad_norm_workspace_bytes(), g.device)
+    check(lib().mv_grad_norm_clip(_p(g), g.numel(), float(grad_scale), float(max_norm), _p(out), _p(ws), ws.numel(), _s()),
+          "grad_norm_clip", n=g.numel())
+    return out
+
+
+def dropout(x, p, seed, offset, out=None):
+    """x * keep / (1 - p) with the Philox mask of (seed, offset); fp32 or bf16, any shape (contiguous)."""
+    require_cuda(x)
+    x = x.contiguous()
+    y = torch.empty_like(x) if out is None else out
+    check(lib().mv_dropout(_p(x), _p(y), _DT[x.dtype], x.numel(), float(p), int(seed), int(offset), _s()), "dropout",
+          n=x.numel(), p=p)
+    return y

@@ -66,12 +66,12 @@ class GELU(nn.GELU, _HipModule):
 
 
 class Dropout(nn.Dropout):
-    """Every shipped config uses p = 0 (train_configs/*.json); p > 0 in training mode is not implemented."""
+    """nn.Dropout on the HIP Philox kernel (reference vit.py:50,52,75,311).  Every shipped config uses p = 0, where this is
+    the identity and the enclosing block stays on its fused path; with p > 0 in training mode the block runs module by
+    module (``fusable()`` is False) and the mask is regenerated in backward from its (seed, offset) pair."""
 
     def forward(self, x):
-        if self.p == 0.0 or not self.training:
-            return x
-        raise NotImplementedError("dropout with p > 0 is not implemented on the HIP path (reference configs use 0.0)")
+        return F.dropout(x, self.p, self.training)
 
 
 def _plain(module, cls):
@@ -429,6 +429,7 @@ class ViT(nn.Module):
 
     def _backbone(self, img: torch.Tensor):
         ops.require_cuda(img, self.pos_embedding)
+        F.chain_reset()                       # no stale producer link from an earlier pass or a stand-alone block call
         b_dim, c_dim, h_dim, w_dim = img.shape
         p = self.patch_size
         gh, gw = h_dim // p, w_dim // p
@@ -502,11 +503,15 @@ class SegmentationDecoder(nn.Module):
 
     def forward(self, x: torch.Tensor):
         g = self.image_size_in_patches
-        if not (_plain(self.norm, LayerNorm) and _plain(self.linear, Linear)):
-            raise NotImplementedError("fake-quantised segmentation decoder is not implemented on the HIP path")
         if x.shape[1] - 1 != g * g:
             raise ValueError(f"expected {g * g} patch tokens for image_size {self.image_size}, got {x.shape[1] - 1}")
         ops.require_cuda(x)
+        if not (_plain(self.norm, LayerNorm) and _plain(self.linear, Linear)) or not isinstance(self.image_size, int):
+            # module by module (reference vit.py:359-374): prepare_qat wrapped norm / linear as Sequential(QuantStub, module)
+            # (utils/quantize.py:253-327), or something hooks into them
+            y = self.linear(self.norm(x[:, 1:]))
+            size = self.image_size if isinstance(self.image_size, int) else self.image_size[0]
+            return F.upsample_bilinear(F.cast(y, torch.float32), g, size)
         return F.seg_head(x.float(), self.norm.weight, self.norm.bias, self.linear.weight, self.linear.bias, g,
                           self.image_size, self.norm.precision)
 

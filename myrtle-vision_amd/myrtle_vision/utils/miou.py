@@ -2,12 +2,18 @@
 import torch
 
 
+def _hist(v, num_classes):
+    """torch.histc(v.float(), bins=C, min=0, max=C-1) of integer labels (reference miou.py:35-40): values outside
+    [0, C-1] are DROPPED, not clamped into the end bins."""
+    v = v[(v >= 0) & (v < num_classes)]
+    return torch.bincount(v, minlength=num_classes)[:num_classes].double()
+
+
 def intersect_and_union(pred_label, label, num_classes):
     pred_label, label = pred_label.reshape(-1).long(), label.reshape(-1).long()
-    inter = pred_label[pred_label == label]
-    area_intersect = torch.bincount(inter, minlength=num_classes)[:num_classes].double()
-    area_pred = torch.bincount(pred_label.clamp(0, num_classes - 1), minlength=num_classes)[:num_classes].double()
-    area_label = torch.bincount(label.clamp(0, num_classes - 1), minlength=num_classes)[:num_classes].double()
+    area_intersect = _hist(pred_label[pred_label == label], num_classes)
+    area_pred = _hist(pred_label, num_classes)
+    area_label = _hist(label, num_classes)
     return area_intersect, area_pred + area_label - area_intersect, area_pred, area_label
 
 

@@ -29,9 +29,15 @@ class ParamArena:
     """Flat fp32 storage for parameters and their gradients, split into (decay, no_decay) regions."""
 
     def __init__(self, named_params: Iterable[Tuple[str, torch.nn.Parameter]], skip=()):
-        named = [(n, p) for n, p in named_params if p.requires_grad and n not in set(skip)]
+        every = [(n, p) for n, p in named_params if p.requires_grad]
+        named = [(n, p) for n, p in every if n not in set(skip)]
         if not named:
             raise ValueError("no trainable parameters")
+        # parameter order of the torch.optim.AdamW the reference builds through timm (add_weight_decay: the no-decay group
+        # first, then the decayed one, each in named_parameters order, the never-used detection parameters included):
+        # the integer keys of the optimizer part of a reference checkpoint index into this list
+        nd = lambda n, p: p.ndim <= 1 or n.endswith(".bias")
+        self.torch_groups = [[n for n, p in every if nd(n, p)], [n for n, p in every if not nd(n, p)]]
         dev = named[0][1].device
         decay = [(n, p) for n, p in named if not (p.ndim <= 1 or n.endswith(".bias"))]
         no_decay = [(n, p) for n, p in named if (p.ndim <= 1 or n.endswith(".bias"))]
@@ -100,6 +106,8 @@ class AdamW:
         self.exp_avg_sq = torch.zeros_like(arena.flat_param)
         self.step_count = 0
         self.grad_scale = 1.0            # e.g. 1/world_size after a SUM all-reduce
+        self.max_grad_norm = None        # train_config.clip_grad: clip_grad_norm_ folded into the step (train.py:265-270)
+        self.last_grad_norm = None       # device tensor [total_norm, clip coefficient] of the last clipped step
 
     def zero_grad(self, set_to_none: bool = False):
         self.arena.zero_grad()
@@ -110,36 +118,78 @@ class AdamW:
         self.step_count += 1
         b1, b2 = self.defaults["betas"]
         a = self.arena
+        coef = None
+        if self.max_grad_norm is not None:
+            # torch.nn.utils.clip_grad_norm_ over every parameter that has a gradient = the whole arena (alignment gaps
+            # hold zeros): one norm reduction, and the coefficient rides into the AdamW kernel as a device scalar
+            self.last_grad_norm = ops.grad_norm_clip(a.flat_grad, self.max_grad_norm, self.grad_scale)
+            coef = self.last_grad_norm[1:2]
         for g in self.param_groups:
             lo, hi = g["range"]
             if hi > lo:
                 ops.adamw_step(a.flat_param[lo:hi], a.flat_grad[lo:hi], self.exp_avg[lo:hi], self.exp_avg_sq[lo:hi],
                                lr=g["lr"], beta1=b1, beta2=b2, eps=self.defaults["eps"],
-                               weight_decay=g["weight_decay"], step=self.step_count, grad_scale=self.grad_scale)
+                               weight_decay=g["weight_decay"], step=self.step_count, grad_scale=self.grad_scale,
+                               clip_coef=coef)
         a.bump_versions()
 
-    # checkpoint format: keyed by parameter NAME so it survives re-flattening
+    # checkpoint format = torch.optim.AdamW.state_dict() of the optimizer the reference builds (classification/train.py:
+    # 161-166, utils/models.py:113-126): ``state`` keyed by the parameter's index in timm's group order with a per-parameter
+    # ``step``, ``param_groups`` = [no_decay, decay] carrying those indices.  ``param_names`` (index -> name) is an extra
+    # key torch ignores.  Parameters that never received a gradient (the detection tokens) have no state, as in torch.
+    def _torch_index(self):
+        names = self.arena.torch_groups[0] + self.arena.torch_groups[1]
+        return {n: i for i, n in enumerate(names)}, names
+
     def state_dict(self):
         a = self.arena
+        index, names = self._torch_index()
         state = {}
-        for n, p, o in zip(a.names, a.params, a.offsets):
-            k = p.numel()
-            state[n] = {"exp_avg": self.exp_avg[o:o + k].view(p.shape).clone(),
-                        "exp_avg_sq": self.exp_avg_sq[o:o + k].view(p.shape).clone()}
-        return {"state": state, "step": self.step_count,
-                "param_groups": [{k: v for k, v in g.items() if k != "range"} for g in self.param_groups],
-                "defaults": self.defaults}
+        if self.step_count > 0:
+            for n, p, o in zip(a.names, a.params, a.offsets):
+                k = p.numel()
+                state[index[n]] = {"step": self.step_count,
+                                   "exp_avg": self.exp_avg[o:o + k].view(p.shape).clone(),
+                                   "exp_avg_sq": self.exp_avg_sq[o:o + k].view(p.shape).clone()}
+        by_name = {g["name"]: g for g in self.param_groups}
+        groups, first = [], 0
+        for gname, members in zip(("no_decay", "decay"), a.torch_groups):
+            g = by_name[gname]
+            groups.append({"lr": g["lr"], "betas": self.defaults["betas"], "eps": self.defaults["eps"],
+                           "weight_decay": g["weight_decay"], "amsgrad": False, "maximize": False,
+                           "initial_lr": g["initial_lr"], "params": list(range(first, first + len(members)))})
+            first += len(members)
+        return {"state": state, "param_groups": groups, "param_names": names}
 
     def load_state_dict(self, sd):
         a = self.arena
+        index, names = self._torch_index()
+        st = sd["state"]
+        if "param_names" in sd and list(sd["param_names"]) != names:
+            raise ValueError("optimizer checkpoint was written for a different parameter list")
+        legacy = any(isinstance(k, str) for k in st)            # round-1 layout: keyed by name, one top-level step
+        steps = set()
         for n, p, o in zip(a.names, a.params, a.offsets):
-            if n in sd["state"]:
-                k = p.numel()
-                self.exp_avg[o:o + k].copy_(sd["state"][n]["exp_avg"].reshape(-1))
-                self.exp_avg_sq[o:o + k].copy_(sd["state"][n]["exp_avg_sq"].reshape(-1))
-        self.step_count = sd["step"]
-        for g, s in zip(self.param_groups, sd["param_groups"]):
-            g.update({k: v for k, v in s.items() if k in ("lr", "initial_lr", "weight_decay")})
+            ent = st.get(n) if legacy else st.get(index[n])
+            if ent is None:
+                continue
+            k = p.numel()
+            if tuple(ent["exp_avg"].shape) != tuple(p.shape):
+                raise ValueError(f"optimizer state of {n}: shape {tuple(ent['exp_avg'].shape)} != {tuple(p.shape)}")
+            self.exp_avg[o:o + k].copy_(ent["exp_avg"].reshape(-1))
+            self.exp_avg_sq[o:o + k].copy_(ent["exp_avg_sq"].reshape(-1))
+            if "step" in ent:
+                steps.add(int(ent["step"]))
+        if legacy:
+            self.step_count = int(sd["step"])
+        else:
+            if len(steps) > 1:
+                raise ValueError(f"per-parameter steps differ ({sorted(steps)}): one fused step counter cannot hold them")
+            self.step_count = steps.pop() if steps else 0
+        by_name = {g["name"]: g for g in self.param_groups}
+        order = ("decay", "no_decay") if legacy else ("no_decay", "decay")
+        for gname, s in zip(order, sd["param_groups"]):
+            by_name[gname].update({k: v for k, v in s.items() if k in ("lr", "initial_lr", "weight_decay")})
 
 
 class CosineLRScheduler:

@@ -400,10 +400,13 @@ class ModelQuantizer:
         reassign = {}
         for name, module in list(self.model.named_modules()):
             if isinstance(module, nn.Linear):
+                # observers live where the layer lives: prepare_qat may be called AFTER model.to("cuda")
+                # (classification/test_quantize.py:100-103), and the min/max kernel updates their state in device memory
+                dev = module.weight.device
                 module.__class__ = QATLinear
                 module.weight_fake_quant = None
-                module.weight_observer = MinMaxObserver(symmetric=True, qmin=-128, qmax=127)
-                reassign[name] = nn.Sequential(QuantStub(MinMaxObserver(symmetric=False, qmin=0, qmax=255)), module)
+                module.weight_observer = MinMaxObserver(symmetric=True, qmin=-128, qmax=127).to(dev)
+                reassign[name] = nn.Sequential(QuantStub(MinMaxObserver(symmetric=False, qmin=0, qmax=255).to(dev)), module)
         self._reassign_attrs(reassign)
 
     def convert(self):

@@ -97,29 +97,36 @@ Quant = Optional[Callable[[str, torch.Tensor], torch.Tensor]]
 
 
 def vit_forward(params: Dict[str, torch.Tensor], img: torch.Tensor, cfg: ViTConfig,
-                quant: Quant = None, taps: Optional[dict] = None) -> torch.Tensor:
+                quant: Quant = None, taps: Optional[dict] = None, quant_outputs: bool = False) -> torch.Tensor:
     """``ViT.forward`` (``vit.py:267-320``) for the classification and segmentation
     decoders.  ``quant(site, tensor)`` is the fake-quant hook (identity when None);
     sites follow ``ModelQuantizer._prepare_qat_fp16_32/_tf32``
     (``utils/quantize.py:289-327``): the input of every Linear / LayerNorm
-    ("act:<module>") and every Linear weight ("w:<module>").  ``taps`` (optional
-    dict) receives intermediate activations.
+    ("act:<module>") and every Linear weight ("w:<module>").  ``quant_outputs``
+    adds the sites of ``_prepare_qat_fp16_16`` (``utils/quantize.py:253-287``): the
+    output of every Linear / LayerNorm ("out:<module>"), the input of every GELU
+    ("act:gelu": nn.GELU gets a QuantStub in front but, not being in torch's
+    observed-module list, no output observer) and every FloatFunctional result
+    ("ff:<name>": cls_token_cat, pos_embedding_cat, pos_embedding_add, res_add).
+    ``taps`` (optional dict) receives intermediate activations.
     """
     q = quant if quant is not None else (lambda site, t: t)
+    qo = q if quant_outputs else (lambda site, t: t)
     P = params
     p = cfg.patch_size
     b, _, h, w = img.shape
 
     def linear(name, x):
-        return F.linear(q(f"act:{name}", x), q(f"w:{name}", P[f"{name}.weight"]), P[f"{name}.bias"])
+        y = F.linear(q(f"act:{name}", x), q(f"w:{name}", P[f"{name}.weight"]), P[f"{name}.bias"])
+        return qo(f"out:{name}", y)
 
     def norm(name, x):
-        return layer_norm(q(f"act:{name}", x), P[f"{name}.weight"], P[f"{name}.bias"])
+        return qo(f"out:{name}", layer_norm(q(f"act:{name}", x), P[f"{name}.weight"], P[f"{name}.bias"]))
 
     x = linear("patch_to_embedding", patchify(img, p))              # :271-278
-    x = torch.cat((P["cls_token"].expand(b, -1, -1), x), dim=1)     # :283-290 (det branch dead, SURVEY 9.3)
-    pos = resized_pos_embedding(P["pos_embedding"], h // p, w // p)  # :292-302
-    x = x + pos                                                     # :305-310; dropout p=0 :311
+    x = qo("ff:cls_token_cat", torch.cat((P["cls_token"].expand(b, -1, -1), x), dim=1))  # :283-290 (det branch dead, SURVEY 9.3)
+    pos = qo("ff:pos_embedding_cat", resized_pos_embedding(P["pos_embedding"], h // p, w // p))  # :292-302
+    x = qo("ff:pos_embedding_add", x + pos)                         # :305-310; dropout p=0 :311
     if taps is not None:
         taps["embed"] = x
 
@@ -138,11 +145,11 @@ def vit_forward(params: Dict[str, torch.Tensor], img: torch.Tensor, cfg: ViTConf
         if taps is not None:
             taps[f"attn{i}"] = attn
         o = (attn @ vh).transpose(1, 2).reshape(b, n, c)             # :96
-        x = linear(f"{pre}.0.fn.fn.to_out.0", o) + x                 # :98, Residual :27
+        x = qo("ff:res_add", linear(f"{pre}.0.fn.fn.to_out.0", o) + x)   # :98, Residual :27
         # Residual(PreNorm(FeedForward)) :142-151, FeedForward :47-53
         y = norm(f"{pre}.1.fn.norm", x)
-        hdn = gelu_erf(linear(f"{pre}.1.fn.fn.net.0", y))
-        x = linear(f"{pre}.1.fn.fn.net.3", hdn) + x
+        hdn = gelu_erf(qo("act:gelu", linear(f"{pre}.1.fn.fn.net.0", y)))
+        x = qo("ff:res_add", linear(f"{pre}.1.fn.fn.net.3", hdn) + x)
         if taps is not None:
             taps[f"block{i}"] = x
 
@@ -157,12 +164,12 @@ def vit_forward(params: Dict[str, torch.Tensor], img: torch.Tensor, cfg: ViTConf
     return out
 
 
-def loss_and_grads(params, img, labels, cfg, quant: Quant = None):
+def loss_and_grads(params, img, labels, cfg, quant: Quant = None, quant_outputs: bool = False):
     """One training micro-step as the reference's loop does it
     (``classification/train.py:245-259``, ``segmentation/train.py:260-270``):
     forward, mean cross-entropy, backward.  Returns (logits, loss, grads)."""
     leaves = {k: v.detach().clone().requires_grad_(True) for k, v in params.items()}
-    logits = vit_forward(leaves, img, cfg, quant)
+    logits = vit_forward(leaves, img, cfg, quant, quant_outputs=quant_outputs)
     loss = F.cross_entropy(logits, labels)
     loss.backward()
     grads = {k: (v.grad if v.grad is not None else None) for k, v in leaves.items()}

@@ -92,6 +92,11 @@ CASES = {
     "micro_cls_tf32": (dict(decoder="classification", image_size=224, num_classes=45, **MICRO), 2, "TF32", False),
     "micro_cls_fp16_16": (dict(decoder="classification", image_size=224, num_classes=45, **MICRO), 2, "FP16_16", False),
     "micro_cls_fp16_32_conv": (dict(decoder="classification", image_size=224, num_classes=45, **MICRO), 2, "FP16_32", True),
+    # round 2: N = 257 tokens + bicubic pos-emb resize + segmentation tail in ONE model; a ViT-B-size segmentation model;
+    # the fake-quantised segmentation decoder (prepare_qat wraps decoder.norm / decoder.linear too, quantize.py:289-327)
+    "micro_seg_256": (dict(decoder="segmentation", image_size=256, num_classes=17, **MICRO), 1, None, False),
+    "base_seg": (dict(decoder="segmentation", image_size=224, num_classes=17, **BASE), 2, None, False),
+    "micro_seg_fp16_32": (dict(decoder="segmentation", image_size=224, num_classes=17, **MICRO), 2, "FP16_32", False),
 }
 
 
@@ -115,6 +120,9 @@ def run_case(name, kwargs, batch, q_format, convert):
     out = {}
     meta = {"kwargs": kwargs, "batch": batch, "q_format": q_format, "convert": convert,
             "param_shapes": {k: list(s) for k, s in shapes.items()},
+            # ORDER of the reference's state dict (a JSON object written with sort_keys loses it; a list does not)
+            "state_keys": list(shapes.keys()),
+            "state_keys_prepared": list(vit.state_dict().keys()),
             "torch": torch.__version__}
 
     img = det_images(name, batch, kwargs["image_size"])

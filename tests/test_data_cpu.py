@@ -53,3 +53,15 @@ def test_miou_matches_definition():
         m.add_img(pred[i], gt[i])
     want = np.mean([((pred == c) & (gt == c)).sum().item() / (((pred == c) | (gt == c)).sum().item()) for c in range(5)])
     assert abs(m.get_miou() - want) < 1e-12
+
+
+def test_miou_drops_out_of_range_like_histc():
+    """reference utils/miou.py:35-40: torch.histc(min=0, max=C-1) ignores unlabeled (-1) and out-of-range pixels"""
+    from myrtle_vision.utils.miou import intersect_and_union
+    g = torch.Generator().manual_seed(1)
+    pred, gt = torch.randint(0, 5, (64, 64), generator=g), torch.randint(-1, 7, (64, 64), generator=g)
+    got = intersect_and_union(pred, gt, 5)
+    inter = pred[pred == gt]
+    want = [torch.histc(t.float(), bins=5, min=0, max=4).double() for t in (inter, pred, gt)]
+    assert torch.equal(got[0], want[0]) and torch.equal(got[2], want[1]) and torch.equal(got[3], want[2])
+    assert torch.equal(got[1], want[1] + want[2] - want[0])

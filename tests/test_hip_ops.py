@@ -486,6 +486,64 @@ def test_cross_entropy_seg(ops):
     assert torch.equal(am.cpu(), logits.argmax(1))
 
 
+def test_cross_entropy_ignore_index_and_bad_labels(ops):
+    """nn.CrossEntropyLoss() label semantics (classification/train.py:170; DLRSD's PNG-1 can yield -1):
+    -100 is skipped and left out of the mean; any other out-of-range label is never dereferenced and poisons the loss."""
+    B, C = 16, 45
+    logits = torch.randn(B, C, generator=g(1)) * 3
+    labels = torch.randint(0, C, (B,), generator=g(2))
+    labels[3] = -100
+    labels[11] = -100
+    ref = logits.double().requires_grad_(True)
+    l = torch.nn.functional.cross_entropy(ref, labels)                      # ignore_index = -100, mean over 14
+    l.backward()
+    loss, dl, _ = ops.cross_entropy(logits.cuda(), labels.cuda(), want_grad=True)
+    assert abs(float(loss) - float(l)) < 1e-5 * max(1, abs(float(l)))
+    assert relerr(dl, ref.grad) < 1e-5 and float(dl[3].abs().max()) == 0.0 and float(dl[11].abs().max()) == 0.0
+    # segmentation layout
+    S = 24
+    lg = torch.randn(2, 17, S, S, generator=g(3))
+    lb = torch.randint(0, 17, (2, S, S), generator=g(4))
+    lb[0, :5] = -100
+    ref = lg.double().requires_grad_(True)
+    l = torch.nn.functional.cross_entropy(ref, lb)
+    l.backward()
+    loss, dl, _ = ops.cross_entropy(lg.cuda(), lb.cuda(), want_grad=True)
+    assert abs(float(loss) - float(l)) < 1e-5 * abs(float(l)) and relerr(dl, ref.grad) < 1e-5
+    # out-of-range (not the ignore index): loud NaN loss, zero gradient row, no fault
+    for bad in (-1, C, 10 ** 9):
+        lab = labels.clone()
+        lab[5] = bad
+        loss, dl, _ = ops.cross_entropy(logits.cuda(), lab.cuda(), want_grad=True)
+        assert torch.isnan(loss).all() and float(dl[5].abs().max()) == 0.0 and torch.isfinite(dl).all()
+    # every label ignored: nan, as torch
+    loss, _, _ = ops.cross_entropy(logits.cuda(), torch.full((B,), -100).cuda(), want_grad=True)
+    assert torch.isnan(loss).all()
+
+
+def test_seg_ce_fused_tail_ignore_index(ops):
+    B, C, g_in, size = 2, 17, 14, 224
+    small = torch.randn(B, g_in * g_in, C, generator=g(1)) * 2
+    labels = torch.randint(0, C, (B, size, size), generator=g(2))
+    labels[0, 10:40, :] = -100
+    labels[1, :, 100:120] = -100
+    ref = small.double().transpose(1, 2).reshape(B, C, g_in, g_in).requires_grad_(True)
+    big = torch.nn.functional.interpolate(ref, size=(size, size), mode="bilinear", align_corners=False)
+    l = torch.nn.functional.cross_entropy(big, labels)
+    l.backward()
+    want_grad = ref.grad.reshape(B, C, -1).transpose(1, 2).reshape(B * g_in * g_in, C)
+    sm = small.cuda().view(B * g_in * g_in, C)
+    stats, lse, pred, lab = ops.seg_ce_fwd(sm, labels.cuda(), B, C, g_in, g_in, size, size)
+    assert abs(float(stats[0]) - float(l)) < 2e-6 * max(1.0, abs(float(l)))
+    assert float(stats[2]) == float((labels != -100).sum()) and float(stats[3]) == 0.0
+    assert abs(float(stats[1]) - float((big.argmax(1) == labels).double().mean())) < 1e-4      # accuracy over ALL pixels
+    ds = ops.seg_ce_bwd(sm, lab, lse, B, C, g_in, g_in, size, size, stats=stats)
+    assert relerr(ds, want_grad) < 1e-5
+    labels[0, 0, 0] = -1                                                    # DLRSD pixel value 0 -> label -1: loud, not a fault
+    stats, lse, pred, lab = ops.seg_ce_fwd(sm, labels.cuda(), B, C, g_in, g_in, size, size)
+    assert torch.isnan(stats[0]) and float(stats[3]) == 1.0
+
+
 @pytest.mark.parametrize("g_in,size", [(14, 224), (16, 256), (7, 20)])
 def test_upsample_bilinear(ops, g_in, size):
     B, C = 2, 17

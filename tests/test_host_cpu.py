@@ -39,6 +39,8 @@ def _parse_header():
                     kinds += "f"
                 elif a.startswith("int"):
                     kinds += "i"
+                elif a.startswith("uint64_t"):
+                    kinds += "Q"
                 else:
                     raise AssertionError(f"unparsed argument {a!r} in {name}")
         decls[name] = (kinds, ret)
@@ -76,16 +78,26 @@ def test_cpu_forward_fails_loudly():
 
 
 # ---------------------------------------------------------------- model class / state dict
-@pytest.mark.parametrize("name", ["micro_cls", "micro_seg", "base_cls"])
+@pytest.mark.parametrize("name", ["micro_cls", "micro_seg", "micro_seg_256", "base_cls", "base_seg"])
 def test_state_dict_matches_reference(name):
     from myrtle_vision.models.vit import ViT
-    from oracle.vit_oracle import ViTConfig
     _, meta = load_golden(name)
     vit = ViT(patch_size=16, q_format="FP32", **meta["kwargs"])
     sd = vit.state_dict()
     assert {k: list(v.shape) for k, v in sd.items()} == meta["param_shapes"]
-    assert list(sd.keys()) == list(ViTConfig(patch_size=16, **meta["kwargs"]).param_shapes().keys())
+    assert list(sd.keys()) == meta["state_keys"]              # the reference's own key ORDER (recorded as a list)
     assert set(vit.unused_parameter_names()) == set(meta["unused_params"])
+
+
+@pytest.mark.parametrize("name,fmt", [("micro_cls_fp16_32", "FP16_32"), ("micro_cls_tf32", "TF32"),
+                                      ("micro_cls_fp16_16", "FP16_16"), ("micro_seg_fp16_32", "FP16_32")])
+def test_prepared_state_dict_keys_match_reference(name, fmt):
+    """prepare_qat wraps modules as Sequential(QuantStub, module): keys gain the same '.1.' as the reference's, in the
+    same order (why the reference has --quantized_ckpt)."""
+    from myrtle_vision.models.vit import ViT
+    _, meta = load_golden(name)
+    vit = ViT(patch_size=16, q_format=fmt, **meta["kwargs"])
+    assert list(vit.state_dict().keys()) == meta["state_keys_prepared"]
 
 
 def test_constructor_asserts_like_reference():
@@ -205,6 +217,48 @@ def test_checkpoint_wire_format_roundtrip(tmp_path):
     vit2.load_state_dict({k: v.clone() for k, v in ckpt["model"].items()})
 
 
+def test_optimizer_state_interchanges_with_torch_adamw():
+    """The optimizer part of a checkpoint is torch.optim.AdamW.state_dict() of the optimizer the reference builds through
+    timm (no-decay group first, detection parameters included but stateless): both directions round-trip."""
+    from myrtle_vision.models.vit import ViT
+    from myrtle_vision.utils.optim import AdamW, ParamArena
+    from oracle.optim_oracle import reference_adamw
+    kw = dict(decoder="classification", image_size=224, patch_size=16, num_classes=5, dim=64, depth=1, heads=1, mlp_dim=64)
+    torch.manual_seed(0)
+    ref_model = ViT(**kw)
+    ref_opt = reference_adamw(list(ref_model.named_parameters()), lr=1e-3, weight_decay=0.05)
+    unused = set(ref_model.unused_parameter_names())
+    for _ in range(2):
+        for n, p in ref_model.named_parameters():
+            p.grad = None if n in unused else torch.randn_like(p)
+        ref_opt.step()
+    sd = ref_opt.state_dict()                                  # what the reference's save_checkpoint stores
+    names = [n for g in sd["param_groups"] for n in [None] * len(g["params"])]
+    vit = ViT(**kw)
+    opt = AdamW(ParamArena(vit.named_parameters(), skip=vit.unused_parameter_names()), lr=1e-3, weight_decay=0.05)
+    opt.load_state_dict(sd)
+    assert opt.step_count == 2
+    index, order = opt._torch_index()
+    assert len(order) == len(names) and set(order) == {n for n, _ in ref_model.named_parameters()}
+    ref_params = dict(ref_model.named_parameters())
+    ref_index = {id(p): i for i, p in enumerate(q for g in ref_opt.param_groups for q in g["params"])}
+    for n, p, o in zip(opt.arena.names, opt.arena.params, opt.arena.offsets):
+        i = ref_index[id(ref_params[n])]
+        assert i == index[n], n                                # same integer key as torch assigns
+        assert torch.equal(opt.exp_avg[o:o + p.numel()].view(p.shape), sd["state"][i]["exp_avg"]), n
+        assert torch.equal(opt.exp_avg_sq[o:o + p.numel()].view(p.shape), sd["state"][i]["exp_avg_sq"]), n
+    # and back: torch loads what we write
+    ours = opt.state_dict()
+    assert [g["params"] for g in ours["param_groups"]] == [g["params"] for g in sd["param_groups"]]
+    assert [g["weight_decay"] for g in ours["param_groups"]] == [0.0, 0.05]
+    assert set(ours["state"]) == set(sd["state"])              # the unused detection parameters carry no state
+    fresh = reference_adamw(list(ViT(**kw).named_parameters()), lr=1e-3, weight_decay=0.05)
+    fresh.load_state_dict({"state": ours["state"], "param_groups": ours["param_groups"]})
+    back = fresh.state_dict()["state"]
+    for i, ent in sd["state"].items():
+        assert torch.equal(back[i]["exp_avg"], ent["exp_avg"]) and float(back[i]["step"]) == float(ent["step"]) == 2.0
+
+
 def test_rename_timm_state_dict_rules():
     from myrtle_vision.utils.models import apply_rules, rename_timm_state_dict
     D, depth = 32, 2
@@ -302,3 +356,24 @@ def test_quantised_formats_force_fp32_on_every_leaf(q_format):
     v.convert()
     precs = {n: m.precision for n, m in v.named_modules() if hasattr(m, "precision")}
     assert set(precs.values()) == {"fp32"}, precs
+
+
+def test_bench_self_launches_two_ranks_and_prints_one_json_line():
+    """``python bench.py --gpus 2`` started plainly spawns its own ranks (the reference scripts mp.spawn themselves,
+    classification/train.py:349-356) and rank 0 prints ONE JSON line.  --dry-run: plumbing only, gloo, no GPU needed."""
+    import json
+    import subprocess
+    import sys
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT", "MASTER_ADDR")}
+    env["MV_DIST_BACKEND"] = "gloo"
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1",
+                        "--dry-run"], env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["steps"] == 3 and out["value"] is None and "dry-run" in out["data"]
+    # a failing rank fails the command: an unknown workload is rejected by every child
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--workload", "nope", "--dry-run"],
+                       env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode != 0

@@ -56,3 +56,18 @@ def test_affine_matches_torch_fake_quantize():
     s, z = obs.calculate_qparams()
     s2, z2 = q.affine_qparams(x.min().item(), x.max().item(), -128, 127, symmetric=True)
     assert abs(float(s) - float(s2)) < 1e-9 and int(z) == z2 == 0
+
+
+def test_philox_oracle_known_answers():
+    """Philox4x32-10 known-answer vectors published with Random123 (kat_vectors): pins oracle/dropout_oracle.py, which in
+    turn pins the dropout mask of the HIP kernel (tests/test_train_gpu.py)."""
+    from oracle.dropout_oracle import dropout_keep_mask, philox4x32_10
+    kats = [((0, 0, 0, 0), (0, 0), (0x6627e8d5, 0xe169c58d, 0xbc57ac4c, 0x9b00dbd8)),
+            ((0xffffffff,) * 4, (0xffffffff, 0xffffffff), (0x408f276d, 0x41c83b0e, 0xa20bc7c6, 0x6d5451fd)),
+            ((0x243f6a88, 0x85a308d3, 0x13198a2e, 0x03707344), (0xa4093822, 0x299f31d0),
+             (0xd16cfe09, 0x94fdcceb, 0x5001e420, 0x24126ea1))]
+    for ctr, key, want in kats:
+        got = philox4x32_10(*[[c] for c in ctr], *key)
+        assert tuple(int(g[0]) for g in got) == want
+    m = dropout_keep_mask(100000, 0.25, 42, 7)
+    assert abs(m.mean() - 0.75) < 6e-3 and m.shape == (100000,)

@@ -170,3 +170,159 @@ def test_ddp_two_ranks_match_single_process(tmp_path):
     assert float((want - got).norm() / want.norm()) < 2e-2
     f0, f1 = torch.load(tmp_path / "final0.pt"), torch.load(tmp_path / "final1.pt")
     assert torch.equal(f0, f1)
+
+
+def test_int8_quantized_evaluation_path(tmp_path):
+    """classification/test_quantize.py with q_format PyTorchINT8 (BASELINE config 5's entry point): the model is moved to
+    the GPU FIRST and prepared afterwards, so the observers must be created on the device (the min/max kernel updates
+    their state with device atomics)."""
+    from myrtle_vision.engine import evaluate, train_worker
+    cfg = _config(tmp_path, "classification")
+    train_worker(0, 1, copy.deepcopy(cfg), "classification")
+    cfg["train_config"]["checkpoint_path"] = os.path.join(cfg["train_config"]["output_directory"], "vit_000002")
+    fp32 = evaluate(copy.deepcopy(cfg), "classification")
+    cfg["vit_config"]["q_format"] = "PyTorchINT8"
+    q = evaluate(copy.deepcopy(cfg), "classification", quantize=True, calib_steps=1)
+    assert abs(q["accuracy"] - fp32["accuracy"]) <= 0.25
+
+
+def test_minmax_observer_rejects_host_state():
+    from myrtle_vision.hip import ops
+    with pytest.raises(RuntimeError):
+        ops.minmax_update(torch.randn(100).cuda(), torch.tensor([float("inf"), float("-inf"), 0.0, 0.0]))
+
+
+def test_clip_grad_matches_torch_clip_grad_norm(tmp_path):
+    """train_config.clip_grad (classification/train.py:265-270): arena norm + coefficient folded into the AdamW kernel ==
+    torch.nn.utils.clip_grad_norm_ followed by torch.optim.AdamW.step, for a clipping and a non-clipping threshold."""
+    from myrtle_vision.hip.functional import cross_entropy
+    from myrtle_vision.models.vit import ViT
+    from myrtle_vision.utils.optim import AdamW, ParamArena
+    from myrtle_vision.utils.utils import seed_everything
+    from oracle.optim_oracle import reference_adamw
+    kw = dict(decoder="classification", image_size=224, patch_size=16, num_classes=7, dim=128, depth=2, heads=2, mlp_dim=256)
+    g = torch.Generator().manual_seed(3)
+    img, labels = torch.randn(4, 3, 224, 224, generator=g).cuda(), torch.randint(0, 7, (4,), generator=g).cuda()
+    for max_norm in (0.05, 1e6):
+        seed_everything(5)
+        vit = ViT(precision="fp32", q_format="FP32", **kw).cuda()
+        opt = AdamW(ParamArena(vit.named_parameters(), skip=vit.unused_parameter_names()), lr=1e-3, weight_decay=0.05)
+        opt.max_grad_norm = max_norm
+        opt.zero_grad()
+        cross_entropy(vit(img), labels).backward()
+        used = [(n, p) for n, p in vit.named_parameters() if p.grad is not None]
+        # torch on copies of the same parameters and gradients
+        ref_params = [(n, torch.nn.Parameter(p.detach().clone())) for n, p in used]
+        for (_, rp), (_, p) in zip(ref_params, used):
+            rp.grad = p.grad.detach().clone()
+        ref_opt = reference_adamw(ref_params, lr=1e-3, weight_decay=0.05)
+        total = torch.nn.utils.clip_grad_norm_([rp for _, rp in ref_params], max_norm)
+        ref_opt.step()
+        opt.step()
+        got_norm, coef = (float(v) for v in opt.last_grad_norm.tolist())
+        assert abs(got_norm - float(total)) < 1e-5 * float(total)
+        assert abs(coef - min(1.0, max_norm / (float(total) + 1e-6))) < 1e-6
+        assert (coef < 1.0) == (max_norm < float(total))
+        for (n, rp), (_, p) in zip(ref_params, used):
+            assert torch.allclose(p.detach(), rp.detach(), rtol=2e-6, atol=2e-7), n
+
+
+def test_dropout_statistics_determinism_and_backward():
+    """nn.Dropout on the Philox kernel (vit.py:50,52,75,311): keep rate, 1/(1-p) scaling, mask = f(seed, offset) (bit-exact
+    against the numpy restatement in oracle/), backward uses the same mask, eval / p = 0 are the identity."""
+    import numpy as np
+    from myrtle_vision.hip import functional as F
+    from myrtle_vision.hip import ops
+    from oracle.dropout_oracle import dropout_keep_mask
+    x = torch.randn(1001, 333).cuda()
+    for p in (0.1, 0.5):
+        y = ops.dropout(x, p, seed=1234567, offset=89)
+        keep = (y != 0)
+        assert abs(float(keep.float().mean()) - (1 - p)) < 4e-3                   # 333 k samples: 4 sigma ~ 3.5e-3 at p = 0.5
+        assert torch.allclose(y[keep], x[keep] / (1 - p), rtol=1e-6)
+        want = dropout_keep_mask(x.numel(), p, 1234567, 89).reshape(x.shape)
+        assert np.array_equal(keep.cpu().numpy(), want)
+        assert torch.equal(y, ops.dropout(x, p, seed=1234567, offset=89))          # deterministic
+        assert not torch.equal(y, ops.dropout(x, p, seed=1234567, offset=90))
+        yb = ops.dropout(x.bfloat16(), p, seed=1234567, offset=89)
+        assert torch.equal(yb != 0, keep)
+    torch.manual_seed(7)
+    xr = torch.randn(64, 128, device="cuda", requires_grad=True)
+    y = F.dropout(xr, 0.3, training=True)
+    y.backward(torch.ones_like(y))
+    assert torch.equal(xr.grad != 0, y != 0) and torch.allclose(xr.grad[xr.grad != 0], torch.tensor(1 / 0.7, device="cuda"))
+    assert F.dropout(xr, 0.3, training=False) is xr and F.dropout(xr, 0.0, training=True) is xr
+    torch.manual_seed(7)
+    assert torch.equal(F.dropout(xr.detach(), 0.3, True), y.detach())              # reproducible under the torch seed
+
+
+def test_vit_with_dropout_trains_and_eval_is_deterministic():
+    from myrtle_vision.hip.functional import cross_entropy
+    from myrtle_vision.models.vit import ViT
+    from myrtle_vision.utils.utils import seed_everything
+    kw = dict(decoder="classification", image_size=224, patch_size=16, num_classes=7, dim=128, depth=2, heads=2, mlp_dim=256)
+    g = torch.Generator().manual_seed(3)
+    img, labels = torch.randn(4, 3, 224, 224, generator=g).cuda(), torch.randint(0, 7, (4,), generator=g).cuda()
+    for precision in ("bf16", "fp32"):
+        seed_everything(5)
+        vit = ViT(precision=precision, q_format="FP32", dropout=0.1, emb_dropout=0.1, **kw).cuda()
+        base = ViT(precision=precision, q_format="FP32", dropout=0.0, emb_dropout=0.0, **kw).cuda()
+        base.load_state_dict(vit.state_dict())
+        vit.train()
+        seed_everything(9)
+        l1 = cross_entropy(vit(img), labels)
+        l1.backward()
+        assert torch.isfinite(l1) and all(torch.isfinite(p.grad).all() for p in vit.parameters() if p.grad is not None)
+        g1 = vit.transformer.layers[0][1].fn.fn.net[0].weight.grad.clone()
+        seed_everything(9)
+        vit.zero_grad()
+        l2 = cross_entropy(vit(img), labels)
+        l2.backward()
+        assert float(l1) == float(l2) and torch.equal(g1, vit.transformer.layers[0][1].fn.fn.net[0].weight.grad)   # same seed, same masks
+        seed_everything(10)
+        assert float(cross_entropy(vit(img), labels)) != float(l1)                                             # other seed, other masks
+        vit.eval()
+        base.eval()
+        with torch.no_grad():
+            assert torch.equal(vit(img), base(img))            # eval: dropout is the identity, the fused path runs
+
+
+def test_block_chain_is_by_identity_not_address():
+    """The forward-order link that routes a LayerNorm backward's column sums to the producing Linear's bias gradient is
+    keyed by tensor identity: a freed-and-reallocated buffer at the same address fed to an unrelated block inherits
+    nothing."""
+    from myrtle_vision.hip import functional as F
+    from myrtle_vision.models.vit import ViT
+    from myrtle_vision.utils.utils import seed_everything
+    seed_everything(1)
+    kw = dict(decoder="classification", image_size=224, patch_size=16, num_classes=7, dim=128, depth=2, heads=2, mlp_dim=256)
+    vit = ViT(precision="bf16", q_format="FP32", **kw).cuda()
+    blk_a, blk_b = vit.transformer.layers[0][1], vit.transformer.layers[1][1]
+    x1 = torch.randn(2, 197, 128, device="cuda")
+    out = blk_a(x1)                                               # records (out, fc2 bias of block a) as the chain link
+    addr = out.data_ptr()
+    del out
+    x2 = torch.empty(2, 197, 128, device="cuda").normal_()       # very likely the same address (caching allocator)
+    x2.requires_grad_(True)
+    y = blk_b(x2)
+    y.float().sum().backward()
+    assert blk_a.fn.fn.net[3].bias.grad is None, f"block a's bias inherited a gradient (x2 at {x2.data_ptr():#x}, old out at {addr:#x})"
+    assert blk_b.fn.fn.net[3].bias.grad is not None and x2.grad is not None
+    F.chain_reset()
+
+
+def test_bench_two_ranks_on_one_gpu_gloo():
+    """The N > 1 path of bench.py end to end with real compute: ``python bench.py --gpus 2`` self-launches two ranks (both on
+    GPU 0, gradients exchanged over gloo -- a rehearsal of the RCCL path's control flow) and rank 0 prints one JSON line with
+    the whole-job throughput."""
+    import subprocess
+    import sys
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT", "MASTER_ADDR")}
+    env["MV_DIST_BACKEND"] = "gloo"
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
+                        "--batch", "16", "--no-cpu-baseline"], env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["config"]["global_batch"] == 32 and out["value"] > 0 and out["scaling"] == "weak"

@@ -2,10 +2,13 @@
 
 precision="fp32": the north-star tolerance, 1e-3 relative to the tensor's max magnitude (measured: ~1e-5), and
 bit-exact argmax.  precision="bf16" (the benchmark configuration): bf16 activations/weights on MFMA cannot meet
-1e-3 end to end (each bf16 rounding is 2^-9 = 2e-3 relative); the test pins its measured envelope, 3e-2 of max
-|logit| and 6e-2 on gradient summaries, plus argmax equality wherever the reference's top-2 margin exceeds that
-envelope.
+1e-3 end to end (each bf16 rounding is 2^-9 = 2e-3 relative); the tests pin its measured envelope with little slack:
+1.5e-2 of max |logit| (measured <= 8.3e-3) and 2e-2 relative L2 per gradient tensor (measured <= 1.1e-2, ViT-B depth 12
+included), plus argmax equality wherever the reference's top-2 margin exceeds that envelope.
+
+MV_TEST_REPORT=<file>: every check appends the value it measured (the numbers quoted above come from that file).
 """
+import os
 import numpy as np
 import pytest
 import torch
@@ -15,7 +18,15 @@ pytestmark = pytest.mark.gpu
 from conftest import load_golden  # noqa: E402
 from oracle.detinit import det_images, det_labels, det_param, summarize  # noqa: E402
 
-CASES = ["micro_cls", "micro_cls_256", "micro_seg", "tiny_cls", "base_cls"]
+CASES = ["micro_cls", "micro_cls_256", "micro_seg", "micro_seg_256", "tiny_cls", "base_cls", "base_seg"]
+BF16_LOGITS, BF16_GRAD = 1.5e-2, 2e-2
+
+
+def report(tag, value):
+    path = os.environ.get("MV_TEST_REPORT")
+    if path:
+        with open(path, "a") as f:
+            f.write(f"{tag} {value:.3e}\n")
 
 
 def build(name, precision, q_format=None):
@@ -25,7 +36,7 @@ def build(name, precision, q_format=None):
     vit = ViT(patch_size=16, q_format="FP32", precision=precision, **kw)
     sd = vit.state_dict()
     assert {k: list(v.shape) for k, v in sd.items()} == meta["param_shapes"]
-    assert list(sd.keys()) == list(meta["param_shapes"].keys()) or True
+    assert list(sd.keys()) == meta["state_keys"]            # the reference's state-dict ORDER (checkpoint wire format)
     vit.load_state_dict({k: det_param(k, v.shape) for k, v in sd.items()})
     vit = vit.cuda()
     if q_format is not None:
@@ -60,8 +71,10 @@ def check_case(name, precision, tol_logits, tol_grad, q_format=None):
     loss.backward()
     torch.cuda.synchronize()
     lg = logits.detach().float().cpu()
+    tag = f"{name}/{precision}" + (f"/{q_format}" if q_format else "")
     if "logits" in arrays:
         want = arrays["logits"]
+        report(f"{tag} logits", rel(lg.numpy(), want))
         assert rel(lg.numpy(), want) < tol_logits
         top2 = np.sort(want, axis=1)[:, -2:]
         margin_ok = (top2[:, 1] - top2[:, 0]) > 2 * tol_logits * np.abs(want).max()
@@ -70,6 +83,7 @@ def check_case(name, precision, tol_logits, tol_grad, q_format=None):
             assert (lg.argmax(1).numpy() == want.argmax(1)).all()          # bit-exact class indices
     else:
         want = arrays["logits_sub"]
+        report(f"{tag} logits", rel(lg[:, :, ::7, ::7].numpy(), want))
         assert rel(lg[:, :, ::7, ::7].numpy(), want) < tol_logits
         if precision == "fp32":
             assert (lg.argmax(1)[:, ::7, ::7].numpy() == arrays["argmax_sub"]).all()
@@ -99,10 +113,11 @@ def check_case(name, precision, tol_logits, tol_grad, q_format=None):
         if f"grad:{c}" in arrays:
             assert rel(p.grad.float().cpu().numpy(), arrays[f"grad:{c}"]) < tol_grad, c
     assert sorted(unused) == sorted(meta["unused_params"])
+    report(f"{tag} grad-summaries", worst)
     return worst
 
 
-@pytest.mark.parametrize("precision,tol,tol_grad", [("fp32", 1e-3, 1e-3), ("bf16", 3e-2, 6e-2)])
+@pytest.mark.parametrize("precision,tol,tol_grad", [("fp32", 1e-3, 1e-3), ("bf16", BF16_LOGITS, 3e-2)])
 def test_fused_segmentation_tail_matches_reference(precision, tol, tol_grad):
     """``vit.segmentation_loss`` (decoder + bilinear upsample + CE + argmax without the [B,C,H,W] logits) against the
     reference's loss / arg-max / gradients for micro_seg, and against ``cross_entropy(vit(img))`` on the same model."""
@@ -156,13 +171,15 @@ def test_fp32_matches_reference(name):
 
 @pytest.mark.parametrize("name", CASES)
 def test_bf16_matches_reference_within_bf16_envelope(name):
-    check_case(name, "bf16", 3e-2, 6e-2)
+    # gradient SUMMARIES (norms + 16 sampled values against the tensor's abs-max) are a noisier statistic than the
+    # per-tensor relative L2 pinned at 2e-2 in test_bf16_vs_fp32_full_tensors: one sampled value sets them
+    check_case(name, "bf16", BF16_LOGITS, 3e-2)
 
 
 @pytest.mark.parametrize("name", CASES)
 def test_bf16_vs_fp32_full_tensors(name):
     """Full-tensor chain: reference -(1e-3, test above)-> fp32 HIP -(here)-> bf16 HIP.  Measured on MI355X:
-    logits rel-max <= 8.3e-3, every gradient tensor rel-L2 <= 1.1e-2 (ViT-B depth 12 included); bound 3e-2."""
+    logits rel-max <= 8.3e-3, every gradient tensor rel-L2 <= 1.1e-2 (ViT-B depth 12 included); bounds 1.5e-2 / 2e-2."""
     from myrtle_vision.hip.functional import cross_entropy
     res = {}
     for prec in ("fp32", "bf16"):
@@ -171,10 +188,16 @@ def test_bf16_vs_fp32_full_tensors(name):
         cross_entropy(logits, labels).backward()
         res[prec] = (logits.detach().float(), {k: p.grad.float() for k, p in vit.named_parameters() if p.grad is not None})
     l32, l16 = res["fp32"][0], res["bf16"][0]
-    assert float((l32 - l16).abs().max() / l32.abs().max()) < 3e-2
+    e = float((l32 - l16).abs().max() / l32.abs().max())
+    report(f"{name}/bf16-vs-fp32 logits", e)
+    assert e < BF16_LOGITS
+    worst = 0.0
     for k, g32 in res["fp32"][1].items():
         g16 = res["bf16"][1][k]
-        assert float((g32 - g16).norm() / g32.norm().clamp_min(1e-30)) < 3e-2, k
+        e = float((g32 - g16).norm() / g32.norm().clamp_min(1e-30))
+        worst = max(worst, e)
+        assert e < BF16_GRAD, (k, e)
+    report(f"{name}/bf16-vs-fp32 grad-rel-l2", worst)
 
 
 def test_block_taps_and_attention_hook_fp32():
@@ -200,7 +223,8 @@ def test_block_taps_and_attention_hook_fp32():
     assert rel(logits2.cpu().numpy(), arrays["logits"]) < 1e-3
 
 
-@pytest.mark.parametrize("name,fmt", [("micro_cls_fp16_32", "FP16_32"), ("micro_cls_tf32", "TF32")])
+@pytest.mark.parametrize("name,fmt", [("micro_cls_fp16_32", "FP16_32"), ("micro_cls_tf32", "TF32"),
+                                      ("micro_cls_fp16_16", "FP16_16"), ("micro_seg_fp16_32", "FP16_32")])
 def test_fake_quant_paths_match_reference_plumbing(name, fmt):
     # quantised paths are compared at 3e-3: rounding flips of the discontinuous quantiser (see tests/test_oracle_golden.py)
     check_case(name, "fp32", 3e-3, 2e-2, q_format=fmt)

@@ -1,0 +1,61 @@
+#!/usr/bin/env python3
+"""A/B of GEMM kernel variants INSIDE the ViT-B/16 training step, one process, one device: the variants take turns in
+blocks of STEPS steps for ROUNDS rounds (cdna guide rule 24); prints mean, std and min of ms/step per variant.
+
+    NT_VARIANTS=0,2569 ROUNDS=10 STEPS=10 python tools/ab_step.py
+"""
+import os
+import statistics
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "myrtle-vision_amd"))
+import torch  # noqa: E402
+
+from myrtle_vision.hip.functional import cross_entropy  # noqa: E402
+from myrtle_vision.hip.lib import lib  # noqa: E402
+from myrtle_vision.models.vit import ViT  # noqa: E402
+from myrtle_vision.utils.optim import AdamW, ParamArena  # noqa: E402
+from myrtle_vision.utils.utils import seed_everything  # noqa: E402
+
+VARIANTS = [int(v) for v in os.environ.get("NT_VARIANTS", "0,2569").split(",")]
+ROUNDS, STEPS, BATCH = int(os.environ.get("ROUNDS", 10)), int(os.environ.get("STEPS", 10)), int(os.environ.get("BATCH", 256))
+dev = torch.device("cuda", 0)
+seed_everything(1234)
+vit = ViT(decoder="classification", image_size=224, patch_size=16, num_classes=1000, dim=768, depth=12, heads=12,
+          mlp_dim=3072, precision="bf16", q_format="FP32").to(dev)
+arena = ParamArena(vit.named_parameters(), skip=vit.unused_parameter_names())
+opt = AdamW(arena, lr=6.25e-5, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.05)
+g = torch.Generator().manual_seed(1234)
+img = torch.randn(BATCH, 3, 224, 224, generator=g).to(dev)
+labels = torch.randint(0, 1000, (BATCH,), generator=g).to(dev)
+vit.train()
+
+
+def step():
+    opt.zero_grad()
+    loss = cross_entropy(vit(img), labels)
+    loss.backward()
+    opt.step()
+
+
+for _ in range(5):
+    step()
+times = {v: [] for v in VARIANTS}
+for r in range(ROUNDS):
+    for v in VARIANTS:
+        lib().mv_gemm_force_variant(v, 0)
+        step()                                    # one untimed step after the switch
+        s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        torch.cuda.synchronize()
+        s.record()
+        for _ in range(STEPS):
+            step()
+        e.record()
+        torch.cuda.synchronize()
+        times[v].append(s.elapsed_time(e) / STEPS)
+lib().mv_gemm_force_variant(0, 0)
+for v in VARIANTS:
+    t = times[v]
+    print(f"variant {v:6d}: mean {statistics.mean(t):7.3f} ms/step  std {statistics.pstdev(t):6.3f}  min {min(t):7.3f}  "
+          f"({BATCH / statistics.mean(t) * 1e3:7.0f} img/s)  blocks {len(t)} x {STEPS} steps")
