@@ -10,8 +10,8 @@
  *   - return 0 on success, a negative MV_ERR_* otherwise; never throw, never synchronise,
  *     never allocate (callers pass workspaces); work is enqueued on `stream`
  *   - re-entrant, no thread-local state (autograd calls backward from a worker thread); the ONLY process-global
- *     state is the kernel-variant override of mv_gemm_force_variant (a tuning / test hook, atomic, default 0 =
- *     automatic): it changes which kernel computes a product, never what is computed
+ *     state is the kernel-variant overrides of mv_gemm_force_variant / mv_gemm_f32_force_fma (tuning / test hooks, atomic,
+ *     default 0 = automatic): they change which kernel computes a product, never what is computed
  *   - "rows x dim" tensors are row-major; `ld*` are leading dimensions in ELEMENTS
  *   - dtype codes: MV_F32 / MV_BF16
  *   - MFMA entry points (mv_gemm_*_bf16, mv_attention_*) need 16-byte aligned pointers and
@@ -109,6 +109,13 @@ int mv_gemm_f32(const float* A, long sa_m, long sa_k, long sa_b1, long sa_b2, co
                 long sb_b1, long sb_b2, float* C, long sc_m, long sc_n, long sc_b1, long sc_b2, int M, int N, int K,
                 int nb1, int nb2, float alpha, int accumulate, const float* bias, int epilogue, const float* aux,
                 long ld_aux, int aux_i, float* out2, long ld_out2, mv_stream_t stream);
+/* out[i] (+)= sum_s slabs[s * stride + i], s in fixed order: the deterministic reduce of a product whose contraction was
+ * split over mv_gemm_f32's batch dimension (dW = dY^T X has 50 432 contraction rows and only 36-144 output tiles) */
+int mv_sum_slabs(const float* slabs, long stride, int S, float* out, long n, int accumulate, mv_stream_t stream);
+/* Test / tuning hook (no reference counterpart; the second piece of process-global state next to mv_gemm_force_variant):
+ * 1 = mv_gemm_f32 runs its FMA kernel, 0 (default; MV_GEMM_F32=fma in the environment starts with 1) = the f32-input MFMA
+ * kernel.  Both compute the same k-ordered fmaf chain per output: results are bit-identical. */
+int mv_gemm_f32_force_fma(int on);
 
 /* ---- fused multi-head self-attention core -- Attention.forward vit.py:87-96 ----
  * qkv: bf16 [B, N, 3, H, 64] (the to_qkv output, feature order [q|k|v][head][dh], vit.py:87-90);
@@ -178,6 +185,19 @@ int mv_quant_affine(const float* x, float* y, long n, float scale, int zero_poin
  * (vit.py:48-51) without the fp32 round trip; 0: none. */
 int mv_quant_affine_codes(const void* x, int x_dtype, void* codes, long rows, int cols, int ld, float scale, int zero_point,
                           int qmin, int qmax, int pre_op, mv_stream_t stream);
+/* the same quantiser writing int8 codes q - 128 (quint8: qmin 0, qmax 255) for mv_gemm_nt_i8; ld = row stride in BYTES
+ * (multiple of 16), columns [cols, ld) zero-filled */
+int mv_quant_affine_i8(const void* x, int x_dtype, void* codes, long rows, int cols, int ld, float scale, int zero_point,
+                       int pre_op, mv_stream_t stream);
+/* int8 x int8 -> int32 NT product on v_mfma_i32_16x16x64_i8 with the affine bookkeeping in the epilogue (config 5; build-
+ * defined: the reference's converted PyTorchINT8 path, quantize.py:230-251 + classification/test_quantize.py:109, does not run):
+ *   C[m][n] = alpha * ( sum_k A8[m][k] * B8[n][k] + icorr[n] ) + bias[n]  (+ aux[m][n] for MV_EPI_RESIDUAL)
+ * With A8 = q_x - 128, B8 = q_w and icorr[n] = (128 - zero_point_x) * sum_k q_w[n][k] the bracket is the exact integer dot
+ * product of (q_x - zero_point_x) and q_w; alpha = scale_x * scale_w.  A8 [M, lda], B8 [N, ldb] int8, strides in bytes
+ * (multiples of 16), K % 256 == 0; C fp32 or bf16; epilogues MV_EPI_NONE / MV_EPI_RESIDUAL (fp32). */
+int mv_gemm_nt_i8(const void* A, int lda, const void* B, int ldb, void* C, int ldc, int c_dtype, int M, int N, int K,
+                  float alpha, const float* bias, const int* icorr, int epilogue, const void* aux, int ld_aux,
+                  mv_stream_t stream);
 /* running min/max observer: minmax[0] = min(minmax[0], min x), minmax[1] = max(minmax[1], max x);
  * minmax points at FOUR floats: [2..3] are scratch for the reduction */
 int mv_minmax(const float* x, long n, float* minmax, mv_stream_t stream);

@@ -332,6 +332,30 @@ __global__ __launch_bounds__(256) void quant_affine_codes_vec_kernel(const XT* _
   }
 }
 
+// int8 form for the v_mfma_i32_16x16x64_i8 GEMM: y = q - 128 (q the uint8 quantiser output in [0, 255]), 16 codes = one
+// 16-byte store per thread iteration; columns [cols, ld) are zero-filled (they meet zero weight codes)
+template <int PRE, typename XT>
+__global__ __launch_bounds__(256) void quant_affine_i8_kernel(const XT* __restrict__ x, int8_t* __restrict__ y, long rows,
+                                                              int cols, int ld, float inv, int zp) {
+  const float fz = (float)zp;
+  const int l16 = ld >> 4;
+  for (long r = blockIdx.x; r < rows; r += gridDim.x) {
+    const XT* xr = x + r * cols;
+    u32x4* yr = reinterpret_cast<u32x4*>(y + r * ld);
+    for (int j = threadIdx.x; j < l16; j += 256) {
+      unsigned w[4] = {0u, 0u, 0u, 0u};
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const int c = 16 * j + e;
+        int code = 0;
+        if (c < cols) code = (int)(affine_code_one<PRE>((float)xr[c], inv, fz, 0.f, 255.f) + fz) - 128;   // q - 128
+        w[e >> 2] |= ((unsigned)code & 0xFFu) << (8 * (e & 3));
+      }
+      yr[j] = (u32x4){w[0], w[1], w[2], w[3]};
+    }
+  }
+}
+
 // order-preserving float <-> uint map so min/max can use integer atomics
 __device__ __forceinline__ unsigned f2ord(float f) {
   const unsigned u = __float_as_uint(f);
@@ -569,6 +593,25 @@ __global__ void upsample_bwd_kernel(const float* __restrict__ dout, float* __res
       }
     }
     din[b * sb + c * sc + (long)(y * w + x) * sp] = s;
+  }
+}
+
+// ---- out[i] (+)= sum over s of slabs[s * stride + i], fixed order (deterministic): the reduce of a K-split product ----
+__global__ __launch_bounds__(256) void sum_slabs_kernel(const float* __restrict__ slabs, long stride, int S,
+                                                        float* __restrict__ out, long n, int accumulate) {
+  const long n4 = n >> 2;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long)gridDim.x * 256) {
+    float4 t = accumulate ? reinterpret_cast<const float4*>(out)[i] : make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int k = 0; k < S; ++k) {
+      const float4 v = reinterpret_cast<const float4*>(slabs + (long)k * stride)[i];
+      t.x += v.x; t.y += v.y; t.z += v.z; t.w += v.w;
+    }
+    reinterpret_cast<float4*>(out)[i] = t;
+  }
+  for (long i = (n4 << 2) + (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
+    float t = accumulate ? out[i] : 0.f;
+    for (int k = 0; k < S; ++k) t += slabs[(long)k * stride + i];
+    out[i] = t;
   }
 }
 
@@ -886,6 +929,23 @@ extern "C" int mv_quant_affine_codes(const void* x, int x_dtype, void* codes, lo
   return launch_quant_codes((const bf16_t*)x, codes, rows, cols, ld, inv, zero_point, qmin, qmax, pre_op, S_);
 }
 
+extern "C" int mv_quant_affine_i8(const void* x, int x_dtype, void* codes, long rows, int cols, int ld, float scale,
+                                  int zero_point, int pre_op, mv_stream_t stream) {
+  MV_REQUIRE(rows >= 0 && cols > 0 && ld >= cols && ld % 16 == 0 && scale > 0.f, MV_ERR_SHAPE);
+  MV_REQUIRE(zero_point >= 0 && zero_point <= 255, MV_ERR_UNSUPPORTED);                     // quint8
+  MV_REQUIRE((pre_op == 0 || pre_op == 1) && (x_dtype == MV_F32 || x_dtype == MV_BF16), MV_ERR_UNSUPPORTED);
+  MV_REQUIRE(mv_aligned16(codes), MV_ERR_ALIGN);
+  if (rows == 0) return MV_OK;
+  const float inv = 1.0f / scale;
+  const int grid = rows < 4096 ? (int)rows : 4096;
+#define MV_QI8(PRE_, T_) quant_affine_i8_kernel<PRE_, T_><<<grid, 256, 0, S_>>>((const T_*)x, (int8_t*)codes, rows, cols, ld, inv, zero_point)
+  if (x_dtype == MV_F32) { if (pre_op) MV_QI8(1, float); else MV_QI8(0, float); }
+  else { if (pre_op) MV_QI8(1, bf16_t); else MV_QI8(0, bf16_t); }
+#undef MV_QI8
+  MV_CHECK_LAUNCH();
+  return MV_OK;
+}
+
 extern "C" int mv_minmax(const float* x, long n, float* minmax, mv_stream_t stream) {
   MV_REQUIRE(n >= 0, MV_ERR_SHAPE);
   if (n == 0) return MV_OK;
@@ -957,6 +1017,15 @@ extern "C" int mv_adamw(float* p, const float* g, float* m, float* v, long n, fl
   MV_REQUIRE(mv_aligned16(p) && mv_aligned16(g) && mv_aligned16(m) && mv_aligned16(v), MV_ERR_ALIGN);
   adamw_kernel<<<ew_grid((n + 3) / 4), 256, 0, S_>>>(p, g, m, v, n, lr, beta1, beta2, eps, weight_decay, bias_corr1,
                                                      bias_corr2, grad_scale, clip_coef);
+  MV_CHECK_LAUNCH();
+  return MV_OK;
+}
+
+extern "C" int mv_sum_slabs(const float* slabs, long stride, int S, float* out, long n, int accumulate, mv_stream_t stream) {
+  MV_REQUIRE(S >= 1 && n >= 0 && stride >= n && (stride & 3) == 0, MV_ERR_SHAPE);
+  MV_REQUIRE(mv_aligned16(slabs) && mv_aligned16(out), MV_ERR_ALIGN);
+  if (n == 0) return MV_OK;
+  sum_slabs_kernel<<<ew_grid((n + 3) / 4), 256, 0, S_>>>(slabs, stride, S, out, n, accumulate);
   MV_CHECK_LAUNCH();
   return MV_OK;
 }

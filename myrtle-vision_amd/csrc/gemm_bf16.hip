@@ -71,6 +71,7 @@ struct EpiArgs {
   int aux_i;
   void* out2;
   int ld_out2;
+  const int* icorr;     // int8 GEMM only: per-output-column integer added to the int32 dot product before scaling
 };
 
 // 16-byte output store of the NT epilogues
@@ -819,7 +820,14 @@ constexpr int P8_SLOT = 128 * 64 * 2;   // 16 KiB
 constexpr int P8_SMEM = 8 * P8_SLOT;    // 128 KiB
 constexpr int P8_BQ0 = 0, P8_AQ0 = 1, P8_BQ1 = 2, P8_AQ1 = 3;   // slot order in a buffer = staging order
 
-template <int EPI, typename CT>
+typedef __attribute__((ext_vector_type(4))) int i32x4;
+
+// I8 = true: the operands are int8 (v_mfma_i32_16x16x64_i8, int32 accumulation: exact).  An int8 row of K bytes has the
+// geometry of a bf16 row of K/2 elements and a lane's 16-byte fragment holds 16 consecutive k instead of 8, for BOTH
+// operands alike, so staging, LDS image, swizzle and fragment reads are unchanged (the caller passes K/2, lda/2, ldb/2);
+// only the MFMA differs, and twice the MACs ride on every staged byte.  The int32 sums leave as floats through the same
+// epilogues, after the zero-point correction icorr[n] has been added in integer arithmetic.
+template <int EPI, typename CT, bool I8 = false>
 __global__ __launch_bounds__(512, 2) void gemm_nt_8phase_kernel(const bf16_t* __restrict__ A, int lda,
                                                                 const bf16_t* __restrict__ B, int ldb, CT* __restrict__ C,
                                                                 int ldc, int M, int N, int K, int tiles_n, EpiArgs ep,
@@ -921,9 +929,15 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_8phase_kernel(const bf16_t* __
     __builtin_amdgcn_s_setprio(1);                                                                           \
     _Pragma("unroll") for (int ks = 0; ks < 2; ++ks)                                                         \
       _Pragma("unroll") for (int i = 0; i < 4; ++i)                                                          \
-        _Pragma("unroll") for (int j = 0; j < 2; ++j)                                                        \
-          acc[(mb_) + i][(nb_) + j] =                                                                        \
-              __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfx_[j][ks], af[i][ks], acc[(mb_) + i][(nb_) + j], 0, 0, 0); \
+        _Pragma("unroll") for (int j = 0; j < 2; ++j) {                                                      \
+          if constexpr (I8)                                                                                  \
+            acc[(mb_) + i][(nb_) + j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_mfma_i32_16x16x64_i8(     \
+                __builtin_bit_cast(i32x4, bfx_[j][ks]), __builtin_bit_cast(i32x4, af[i][ks]),                \
+                __builtin_bit_cast(i32x4, acc[(mb_) + i][(nb_) + j]), 0, 0, 0));                             \
+          else                                                                                               \
+            acc[(mb_) + i][(nb_) + j] =                                                                      \
+                __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfx_[j][ks], af[i][ks], acc[(mb_) + i][(nb_) + j], 0, 0, 0); \
+        }                                                                                                    \
     __builtin_amdgcn_s_setprio(0);                                                                           \
   }
 #define P8_BAR()                                  \
@@ -1008,6 +1022,24 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_8phase_kernel(const bf16_t* __
   // 64-register accumulator halves: the second half waits in LDS (free now: every wave has passed the final barrier
   // after its last fragment read, and no DMA is outstanding) -- a 16 x ds_write_b128 / ds_read_b128 round trip per lane
   // instead of 60-170 registers spilled to scratch memory.
+  if constexpr (I8) {
+    // exact int32 dot products (+ the per-column zero-point correction, still in integer arithmetic) -> float
+    const int nc = n0 + 128 * (wn >> 1) + 64 * (wn & 1) + 4 * (lane >> 4);          // + 16 j + r: this lane's columns
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      int c[4] = {0, 0, 0, 0};
+      if (ep.icorr) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) c[r] = (nc + 16 * j + r < N) ? ep.icorr[nc + 16 * j + r] : 0;
+      }
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        // (bit-cast the WHOLE vector: __builtin_bit_cast of a single vector element reads element 0's storage)
+        const i32x4 iv = __builtin_bit_cast(i32x4, acc[i][j]);
+        acc[i][j] = (f32x4){(float)(iv[0] + c[0]), (float)(iv[1] + c[1]), (float)(iv[2] + c[2]), (float)(iv[3] + c[3])};
+      }
+    }
+  }
 #if MV_ABLATE == 8
   {                                              // diagnostic: no epilogue; one conditional store keeps the accumulators alive
     float keep = 0.f;
@@ -1878,7 +1910,7 @@ extern "C" int mv_gemm_nt_bf16_scaled(const void* A, int lda, const void* B, int
   MV_REQUIRE(lda % 8 == 0 && ldb % 8 == 0 && lda >= ((K + 7) & ~7) && ldb >= ((K + 7) & ~7), MV_ERR_ALIGN);
   MV_REQUIRE(mv_aligned16(A) && mv_aligned16(B) && mv_aligned16(C), MV_ERR_ALIGN);
   hipStream_t s = (hipStream_t)stream;
-  EpiArgs ep{alpha, bias, aux, ld_aux, aux_i, out2, ld_out2};
+  EpiArgs ep{alpha, bias, aux, ld_aux, aux_i, out2, ld_out2, nullptr};
   switch (epilogue) {
     case MV_EPI_NONE:
       return c_dtype == MV_F32 ? launch_nt<MV_EPI_NONE, float>(A, lda, B, ldb, C, ldc, M, N, K, ep, s)
@@ -1901,6 +1933,46 @@ extern "C" int mv_gemm_nt_bf16_scaled(const void* A, int lda, const void* B, int
     case MV_EPI_EMBED:
       MV_REQUIRE(c_dtype == MV_F32 && aux && aux_i > 0, MV_ERR_UNSUPPORTED);
       return launch_nt<MV_EPI_EMBED, float>(A, lda, B, ldb, C, ldc, M, N, K, ep, s);
+    default:
+      return MV_ERR_UNSUPPORTED;
+  }
+}
+
+namespace {
+template <int EPI, typename CT>
+int launch_nt_i8(const void* A, int lda, const void* B, int ldb, void* C, int ldc, int M, int N, int K, EpiArgs ep,
+                 hipStream_t s) {
+  static const int a8 = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_nt_8phase_kernel<EPI, CT, true>),
+                                            hipFuncAttributeMaxDynamicSharedMemorySize, P8_SMEM) == hipSuccess ? 0 : -1;
+  if (a8) return MV_ERR_LAUNCH;
+  const int t2m = mv_cdiv(M, BM2), t2n = mv_cdiv(N, BN2);
+  const int tiles = t2m * t2n, full = nt_full_tiles(tiles);
+  // bytes -> the bf16-element geometry the kernel is written in
+  gemm_nt_8phase_kernel<EPI, CT, true><<<full + 2 * (tiles - full), 512, P8_SMEM, s>>>(
+      (const bf16_t*)A, lda / 2, (const bf16_t*)B, ldb / 2, (CT*)C, ldc, M, N, K / 2, t2n, ep, full, 0, 0);
+  MV_CHECK_LAUNCH();
+  return MV_OK;
+}
+}  // namespace
+
+extern "C" int mv_gemm_nt_i8(const void* A, int lda, const void* B, int ldb, void* C, int ldc, int c_dtype, int M, int N, int K,
+                             float alpha, const float* bias, const int* icorr, int epilogue, const void* aux, int ld_aux,
+                             mv_stream_t stream) {
+  MV_REQUIRE(M >= 0 && N >= 0 && K > 0, MV_ERR_SHAPE);
+  if (M == 0 || N == 0) return MV_OK;
+  MV_REQUIRE(K % 256 == 0, MV_ERR_UNSUPPORTED);                       // two whole 128-byte K-tiles per 8-phase iteration
+  MV_REQUIRE(lda % 16 == 0 && ldb % 16 == 0 && lda >= K && ldb >= K, MV_ERR_ALIGN);
+  MV_REQUIRE(mv_aligned16(A) && mv_aligned16(B) && mv_aligned16(C), MV_ERR_ALIGN);
+  MV_REQUIRE((long)M * lda < (1L << 32) && (long)N * ldb < (1L << 32), MV_ERR_SHAPE);
+  hipStream_t s = (hipStream_t)stream;
+  EpiArgs ep{alpha, bias, aux, ld_aux, 0, nullptr, 0, icorr};
+  switch (epilogue) {
+    case MV_EPI_NONE:
+      return c_dtype == MV_F32 ? launch_nt_i8<MV_EPI_NONE, float>(A, lda, B, ldb, C, ldc, M, N, K, ep, s)
+                               : launch_nt_i8<MV_EPI_NONE, bf16_t>(A, lda, B, ldb, C, ldc, M, N, K, ep, s);
+    case MV_EPI_RESIDUAL:
+      MV_REQUIRE(c_dtype == MV_F32 && aux, MV_ERR_UNSUPPORTED);
+      return launch_nt_i8<MV_EPI_RESIDUAL, float>(A, lda, B, ldb, C, ldc, M, N, K, ep, s);
     default:
       return MV_ERR_UNSUPPORTED;
   }

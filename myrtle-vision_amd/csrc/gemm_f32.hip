@@ -1,4 +1,5 @@
 // Generic strided, batched fp32 contraction + row softmax: the exact-parity (precision="fp32") path.
+// Two kernels with bit-identical results: gemm_f32_mfma_kernel (matrix cores, the default) and gemm_f32_kernel (FMA).
 //
 // Every product of the hot path can be expressed through element strides, so this one kernel covers
 // nn.Linear forward / dX / dW and the materialised attention products q k^T, p v and their gradients
@@ -8,6 +9,10 @@
 // 64x64 tile, K-step 16, 256 threads x (4x4) outputs, LDS-staged, staging map chosen per operand so the
 // unit-stride axis is the one consecutive lanes walk.
 #include "mv_common.h"
+
+#include <string.h>
+
+#include <atomic>
 
 namespace {
 
@@ -100,6 +105,203 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(F32Args a) {
   }
 }
 
+// ------------------------------------------------------------------------------------------------------------------
+// The same contraction on the matrix cores: v_mfma_f32_16x16x4_f32 (f32 in, f32 accumulate).  The instruction IS a
+// k-ordered fmaf chain (one rounding per product, no wider accumulator: MI355X_MICROARCH.md, Matrix cores), so every output
+// is bit-for-bit what gemm_f32_kernel computes -- at the f32 MFMA rate (64 FLOP/clk/SIMD = the f32 VALU peak, but with one
+// operand VGPR per 16x16x4 block instead of a 4x4 register tile per thread, and no VALU issue competing with address
+// arithmetic): 4-6x the FMA kernel on the ViT shapes.
+//   block = 4 waves as 2 x 2, wave tile (16 WT)^2 with WT = 4 (128 x 128 block) or 2 (64 x 64 block: the 197-token
+//   attention products); K-step 16 = four MFMA k-blocks.
+//   LDS image, both operands: X[idx][16 k] stored as [idx][g][kk] with k = 4 kk + g, rows of 20 floats (80 B): lane
+//   (idx = l & 15, g = l >> 4) -- exactly the MFMA operand map A[l&15][k = l>>4] -- reads its four k-blocks as ONE
+//   ds_read_b128; element kk of that vector feeds MFMA kk.
+//   The MFMA is issued as D' = Bfrag x Afrag (i.e. it produces C^T), so a lane holds four CONSECUTIVE COLUMNS of one output
+//   row: float4 epilogue accesses when C is row-major.
+//   Staging is register double-buffered (global loads of step t+1 in flight under the MFMAs of step t, one barrier per
+//   step) with the same stride-adaptive thread map as the FMA kernel: consecutive lanes walk the operand's unit-stride axis.
+template <int EPI, int WT>
+__global__ __launch_bounds__(256) void gemm_f32_mfma_kernel(F32Args a) {
+  constexpr int TB = 32 * WT;              // block tile edge
+  constexpr int LDK = 20;                  // floats per LDS row (16 + 4 pad; keeps 16-byte alignment of the b128 reads)
+  constexpr int PER = TB * 16 / 256;       // staged elements per thread and operand
+  __shared__ __attribute__((aligned(16))) float As[2][TB * LDK];
+  __shared__ __attribute__((aligned(16))) float Bs[2][TB * LDK];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wr = wave >> 1, wc = wave & 1;
+  const int b1 = blockIdx.z / a.nb2, b2 = blockIdx.z % a.nb2;
+  const float* A = a.A + b1 * a.sa_b1 + b2 * a.sa_b2;
+  const float* B = a.B + b1 * a.sb_b1 + b2 * a.sb_b2;
+  float* C = a.C + b1 * a.sc_b1 + b2 * a.sc_b2;
+  const int m0 = blockIdx.y * TB, n0 = blockIdx.x * TB;
+  const bool a_kfast = (a.sa_k == 1), b_kfast = (a.sb_k == 1);
+
+  // staging map: element e (0 .. PER-1) of this thread is tile position (idx0 + e di, k0 + e dk) -- consecutive lanes walk
+  // the operand's unit-stride axis; the per-element step is wave-uniform, so one base pointer per operand is enough
+  const int ai0 = a_kfast ? (tid >> 4) : (tid % TB), ak0 = a_kfast ? (tid & 15) : (tid / TB);
+  const int bi0 = b_kfast ? (tid >> 4) : (tid % TB), bk0 = b_kfast ? (tid & 15) : (tid / TB);
+  const int adi = a_kfast ? 16 : 0, adk = a_kfast ? 0 : 256 / TB, bdi = b_kfast ? 16 : 0, bdk = b_kfast ? 0 : 256 / TB;
+  const float* const pa = A + (long)(m0 + ai0) * a.sa_m + (long)ak0 * a.sa_k;
+  const float* const pb = B + (long)(n0 + bi0) * a.sb_n + (long)bk0 * a.sb_k;
+  const long astep = (long)adi * a.sa_m + (long)adk * a.sa_k, bstep = (long)bdi * a.sb_n + (long)bdk * a.sb_k;
+  // Loads are unconditional from clamped addresses; the zero-fill select happens at STORE time, after the MFMAs of the
+  // current step -- selecting right after the load would make the compiler wait for the data before the MFMA block and
+  // expose a full memory latency per step (seen in the first version's ISA: vmcnt(0) in front of the MFMAs).
+  float ra[PER], rb[PER];
+  unsigned oka = 0, okb = 0;                 // bit e: element e is inside the operand
+  auto load_tile = [&](int k0) {
+    oka = okb = 0;
+#pragma unroll
+    for (int e = 0; e < PER; ++e) {
+      const bool ok = (m0 + ai0 + e * adi) < a.M && (k0 + ak0 + e * adk) < a.K;
+      ra[e] = *(ok ? pa + e * astep + (long)k0 * a.sa_k : A);
+      oka |= (ok ? 1u : 0u) << e;
+      const bool ob = (n0 + bi0 + e * bdi) < a.N && (k0 + bk0 + e * bdk) < a.K;
+      rb[e] = *(ob ? pb + e * bstep + (long)k0 * a.sb_k : B);
+      okb |= (ob ? 1u : 0u) << e;
+    }
+  };
+  auto store_tile = [&](int buf) {
+#pragma unroll
+    for (int e = 0; e < PER; ++e) {
+      const int ka = ak0 + e * adk, kb = bk0 + e * bdk;
+      As[buf][(ai0 + e * adi) * LDK + (ka & 3) * 4 + (ka >> 2)] = ((oka >> e) & 1u) ? ra[e] : 0.f;
+      Bs[buf][(bi0 + e * bdi) * LDK + (kb & 3) * 4 + (kb >> 2)] = ((okb >> e) & 1u) ? rb[e] : 0.f;
+    }
+  };
+
+  f32x4 acc[WT][WT];
+#pragma unroll
+  for (int i = 0; i < WT; ++i)
+#pragma unroll
+    for (int j = 0; j < WT; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  const int nk = (a.K + 15) >> 4;
+  const int frag = (lane & 15) * LDK + (lane >> 4) * 4;
+  if (nk > 0) {
+    load_tile(0);
+    store_tile(0);
+  }
+  __syncthreads();
+  for (int kt = 0; kt < nk; ++kt) {
+    const int cur = kt & 1;
+    if (kt + 1 < nk) load_tile((kt + 1) << 4);
+    f32x4 af[WT], bf[WT];
+#pragma unroll
+    for (int i = 0; i < WT; ++i) {
+      af[i] = *reinterpret_cast<const f32x4*>(&As[cur][(wr * WT + i) * 16 * LDK + frag]);
+      bf[i] = *reinterpret_cast<const f32x4*>(&Bs[cur][(wc * WT + i) * 16 * LDK + frag]);
+    }
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk)
+#pragma unroll
+      for (int i = 0; i < WT; ++i)
+#pragma unroll
+        for (int j = 0; j < WT; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(bf[j][kk], af[i][kk], acc[i][j], 0, 0, 0);
+    if (kt + 1 < nk) store_tile(cur ^ 1);
+    __syncthreads();
+  }
+
+  // epilogue: lane holds, per 16x16 block (i, j), row m = .. + (lane & 15) and columns n = .. + 4 (lane >> 4) + 0..3
+  const bool vec = a.sc_n == 1 && (a.sc_m & 3) == 0 && (reinterpret_cast<uintptr_t>(C) & 15) == 0 && !a.accumulate;
+  // interior blocks of row-major outputs: branch-free, every bias / aux vector loaded before the first store (a
+  // per-element "n < N ? load : 0" makes the compiler branch around each load and wait vmcnt(0) per element)
+  const bool interior = vec && m0 + TB <= a.M && n0 + TB <= a.N && (a.ld_aux & 3) == 0 && (a.ld_out2 & 3) == 0 &&
+                        (reinterpret_cast<uintptr_t>(a.bias) & 15) == 0 && (reinterpret_cast<uintptr_t>(a.aux) & 15) == 0 &&
+                        (reinterpret_cast<uintptr_t>(a.out2) & 15) == 0;
+  if (interior) {
+    const int mb = m0 + wr * WT * 16 + (lane & 15), nb0 = n0 + wc * WT * 16 + (lane >> 4) * 4;
+    float4 bv[WT];
+#pragma unroll
+    for (int j = 0; j < WT; ++j)
+      bv[j] = a.bias ? *reinterpret_cast<const float4*>(a.bias + nb0 + 16 * j) : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+    for (int i = 0; i < WT; ++i) {
+      const int m = mb + 16 * i;
+      long crow = m, arow = m;
+      if constexpr (EPI == MV_EPI_EMBED) {
+        const int img = m / a.aux_i;
+        arow = 1 + (m - img * a.aux_i);
+        crow = (long)img * (a.aux_i + 1) + arow;
+      }
+      float4 ax[WT];
+      if constexpr (EPI == MV_EPI_RESIDUAL || EPI == MV_EPI_DGELU || EPI == MV_EPI_EMBED) {
+#pragma unroll
+        for (int j = 0; j < WT; ++j) ax[j] = *reinterpret_cast<const float4*>(a.aux + arow * a.ld_aux + nb0 + 16 * j);
+      }
+#pragma unroll
+      for (int j = 0; j < WT; ++j) {
+        const float bb[4] = {bv[j].x, bv[j].y, bv[j].z, bv[j].w};
+        float v[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          float t = acc[i][j][r] * a.alpha;
+          if (a.bias) t += bb[r];
+          v[r] = t;
+        }
+        if constexpr (EPI == MV_EPI_GELU) {
+          if (a.out2) *reinterpret_cast<float4*>(a.out2 + (long)m * a.ld_out2 + nb0 + 16 * j) = make_float4(v[0], v[1], v[2], v[3]);
+#pragma unroll
+          for (int r = 0; r < 4; ++r) v[r] = gelu_f(v[r]);
+        } else if constexpr (EPI == MV_EPI_RESIDUAL || EPI == MV_EPI_EMBED) {
+          v[0] += ax[j].x; v[1] += ax[j].y; v[2] += ax[j].z; v[3] += ax[j].w;
+        } else if constexpr (EPI == MV_EPI_DGELU) {
+          v[0] *= dgelu_f(ax[j].x); v[1] *= dgelu_f(ax[j].y); v[2] *= dgelu_f(ax[j].z); v[3] *= dgelu_f(ax[j].w);
+        }
+        *reinterpret_cast<float4*>(C + crow * a.sc_m + nb0 + 16 * j) = make_float4(v[0], v[1], v[2], v[3]);
+      }
+    }
+    return;
+  }
+#pragma unroll
+  for (int i = 0; i < WT; ++i) {
+    const int m = m0 + (wr * WT + i) * 16 + (lane & 15);
+    if (m >= a.M) continue;
+    long crow = m;
+    int patch = 0;
+    if constexpr (EPI == MV_EPI_EMBED) {
+      const int img = m / a.aux_i;
+      patch = m - img * a.aux_i;
+      crow = (long)img * (a.aux_i + 1) + 1 + patch;
+    }
+#pragma unroll
+    for (int j = 0; j < WT; ++j) {
+      const int nb = n0 + (wc * WT + j) * 16 + (lane >> 4) * 4;
+      float v[4];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int n = nb + r;
+        float t = acc[i][j][r] * a.alpha;
+        if (n < a.N) {
+          if (a.bias) t += a.bias[n];
+          if constexpr (EPI == MV_EPI_GELU) {
+            if (a.out2) a.out2[(long)m * a.ld_out2 + n] = t;
+            t = gelu_f(t);
+          } else if constexpr (EPI == MV_EPI_RESIDUAL) {
+            t += a.aux[(long)m * a.ld_aux + n];
+          } else if constexpr (EPI == MV_EPI_DGELU) {
+            t *= dgelu_f(a.aux[(long)m * a.ld_aux + n]);
+          } else if constexpr (EPI == MV_EPI_EMBED) {
+            t += a.aux[(long)(1 + patch) * a.ld_aux + n];
+          }
+        }
+        v[r] = t;
+      }
+      if (vec && nb + 3 < a.N) {
+        *reinterpret_cast<float4*>(C + crow * a.sc_m + nb) = make_float4(v[0], v[1], v[2], v[3]);
+      } else {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          if (nb + r >= a.N) continue;
+          float* c = C + crow * a.sc_m + (long)(nb + r) * a.sc_n;
+          *c = a.accumulate ? (*c + v[r]) : v[r];
+        }
+      }
+    }
+  }
+}
+
 // one wave per row; row kept in registers when cols <= 64*VPL, else re-read (cols here: 197..257)
 __global__ __launch_bounds__(256) void softmax_fwd_kernel(const float* __restrict__ x, float* __restrict__ y, long rows,
                                                           int cols, float scale) {
@@ -132,7 +334,15 @@ __global__ __launch_bounds__(256) void softmax_bwd_kernel(const float* __restric
   }
 }
 
+// test / tuning hook: 1 = FMA kernel, 0 = matrix cores (initialised from MV_GEMM_F32=fma)
+std::atomic<int> g_f32_fma{getenv("MV_GEMM_F32") && !strcmp(getenv("MV_GEMM_F32"), "fma") ? 1 : 0};
+
 }  // namespace
+
+extern "C" int mv_gemm_f32_force_fma(int on) {
+  g_f32_fma.store(on ? 1 : 0, std::memory_order_relaxed);
+  return MV_OK;
+}
 
 extern "C" int mv_gemm_f32(const float* A, long sa_m, long sa_k, long sa_b1, long sa_b2, const float* B, long sb_k,
                            long sb_n, long sb_b1, long sb_b2, float* C, long sc_m, long sc_n, long sc_b1, long sc_b2,
@@ -144,8 +354,34 @@ extern "C" int mv_gemm_f32(const float* A, long sa_m, long sa_k, long sa_b1, lon
   MV_REQUIRE((long)nb1 * nb2 <= 65535, MV_ERR_SHAPE);
   F32Args a{A, sa_m, sa_k, sa_b1, sa_b2, B, sb_k, sb_n, sb_b1, sb_b2, C, sc_m, sc_n, sc_b1, sc_b2,
             M, N, K, nb2, alpha, accumulate, bias, aux, ld_aux, aux_i, out2, ld_out2};
-  dim3 grid(mv_cdiv(N, TN), mv_cdiv(M, TM), nb1 * nb2);
   hipStream_t s = (hipStream_t)stream;
+  // Matrix-core form (bit-identical results).  128 x 128 blocks when that wastes little of the last row / column of blocks,
+  // 64 x 64 otherwise (M = N = 197: 77 % useful instead of 59 %).  mv_gemm_f32_force_fma(1) / MV_GEMM_F32=fma keeps the FMA kernel.
+  if (!g_f32_fma.load(std::memory_order_relaxed)) {
+    const long pad128 = (long)mv_cdiv(M, 128) * 128 * mv_cdiv(N, 128) * 128, pad64 = (long)mv_cdiv(M, 64) * 64 * mv_cdiv(N, 64) * 64;
+    const bool big = pad128 * 10 <= pad64 * 11;             // at most 10 % more padded work than the 64-tiles need
+#define MV_F32_LAUNCH(E)                                                                                    \
+    if (big) gemm_f32_mfma_kernel<E, 4><<<dim3(mv_cdiv(N, 128), mv_cdiv(M, 128), nb1 * nb2), 256, 0, s>>>(a); \
+    else gemm_f32_mfma_kernel<E, 2><<<dim3(mv_cdiv(N, 64), mv_cdiv(M, 64), nb1 * nb2), 256, 0, s>>>(a);
+    switch (epilogue) {
+      case MV_EPI_NONE: MV_F32_LAUNCH(MV_EPI_NONE) break;
+      case MV_EPI_GELU: MV_F32_LAUNCH(MV_EPI_GELU) break;
+      case MV_EPI_RESIDUAL:
+        MV_REQUIRE(aux, MV_ERR_UNSUPPORTED);
+        MV_F32_LAUNCH(MV_EPI_RESIDUAL) break;
+      case MV_EPI_DGELU:
+        MV_REQUIRE(aux, MV_ERR_UNSUPPORTED);
+        MV_F32_LAUNCH(MV_EPI_DGELU) break;
+      case MV_EPI_EMBED:
+        MV_REQUIRE(aux && aux_i > 0, MV_ERR_UNSUPPORTED);
+        MV_F32_LAUNCH(MV_EPI_EMBED) break;
+      default: return MV_ERR_UNSUPPORTED;
+    }
+#undef MV_F32_LAUNCH
+    MV_CHECK_LAUNCH();
+    return MV_OK;
+  }
+  dim3 grid(mv_cdiv(N, TN), mv_cdiv(M, TM), nb1 * nb2);
   switch (epilogue) {
     case MV_EPI_NONE: gemm_f32_kernel<MV_EPI_NONE><<<grid, 256, 0, s>>>(a); break;
     case MV_EPI_GELU: gemm_f32_kernel<MV_EPI_GELU><<<grid, 256, 0, s>>>(a); break;

@@ -29,8 +29,12 @@ SIGNATURES = {
     "mv_gemm_nt_bf16": ("pipipii" "iii" "pi" "pii" "pi" "p", _I),
     "mv_gemm_nt_bf16_scaled": ("pipipii" "iii" "f" "pi" "pii" "pi" "p", _I),
     "mv_quant_affine_codes": ("pip" "lii" "f" "iiii" "p", _I),
+    "mv_quant_affine_i8": ("pip" "lii" "f" "ii" "p", _I),
+    "mv_gemm_nt_i8": ("pipipii" "iii" "f" "pp" "i" "pi" "p", _I),
     "mv_gemm_tn_bf16": ("pipipi" "iii" "i" "p" "pz" "p", _I),
     "mv_gemm_f32": ("pllll" "pllll" "pllll" "iii" "ii" "fi" "pi" "pli" "pl" "p", _I),
+    "mv_gemm_f32_force_fma": ("i", _I),
+    "mv_sum_slabs": ("pli" "pli" "p", _I),
     "mv_attention_fwd": ("ppp" "iii" "f" "p", _I),
     "mv_attention_bwd": ("pppppp" "iii" "f" "p", _I),
     "mv_softmax_fwd": ("pp" "li" "f" "p", _I),

@@ -330,11 +330,33 @@ def linear_dw(dy, x, M, N, K, *, ld_dy=None, ldx=None, want_bias=True, weight=No
         if t0 is not None:
             _timer.end("gemm_tn_bf16(+reduce+colsum)", t0, 2.0 * M * N * K, shape=f"dw N{N} K{K} bias{int(want_bias)}")
     else:
-        check(lib().mv_gemm_f32(_p(dy), 1, ld_dy, 0, 0, _p(x), ldx, 1, 0, 0, _p(dw), K, 1, 0, 0, N, K, M, 1, 1, 1.0, 0,
-                                None, EPI_NONE, None, 0, 0, None, 0, _s()), "gemm_f32(dw)", M=N, N=K, K=M)
+        S = f32_dw_splits(M, N, K)
+        if S == 1:
+            check(lib().mv_gemm_f32(_p(dy), 1, ld_dy, 0, 0, _p(x), ldx, 1, 0, 0, _p(dw), K, 1, 0, 0, N, K, M, 1, 1, 1.0, 0,
+                                    None, EPI_NONE, None, 0, 0, None, 0, _s()), "gemm_f32(dw)", M=N, N=K, K=M)
+        else:
+            # the token dimension (50 432 rows at batch 256) split over the kernel's batch axis: S x as many workgroups for a
+            # product with only 36-144 output tiles; slabs summed in a fixed order (deterministic)
+            Mc = M // S
+            slabs = workspace(S * N * K * 4, x.device).view(torch.float32)[:S * N * K]
+            check(lib().mv_gemm_f32(_p(dy), 1, ld_dy, Mc * ld_dy, 0, _p(x), ldx, 1, Mc * ldx, 0, _p(slabs), K, 1, N * K, 0,
+                                    N, K, Mc, S, 1, 1.0, 0, None, EPI_NONE, None, 0, 0, None, 0, _s()),
+                  "gemm_f32(dw, split)", M=N, N=K, K=Mc, S=S)
+            check(lib().mv_sum_slabs(_p(slabs), N * K, S, _p(dw), N * K, 0, _s()), "sum_slabs", S=S, n=N * K)
         if want_bias:
             colsum(dy, M, N, ld_dy, db)
     return dw, db
+
+
+def f32_dw_splits(M, N, K):
+    """Number of equal token-dimension splits of the fp32 dW product [N, K] = dY[M, N]^T X[M, K]: enough for >= 2 workgroups
+    per CU, each split a multiple of 16 rows and at least 512 rows long."""
+    tiles = ((N + 127) // 128) * ((K + 127) // 128)
+    best = 1
+    for s in (2, 4, 8, 16, 32):
+        if M % (16 * s) == 0 and M // s >= 512 and tiles * best < 512 and (N * K) % 4 == 0:
+            best = s
+    return best
 
 
 def colsum(x, rows, cols, ld, out):
@@ -534,6 +556,42 @@ def linear_codes(xc, wc, M, N, K, alpha, bias, out, residual=None):
           "gemm_nt_bf16_scaled", M=M, N=N, K=K)
     if t0 is not None:
         _timer.end("gemm_nt_bf16", t0, 2.0 * M * N * K)
+    return out
+
+
+def pad16(n: int) -> int:
+    return (n + 15) & ~15
+
+
+def quant_affine_i8(x, rows, cols, scale, zero_point, pre_gelu=False):
+    """fp32 or bf16 [rows, cols] -> int8 [rows, pad16(cols)] codes q - 128 of the quint8 affine quantiser (exact);
+    ``pre_gelu``: of gelu(x).  Feeds ``linear_i8``."""
+    require_cuda(x)
+    xf = x.detach()
+    if xf.dtype not in (torch.float32, torch.bfloat16):
+        xf = xf.float()
+    xf = xf.contiguous()
+    ld = pad16(cols)
+    codes = torch.empty(rows, ld, dtype=torch.int8, device=x.device)
+    check(lib().mv_quant_affine_i8(_p(xf), _DT[xf.dtype], _p(codes), rows, cols, ld, float(scale), int(zero_point),
+                                   1 if pre_gelu else 0, _s()), "quant_affine_i8", rows=rows, cols=cols)
+    return codes
+
+
+def linear_i8_supported(M, N, K):
+    """Shapes the int8 MFMA GEMM takes (8-phase kernel: two whole 128-byte K-tiles per iteration, a grid worth a launch)."""
+    return K % 256 == 0 and M >= 256 and N >= 256
+
+
+def linear_i8(x8, w8, M, N, K, alpha, bias, icorr, out, residual=None):
+    """out (fp32 or bf16) [M, N] = alpha * (x8 [M, pad16(K)] . w8 [N, pad16(K)]^T + icorr[N]) + bias (+ residual fp32):
+    int8 operands on v_mfma_i32_16x16x64_i8, int32 accumulation."""
+    t0 = _timer.begin() if _timer is not None else None
+    epi, aux, ld_aux = (EPI_RESIDUAL, _p(residual), N) if residual is not None else (EPI_NONE, None, 0)
+    check(lib().mv_gemm_nt_i8(_p(x8), x8.shape[1], _p(w8), w8.shape[1], _p(out), N, _DT[out.dtype], M, N, K, float(alpha),
+                              _p(bias), _p(icorr), epi, aux, ld_aux, _s()), "gemm_nt_i8", M=M, N=N, K=K)
+    if t0 is not None:
+        _timer.end("gemm_nt_i8", t0, 2.0 * M * N * K, shape=f"i8 N{N} K{K} epi{epi}")
     return out
 
 

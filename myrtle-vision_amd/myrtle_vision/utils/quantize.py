@@ -246,12 +246,14 @@ class QLinear(nn.Linear):
 
 class Int8Linear(nn.Linear):
     """Converted PyTorchINT8 Linear: per-tensor affine uint8 activations x symmetric int8 weights on the matrix cores.
-    Input and weight are turned into INTEGER CODES ((q - zero_point) and w_q, |code| <= 255: exact in bf16), the bf16
-    MFMA GEMM with fp32 accumulation is then the exact integer dot product, and scale_x * scale_w (+ bias) is applied in
-    its epilogue.  Equal to ``linear(fake_quantize(x), fake_quantize(W)) `` -- what the fp32 fallback below computes --
+    Large layers (K % 256 == 0, M, N >= 256: every ViT-B Linear but the classifier head) run on the int8 MFMA
+    (v_mfma_i32_16x16x64_i8: operands q_x - 128 and w_q, int32 accumulation, the (128 - zero_point) sum_k w_q correction and
+    scale_x * scale_w (+ bias) in the epilogue).  Other shapes turn input and weight into INTEGER CODES ((q - zero_point)
+    and w_q, |code| <= 255: exact in bf16) for the bf16 MFMA GEMM with fp32 accumulation -- the same integer dot product.  Equal to ``linear(fake_quantize(x), fake_quantize(W)) `` -- what the fp32 fallback below computes --
     up to fp32 summation order.  (The reference's own converted int8 path does not run: SURVEY 9.2.)"""
 
     precision = "fp32"
+    use_i8 = True          # False: integer codes on the bf16 MFMA for every shape (the round-1 path; A/B tests)
 
     @classmethod
     def from_observed(cls, lin, act_observer, weight_scale):
@@ -259,9 +261,18 @@ class Int8Linear(nn.Linear):
         lin.act_observer = act_observer                       # frozen MinMaxObserver: (scale, zero_point), qmin, qmax
         lin.weight_scale = float(weight_scale)
         N, K = lin.weight.shape
+        wq = torch.round(lin.weight.data.float() / lin.weight_scale)
         codes = torch.zeros(N, ops.pad8(K), dtype=torch.bfloat16, device=lin.weight.device)
-        codes[:, :K] = torch.round(lin.weight.data.float() / lin.weight_scale)
-        lin.weight_codes = codes
+        codes[:, :K] = wq
+        lin.weight_codes = codes                              # small / ragged shapes: integer codes on the bf16 MFMA
+        # int8 MFMA operands (v_mfma_i32_16x16x64_i8): w_q as int8, and the zero-point term of
+        #   sum_k (q_x - z) w = sum_k (q_x - 128) w + (128 - z) sum_k w
+        # folded into one int32 per output column
+        w8 = torch.zeros(N, ops.pad16(K), dtype=torch.int8, device=lin.weight.device)
+        w8[:, :K] = wq.to(torch.int8)
+        lin.weight_i8 = w8
+        z_x = int(act_observer.frozen[1])
+        lin.weight_icorr = ((128 - z_x) * wq.sum(dim=1).to(torch.int64)).to(torch.int32).contiguous()
         return lin
 
     def forward(self, x, pre_gelu=False, residual=None, out_dtype=torch.float32):
@@ -281,14 +292,20 @@ class Int8Linear(nn.Linear):
         N = self.weight.shape[0]
         x2 = x.reshape(-1, K)
         M = x2.shape[0]
-        xc = ops.quant_affine_codes(x2, M, K, s_x, z_x, self.act_observer.qmin, self.act_observer.qmax, pre_gelu=pre_gelu)
         out = torch.empty(M, N, dtype=out_dtype, device=x.device)
         res = None
         if residual is not None:
             if out_dtype != torch.float32:
                 raise ValueError("a fused residual needs an fp32 output")
             res = residual.detach().float().contiguous().view(M, N)
-        ops.linear_codes(xc, self.weight_codes, M, N, K, s_x * self.weight_scale, self.bias, out, residual=res)
+        quint8 = self.act_observer.qmin == 0 and self.act_observer.qmax == 255
+        if quint8 and ops.linear_i8_supported(M, N, K) and getattr(self, "weight_i8", None) is not None and Int8Linear.use_i8:
+            # int8 operands, int32 accumulation on the matrix cores: the same integer dot product, exactly
+            x8 = ops.quant_affine_i8(x2, M, K, s_x, z_x, pre_gelu=pre_gelu)
+            ops.linear_i8(x8, self.weight_i8, M, N, K, s_x * self.weight_scale, self.bias, self.weight_icorr, out, residual=res)
+        else:
+            xc = ops.quant_affine_codes(x2, M, K, s_x, z_x, self.act_observer.qmin, self.act_observer.qmax, pre_gelu=pre_gelu)
+            ops.linear_codes(xc, self.weight_codes, M, N, K, s_x * self.weight_scale, self.bias, out, residual=res)
         return out.view(*x.shape[:-1], N)
 
 

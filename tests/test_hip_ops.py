@@ -321,6 +321,59 @@ def test_gemm_f32_linear_forms(ops):
     assert relerr(db, dy.double().sum(0)) < 2e-6
 
 
+@pytest.mark.parametrize("M,N,K", [(333, 77, 130), (1024, 768, 768), (197, 197, 64), (197, 64, 197), (130, 260, 19)])
+def test_gemm_f32_mfma_is_bitwise_the_fma_chain(ops, M, N, K):
+    """The f32-input MFMA kernel (v_mfma_f32_16x16x4_f32) computes, per output, the same k-ordered fmaf chain as the FMA
+    kernel: every Linear form (forward / dX / dW: three stride patterns), the batched attention products and the fused
+    epilogues must agree BIT FOR BIT, and both must match fp64."""
+    from myrtle_vision.hip.lib import lib
+    x, w, b = torch.randn(M, K, generator=g(1)).cuda(), torch.randn(N, K, generator=g(2)).cuda(), torch.randn(N, generator=g(3)).cuda()
+    dy = torch.randn(M, N, generator=g(4)).cuda()
+    res = torch.randn(M, N, generator=g(5)).cuda()
+
+    def run_all():
+        outs = []
+        o = torch.empty(M, N, device="cuda"); ops.linear_fwd(x, M, K, w, b, o, N); outs.append(o)
+        o = torch.empty(M, N, device="cuda"); ops.linear_fwd(x, M, K, w, b, o, N, epi=ops.EPI_RESIDUAL, aux=res, ld_aux=N); outs.append(o)
+        o, h = torch.empty(M, N, device="cuda"), torch.empty(M, N, device="cuda")
+        ops.linear_fwd(x, M, K, w, b, o, N, epi=ops.EPI_GELU, out2=h, ld_out2=N); outs += [o, h]
+        o = torch.empty(M, K, device="cuda"); ops.linear_dx(dy, M, N, w, o, K); outs.append(o)
+        o = torch.empty(M, K, device="cuda"); ops.linear_dx(dy, M, N, w, o, K, epi=ops.EPI_DGELU, aux=x, ld_aux=K); outs.append(o)
+        dw, db = ops.linear_dw(dy, x, M, N, K); outs += [dw, db]
+        return outs
+
+    lib().mv_gemm_f32_force_fma(1)
+    try:
+        fma = run_all()
+    finally:
+        lib().mv_gemm_f32_force_fma(0)
+    mfma = run_all()
+    for i, (a, c) in enumerate(zip(fma, mfma)):
+        assert torch.equal(a, c), i
+    assert relerr(mfma[0], x.double().cpu() @ w.double().cpu().t() + b.double().cpu()) < 2e-6
+    assert relerr(mfma[4], dy.double().cpu() @ w.double().cpu()) < 2e-6
+    assert relerr(mfma[6], dy.double().cpu().t() @ x.double().cpu()) < 2e-6
+
+
+def test_attention_materialised_fp32_mfma_equals_fma(ops):
+    from myrtle_vision.hip.lib import lib
+    B, N, H, dh = 2, 197, 3, 64
+    qkv = torch.randn(B, N, 3 * H * dh, generator=g(1)).cuda()
+    dout = torch.randn(B, N, H * dh, generator=g(2)).cuda()
+
+    def run():
+        probs = ops.attention_probs_fp32(qkv, B, N, H, dh, dh ** -0.5)
+        return probs, ops.attention_pv_fp32(probs, qkv, B, N, H, dh), ops.attention_bwd_fp32(probs, qkv, dout, B, N, H, dh, dh ** -0.5)
+
+    lib().mv_gemm_f32_force_fma(1)
+    try:
+        a = run()
+    finally:
+        lib().mv_gemm_f32_force_fma(0)
+    for u, v in zip(a, run()):
+        assert torch.equal(u, v)
+
+
 # ---------------------------------------------------------------- attention
 def attn_ref(qkv, H, scale):
     B, N, _ = qkv.shape
@@ -646,6 +699,102 @@ def test_int8_codes_gemm_equals_fake_quant_linear(ops, M, N, K):
     out = torch.empty(M, N, device="cuda")
     ops.linear_codes(xc, wc.cuda(), M, N, K, s_x * s_w, b.cuda(), out)
     assert relerr(out, want) < 2e-6
+
+
+@pytest.mark.parametrize("M,N,K", [(512, 768, 768), (197 * 8, 3072, 768), (1000, 768, 3072), (300, 512, 256)])
+def test_int8_mfma_gemm_is_the_exact_integer_product(ops, M, N, K):
+    """mv_gemm_nt_i8 (v_mfma_i32_16x16x64_i8): int32 accumulation is the exact integer dot product; with A8 = q - 128 and
+    icorr[n] = (128 - z) sum_k w[n][k] the result equals the integer-codes product on the bf16 MFMA (bit for bit after the
+    same scale/bias epilogue) and torch's linear(fake_quantize(x), fake_quantize(W)) + b."""
+    x = torch.randn(M, K, generator=g(1)) * 2 + 0.3
+    w = torch.randn(N, K, generator=g(2)) * K ** -0.5
+    b = torch.randn(N, generator=g(3))
+    s_x = float((x.max() - min(x.min(), 0)) / 255.0)
+    z_x = int(min(max(round(-float(min(x.min(), 0)) / s_x), 0), 255))
+    s_w = float(w.abs().max() / 127.5)
+    xq = torch.fake_quantize_per_tensor_affine(x, s_x, z_x, 0, 255)
+    wq = torch.fake_quantize_per_tensor_affine(w, s_w, 0, -128, 127)
+    want = torch.nn.functional.linear(xq.double(), wq.double(), b.double())
+    x8 = ops.quant_affine_i8(x.cuda(), M, K, s_x, z_x)
+    assert x8.dtype == torch.int8 and x8.shape == (M, (K + 15) & ~15)
+    q = torch.round(xq / s_x) + z_x                                        # the uint8 level
+    assert torch.equal(x8[:, :K].cpu().to(torch.int64), (q - 128).to(torch.int64))
+    wcodes = torch.round(wq / s_w)
+    w8 = torch.zeros(N, (K + 15) & ~15, dtype=torch.int8)
+    w8[:, :K] = wcodes.to(torch.int8)
+    icorr = ((128 - z_x) * wcodes.sum(1).to(torch.int64)).to(torch.int32)
+    out = torch.empty(M, N, device="cuda")
+    ops.linear_i8(x8, w8.cuda(), M, N, K, s_x * s_w, b.cuda(), icorr.cuda(), out)
+    # exact integer reference: (q - z) . w in int64, then the fp32 epilogue fmaf(acc, alpha, bias)
+    acc = (q - z_x).to(torch.int64) @ wcodes.to(torch.int64).t()
+    assert acc.abs().max() < 2 ** 24                                       # so the float conversion is exact
+    ref32 = torch.addcmul(b, acc.float(), torch.tensor(s_x * s_w, dtype=torch.float32))   # one rounding, like fmaf? (checked loosely)
+    assert relerr(out, want) < 2e-6 and relerr(out, ref32.double()) < 1e-6
+    # against the round-1 path (integer codes on the bf16 MFMA): identical bits
+    xc = ops.quant_affine_codes(x.cuda(), M, K, s_x, z_x, 0, 255)
+    wc = torch.zeros(N, (K + 7) & ~7, dtype=torch.bfloat16)
+    wc[:, :K] = wcodes
+    out_codes = torch.empty(M, N, device="cuda")
+    ops.linear_codes(xc, wc.cuda(), M, N, K, s_x * s_w, b.cuda(), out_codes)
+    assert torch.equal(out, out_codes)
+    # fused residual and bf16 output
+    res = torch.randn(M, N, generator=g(4)).cuda()
+    out_r, out_rc = torch.empty(M, N, device="cuda"), torch.empty(M, N, device="cuda")
+    ops.linear_i8(x8, w8.cuda(), M, N, K, s_x * s_w, b.cuda(), icorr.cuda(), out_r, residual=res)
+    ops.linear_codes(xc, wc.cuda(), M, N, K, s_x * s_w, b.cuda(), out_rc, residual=res)
+    assert torch.equal(out_r, out_rc)
+    out_b = torch.empty(M, N, device="cuda", dtype=torch.bfloat16)
+    ops.linear_i8(x8, w8.cuda(), M, N, K, s_x * s_w, b.cuda(), icorr.cuda(), out_b)
+    assert torch.equal(out_b, out.bfloat16())
+    # the GELU pre-op of the int8 quantiser == unfused gelu then quantise
+    assert torch.equal(ops.quant_affine_i8(x.cuda(), M, K, s_x, z_x, pre_gelu=True),
+                       ops.quant_affine_i8(ops.gelu_fwd(x.cuda()), M, K, s_x, z_x))
+
+
+def test_int8_vit_base_dim_matches_torch_fake_quant():
+    """BASELINE config 5 at ViT-B/16 width (dim 768, 12 heads, mlp 3072; depth 2 keeps it short): the converted model on the
+    int8 MFMA == the same model with every Int8Linear replaced by torch's own fake-quant arithmetic
+    linear(fake_quantize_per_tensor_affine(x), fake_quantize(W)) + b (what its grad-mode path computes through the fp32
+    kernels), == the integer-codes path on the bf16 MFMA bit for bit."""
+    from myrtle_vision.models.vit import ViT
+    from myrtle_vision.utils.quantize import Int8Linear
+    from myrtle_vision.utils.utils import seed_everything
+    seed_everything(3)
+    vit = ViT(precision="bf16", q_format="PyTorchINT8", decoder="classification", image_size=224, patch_size=16, num_classes=1000,
+              dim=768, depth=2, heads=12, mlp_dim=3072, dropout=0.0, emb_dropout=0.0).cuda()
+    gen = torch.Generator().manual_seed(4)
+    vit.train()
+    with torch.no_grad():
+        for _ in range(2):
+            vit(torch.randn(8, 3, 224, 224, generator=gen).cuda())
+    vit.convert()
+    vit.eval()
+    img = torch.randn(8, 3, 224, 224, generator=gen).cuda()
+    used = []
+    orig = Int8Linear.forward
+    with torch.no_grad():
+        fast = vit(img)                                                    # int8 MFMA where the shape allows
+        Int8Linear.use_i8 = False
+        try:
+            codes = vit(img)                                               # integer codes on the bf16 MFMA (round 1)
+        finally:
+            Int8Linear.use_i8 = True
+    assert torch.equal(fast, codes)
+    # torch's own fake-quant arithmetic on the CPU for one layer of that model, at its calibrated parameters
+    lin = vit.transformer.layers[0][1].fn.fn.net[0][1]
+    assert isinstance(lin, Int8Linear) and lin.weight_i8 is not None
+    s_x, z_x = lin.act_observer.frozen
+    x = torch.randn(197 * 4, 768, generator=gen)
+    want = torch.nn.functional.linear(torch.fake_quantize_per_tensor_affine(x, s_x, z_x, 0, 255).double(),
+                                      lin.weight.detach().double().cpu(), lin.bias.detach().double().cpu())
+    with torch.no_grad():
+        got = lin(x.cuda())
+    assert relerr(got, want) < 2e-6
+    # grad mode: fp32 fake-quant (straight-through) kernels end to end.  Same arithmetic up to fp32 summation order, but 8-bit
+    # quantisers are discontinuous: an ulp of difference in front of one flips a code (0.4 % of the tensor's range), and at
+    # this width a few of the 3 M activations per layer do (measured 5e-3 of the logits' range)
+    slow = vit(img)
+    assert relerr(fast, slow.detach().double().cpu()) < 2e-2
 
 
 def test_int8_converted_model_fast_path_equals_fake_quant_path():

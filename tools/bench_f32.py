@@ -1,0 +1,45 @@
+#!/usr/bin/env python3
+"""fp32 GEMM microbenchmark: the f32-input MFMA kernel against the FMA kernel on the ViT-B shapes (TFLOP/s), one process."""
+import os, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "myrtle-vision_amd"))
+import torch
+from myrtle_vision.hip import ops
+from myrtle_vision.hip.lib import lib
+
+M = int(os.environ.get("M", 197 * 64))
+
+
+def timeit(fn, iters=5):
+    for _ in range(2): fn()
+    torch.cuda.synchronize()
+    s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    s.record()
+    for _ in range(iters): fn()
+    e.record(); torch.cuda.synchronize()
+    return s.elapsed_time(e) / iters * 1e-3
+
+
+rows = []
+for name, N, K in [("qkv", 2304, 768), ("proj", 768, 768), ("fc1", 3072, 768), ("fc2", 768, 3072)]:
+    x, w, b = torch.randn(M, K, device="cuda"), torch.randn(N, K, device="cuda"), torch.randn(N, device="cuda")
+    dy, out, dx = torch.randn(M, N, device="cuda"), torch.empty(M, N, device="cuda"), torch.empty(M, K, device="cuda")
+    for label, fn in [("fwd", lambda: ops.linear_fwd(x, M, K, w, b, out, N)), ("dx", lambda: ops.linear_dx(dy, M, N, w, dx, K)),
+                      ("dw", lambda: ops.linear_dw(dy, x, M, N, K))]:
+        t = {}
+        for mode in (1, 0):
+            lib().mv_gemm_f32_force_fma(mode)
+            t[mode] = timeit(fn)
+        lib().mv_gemm_f32_force_fma(0)
+        fl = 2.0 * M * N * K
+        rows.append((f"{name} {label}", fl / t[1] / 1e12, fl / t[0] / 1e12))
+B, H, N_, dh = 64, 12, 197, 64
+qkv = torch.randn(B, N_, 3 * H * dh, device="cuda")
+for mode in (1, 0):
+    lib().mv_gemm_f32_force_fma(mode)
+    t = timeit(lambda: ops.attention_probs_fp32(qkv, B, N_, H, dh, 0.125))
+    rows.append((f"attn probs ({'fma' if mode else 'mfma'})", 2.0 * B * H * N_ * N_ * dh / t / 1e12, 0.0))
+lib().mv_gemm_f32_force_fma(0)
+print(f"{'shape (M=%d)' % M:24s} {'FMA':>8s} {'MFMA':>8s}  TFLOP/s")
+for r in rows:
+    print(f"{r[0]:24s} {r[1]:8.1f} {r[2]:8.1f}")
