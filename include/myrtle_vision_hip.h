@@ -114,7 +114,8 @@ int mv_gemm_f32(const float* A, long sa_m, long sa_k, long sa_b1, long sa_b2, co
 int mv_sum_slabs(const float* slabs, long stride, int S, float* out, long n, int accumulate, mv_stream_t stream);
 /* Test / tuning hook (no reference counterpart; the second piece of process-global state next to mv_gemm_force_variant):
  * 1 = mv_gemm_f32 runs its FMA kernel, 0 (default; MV_GEMM_F32=fma in the environment starts with 1) = the f32-input MFMA
- * kernel.  Both compute the same k-ordered fmaf chain per output: results are bit-identical. */
+ * kernels, 2 = matrix cores but only the generic (any stride, any size) kernel.  All compute the same k-ordered fmaf chain
+ * per output: results are bit-identical. */
 int mv_gemm_f32_force_fma(int on);
 
 /* ---- fused multi-head self-attention core -- Attention.forward vit.py:87-96 ----
@@ -127,6 +128,11 @@ int mv_attention_fwd(const void* qkv, void* out, float* lse, int B, int N, int H
  * so no separate pass over dqkv is needed for it. */
 int mv_attention_bwd(const void* qkv, const void* out, const void* dout, const float* lse, void* dqkv, float* colsum,
                      int B, int N, int H, float scale, mv_stream_t stream);
+/* The same attention core in EXACT fp32 arithmetic on the f32-input matrix cores, forward only: qkv fp32 [B, N, 3, H, 64],
+ * out fp32 [B, N, H*64]; N <= 272.  For the paths that need fp32 values and no gradient (converted PyTorchINT8 model,
+ * precision="fp32" evaluation): same products and sums as mv_gemm_f32 + mv_softmax_fwd + mv_gemm_f32 up to summation order,
+ * without the [B, H, N, N] probabilities. */
+int mv_attention_fwd_f32(const float* qkv, float* out, int B, int N, int H, float scale, mv_stream_t stream);
 
 /* ---- row softmax for the materialised attention path (fp32): attn.softmax(dim=-1) vit.py:93 ---- */
 int mv_softmax_fwd(const float* x, float* y, long rows, int cols, float scale, mv_stream_t stream);

@@ -356,6 +356,41 @@ __global__ __launch_bounds__(256) void quant_affine_i8_kernel(const XT* __restri
   }
 }
 
+// flat form (ld == cols: no padding columns): a wave takes 1024 consecutive elements per iteration; lane l reads the four
+// 16-byte groups 4 l + 256 k (coalesced 1 KiB per load instruction) and stores one packed dword per group (256 B per
+// store instruction).  The row-wise kernel above reads 64 B per lane at a 64-byte lane stride: 3.5x off the HBM rate.
+template <int PRE, typename XT>
+__global__ __launch_bounds__(256) void quant_affine_i8_flat_kernel(const XT* __restrict__ x, unsigned* __restrict__ y, long n,
+                                                                   float inv, int zp) {
+  const float fz = (float)zp;
+  const long nchunk = n >> 10;                      // n % 1024 == 0 (dispatch)
+  const int lane = threadIdx.x & 63;
+  for (long ch = (long)blockIdx.x * 4 + (threadIdx.x >> 6); ch < nchunk; ch += (long)gridDim.x * 4) {
+    const XT* xc = x + (ch << 10);
+    float4 v[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      if constexpr (sizeof(XT) == 4) {
+        v[k] = reinterpret_cast<const float4*>(xc)[lane + 64 * k];
+      } else {
+        const bf16x4 hh = reinterpret_cast<const bf16x4*>(xc)[lane + 64 * k];
+        v[k] = make_float4((float)hh[0], (float)hh[1], (float)hh[2], (float)hh[3]);
+      }
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const float e[4] = {v[k].x, v[k].y, v[k].z, v[k].w};
+      unsigned w = 0u;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int code = (int)(affine_code_one<PRE>(e[j], inv, fz, 0.f, 255.f) + fz) - 128;
+        w |= ((unsigned)code & 0xFFu) << (8 * j);
+      }
+      y[(ch << 8) + lane + 64 * k] = w;
+    }
+  }
+}
+
 // order-preserving float <-> uint map so min/max can use integer atomics
 __device__ __forceinline__ unsigned f2ord(float f) {
   const unsigned u = __float_as_uint(f);
@@ -937,6 +972,16 @@ extern "C" int mv_quant_affine_i8(const void* x, int x_dtype, void* codes, long 
   MV_REQUIRE(mv_aligned16(codes), MV_ERR_ALIGN);
   if (rows == 0) return MV_OK;
   const float inv = 1.0f / scale;
+  const long n = rows * (long)cols;
+  if (ld == cols && (n & 1023) == 0 && mv_aligned16(x)) {         // no padding columns: the coalesced flat form
+    const int fgrid = ew_grid(n >> 10, 4);
+#define MV_QI8F(PRE_, T_) quant_affine_i8_flat_kernel<PRE_, T_><<<fgrid, 256, 0, S_>>>((const T_*)x, (unsigned*)codes, n, inv, zero_point)
+    if (x_dtype == MV_F32) { if (pre_op) MV_QI8F(1, float); else MV_QI8F(0, float); }
+    else { if (pre_op) MV_QI8F(1, bf16_t); else MV_QI8F(0, bf16_t); }
+#undef MV_QI8F
+    MV_CHECK_LAUNCH();
+    return MV_OK;
+  }
   const int grid = rows < 4096 ? (int)rows : 4096;
 #define MV_QI8(PRE_, T_) quant_affine_i8_kernel<PRE_, T_><<<grid, 256, 0, S_>>>((const T_*)x, (int8_t*)codes, rows, cols, ld, inv, zero_point)
   if (x_dtype == MV_F32) { if (pre_op) MV_QI8(1, float); else MV_QI8(0, float); }

@@ -120,89 +120,11 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(F32Args a) {
 //   row: float4 epilogue accesses when C is row-major.
 //   Staging is register double-buffered (global loads of step t+1 in flight under the MFMAs of step t, one barrier per
 //   step) with the same stride-adaptive thread map as the FMA kernel: consecutive lanes walk the operand's unit-stride axis.
+// shared epilogue of the two MFMA kernels
 template <int EPI, int WT>
-__global__ __launch_bounds__(256) void gemm_f32_mfma_kernel(F32Args a) {
-  constexpr int TB = 32 * WT;              // block tile edge
-  constexpr int LDK = 20;                  // floats per LDS row (16 + 4 pad; keeps 16-byte alignment of the b128 reads)
-  constexpr int PER = TB * 16 / 256;       // staged elements per thread and operand
-  __shared__ __attribute__((aligned(16))) float As[2][TB * LDK];
-  __shared__ __attribute__((aligned(16))) float Bs[2][TB * LDK];
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int wr = wave >> 1, wc = wave & 1;
-  const int b1 = blockIdx.z / a.nb2, b2 = blockIdx.z % a.nb2;
-  const float* A = a.A + b1 * a.sa_b1 + b2 * a.sa_b2;
-  const float* B = a.B + b1 * a.sb_b1 + b2 * a.sb_b2;
-  float* C = a.C + b1 * a.sc_b1 + b2 * a.sc_b2;
-  const int m0 = blockIdx.y * TB, n0 = blockIdx.x * TB;
-  const bool a_kfast = (a.sa_k == 1), b_kfast = (a.sb_k == 1);
-
-  // staging map: element e (0 .. PER-1) of this thread is tile position (idx0 + e di, k0 + e dk) -- consecutive lanes walk
-  // the operand's unit-stride axis; the per-element step is wave-uniform, so one base pointer per operand is enough
-  const int ai0 = a_kfast ? (tid >> 4) : (tid % TB), ak0 = a_kfast ? (tid & 15) : (tid / TB);
-  const int bi0 = b_kfast ? (tid >> 4) : (tid % TB), bk0 = b_kfast ? (tid & 15) : (tid / TB);
-  const int adi = a_kfast ? 16 : 0, adk = a_kfast ? 0 : 256 / TB, bdi = b_kfast ? 16 : 0, bdk = b_kfast ? 0 : 256 / TB;
-  const float* const pa = A + (long)(m0 + ai0) * a.sa_m + (long)ak0 * a.sa_k;
-  const float* const pb = B + (long)(n0 + bi0) * a.sb_n + (long)bk0 * a.sb_k;
-  const long astep = (long)adi * a.sa_m + (long)adk * a.sa_k, bstep = (long)bdi * a.sb_n + (long)bdk * a.sb_k;
-  // Loads are unconditional from clamped addresses; the zero-fill select happens at STORE time, after the MFMAs of the
-  // current step -- selecting right after the load would make the compiler wait for the data before the MFMA block and
-  // expose a full memory latency per step (seen in the first version's ISA: vmcnt(0) in front of the MFMAs).
-  float ra[PER], rb[PER];
-  unsigned oka = 0, okb = 0;                 // bit e: element e is inside the operand
-  auto load_tile = [&](int k0) {
-    oka = okb = 0;
-#pragma unroll
-    for (int e = 0; e < PER; ++e) {
-      const bool ok = (m0 + ai0 + e * adi) < a.M && (k0 + ak0 + e * adk) < a.K;
-      ra[e] = *(ok ? pa + e * astep + (long)k0 * a.sa_k : A);
-      oka |= (ok ? 1u : 0u) << e;
-      const bool ob = (n0 + bi0 + e * bdi) < a.N && (k0 + bk0 + e * bdk) < a.K;
-      rb[e] = *(ob ? pb + e * bstep + (long)k0 * a.sb_k : B);
-      okb |= (ob ? 1u : 0u) << e;
-    }
-  };
-  auto store_tile = [&](int buf) {
-#pragma unroll
-    for (int e = 0; e < PER; ++e) {
-      const int ka = ak0 + e * adk, kb = bk0 + e * bdk;
-      As[buf][(ai0 + e * adi) * LDK + (ka & 3) * 4 + (ka >> 2)] = ((oka >> e) & 1u) ? ra[e] : 0.f;
-      Bs[buf][(bi0 + e * bdi) * LDK + (kb & 3) * 4 + (kb >> 2)] = ((okb >> e) & 1u) ? rb[e] : 0.f;
-    }
-  };
-
-  f32x4 acc[WT][WT];
-#pragma unroll
-  for (int i = 0; i < WT; ++i)
-#pragma unroll
-    for (int j = 0; j < WT; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
-
-  const int nk = (a.K + 15) >> 4;
-  const int frag = (lane & 15) * LDK + (lane >> 4) * 4;
-  if (nk > 0) {
-    load_tile(0);
-    store_tile(0);
-  }
-  __syncthreads();
-  for (int kt = 0; kt < nk; ++kt) {
-    const int cur = kt & 1;
-    if (kt + 1 < nk) load_tile((kt + 1) << 4);
-    f32x4 af[WT], bf[WT];
-#pragma unroll
-    for (int i = 0; i < WT; ++i) {
-      af[i] = *reinterpret_cast<const f32x4*>(&As[cur][(wr * WT + i) * 16 * LDK + frag]);
-      bf[i] = *reinterpret_cast<const f32x4*>(&Bs[cur][(wc * WT + i) * 16 * LDK + frag]);
-    }
-#pragma unroll
-    for (int kk = 0; kk < 4; ++kk)
-#pragma unroll
-      for (int i = 0; i < WT; ++i)
-#pragma unroll
-        for (int j = 0; j < WT; ++j)
-          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(bf[j][kk], af[i][kk], acc[i][j], 0, 0, 0);
-    if (kt + 1 < nk) store_tile(cur ^ 1);
-    __syncthreads();
-  }
-
+__device__ __forceinline__ void f32_mfma_epilogue(const F32Args& a, float* C, f32x4 (&acc)[WT][WT], int m0, int n0, int wr, int wc,
+                                                  int lane) {
+  constexpr int TB = 32 * WT;
   // epilogue: lane holds, per 16x16 block (i, j), row m = .. + (lane & 15) and columns n = .. + 4 (lane >> 4) + 0..3
   const bool vec = a.sc_n == 1 && (a.sc_m & 3) == 0 && (reinterpret_cast<uintptr_t>(C) & 15) == 0 && !a.accumulate;
   // interior blocks of row-major outputs: branch-free, every bias / aux vector loaded before the first store (a
@@ -302,6 +224,230 @@ __global__ __launch_bounds__(256) void gemm_f32_mfma_kernel(F32Args a) {
   }
 }
 
+template <int EPI, int WT>
+__global__ __launch_bounds__(256) void gemm_f32_mfma_kernel(F32Args a) {
+  constexpr int TB = 32 * WT;              // block tile edge
+  constexpr int LDK = 20;                  // floats per LDS row (16 + 4 pad; keeps 16-byte alignment of the b128 reads)
+  constexpr int PER = TB * 16 / 256;       // staged elements per thread and operand
+  __shared__ __attribute__((aligned(16))) float As[2][TB * LDK];
+  __shared__ __attribute__((aligned(16))) float Bs[2][TB * LDK];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wr = wave >> 1, wc = wave & 1;
+  const int b1 = blockIdx.z / a.nb2, b2 = blockIdx.z % a.nb2;
+  const float* A = a.A + b1 * a.sa_b1 + b2 * a.sa_b2;
+  const float* B = a.B + b1 * a.sb_b1 + b2 * a.sb_b2;
+  float* C = a.C + b1 * a.sc_b1 + b2 * a.sc_b2;
+  const int m0 = blockIdx.y * TB, n0 = blockIdx.x * TB;
+  const bool a_kfast = (a.sa_k == 1), b_kfast = (a.sb_k == 1);
+
+  // staging map: element e (0 .. PER-1) of this thread is tile position (idx0 + e di, k0 + e dk) -- consecutive lanes walk
+  // the operand's unit-stride axis; the per-element step is wave-uniform, so one base pointer per operand is enough
+  const int ai0 = a_kfast ? (tid >> 4) : (tid % TB), ak0 = a_kfast ? (tid & 15) : (tid / TB);
+  const int bi0 = b_kfast ? (tid >> 4) : (tid % TB), bk0 = b_kfast ? (tid & 15) : (tid / TB);
+  const int adi = a_kfast ? 16 : 0, adk = a_kfast ? 0 : 256 / TB, bdi = b_kfast ? 16 : 0, bdk = b_kfast ? 0 : 256 / TB;
+  const float* const pa = A + (long)(m0 + ai0) * a.sa_m + (long)ak0 * a.sa_k;
+  const float* const pb = B + (long)(n0 + bi0) * a.sb_n + (long)bk0 * a.sb_k;
+  const long astep = (long)adi * a.sa_m + (long)adk * a.sa_k, bstep = (long)bdi * a.sb_n + (long)bdk * a.sb_k;
+  // Loads are unconditional from clamped addresses; the zero-fill select happens at STORE time, after the MFMAs of the
+  // current step -- selecting right after the load would make the compiler wait for the data before the MFMA block and
+  // expose a full memory latency per step (seen in the first version's ISA: vmcnt(0) in front of the MFMAs).
+  float ra[PER], rb[PER];
+  unsigned oka = 0, okb = 0;                 // bit e: element e is inside the operand
+  auto load_tile = [&](int k0) {
+    oka = okb = 0;
+#pragma unroll
+    for (int e = 0; e < PER; ++e) {
+      const bool ok = (m0 + ai0 + e * adi) < a.M && (k0 + ak0 + e * adk) < a.K;
+      ra[e] = *(ok ? pa + e * astep + (long)k0 * a.sa_k : A);
+      oka |= (ok ? 1u : 0u) << e;
+      const bool ob = (n0 + bi0 + e * bdi) < a.N && (k0 + bk0 + e * bdk) < a.K;
+      rb[e] = *(ob ? pb + e * bstep + (long)k0 * a.sb_k : B);
+      okb |= (ob ? 1u : 0u) << e;
+    }
+  };
+  auto store_tile = [&](int buf) {
+#pragma unroll
+    for (int e = 0; e < PER; ++e) {
+      const int ka = ak0 + e * adk, kb = bk0 + e * bdk;
+      As[buf][(ai0 + e * adi) * LDK + (ka & 3) * 4 + (ka >> 2)] = ((oka >> e) & 1u) ? ra[e] : 0.f;
+      Bs[buf][(bi0 + e * bdi) * LDK + (kb & 3) * 4 + (kb >> 2)] = ((okb >> e) & 1u) ? rb[e] : 0.f;
+    }
+  };
+
+  f32x4 acc[WT][WT];
+#pragma unroll
+  for (int i = 0; i < WT; ++i)
+#pragma unroll
+    for (int j = 0; j < WT; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  const int nk = (a.K + 15) >> 4;
+  const int frag = (lane & 15) * LDK + (lane >> 4) * 4;
+  if (nk > 0) {
+    load_tile(0);
+    store_tile(0);
+  }
+  __syncthreads();
+  for (int kt = 0; kt < nk; ++kt) {
+    const int cur = kt & 1;
+    if (kt + 1 < nk) load_tile((kt + 1) << 4);
+    f32x4 af[WT], bf[WT];
+#pragma unroll
+    for (int i = 0; i < WT; ++i) {
+      af[i] = *reinterpret_cast<const f32x4*>(&As[cur][(wr * WT + i) * 16 * LDK + frag]);
+      bf[i] = *reinterpret_cast<const f32x4*>(&Bs[cur][(wc * WT + i) * 16 * LDK + frag]);
+    }
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk)
+#pragma unroll
+      for (int i = 0; i < WT; ++i)
+#pragma unroll
+        for (int j = 0; j < WT; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(bf[j][kk], af[i][kk], acc[i][j], 0, 0, 0);
+    if (kt + 1 < nk) store_tile(cur ^ 1);
+    __syncthreads();
+  }
+
+  f32_mfma_epilogue<EPI, WT>(a, C, acc, m0, n0, wr, wc, lane);
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// Fast form of the MFMA kernel for the three nn.Linear products at their usual alignment (what the generic kernel's ISA
+// showed: ~700 address / select / branch instructions per wave and K-step around 64 MFMAs, 32 scalar loads per thread):
+//   * the unit-stride axis of each operand is a template parameter (AK / BK: true = K is contiguous, false = the M / N index
+//     is), so the staging map and all strides are compile-time shapes;
+//   * global loads are 16 bytes: 2 + 2 per thread and K-step instead of 16 + 16; rows past the end are CLAMPED to the last
+//     valid row (their products only reach outputs that are never stored), so there are no bounds selects in the loop;
+//   * requirements checked by the dispatcher: K % 16 == 0, 16-byte aligned operands and leading dimensions % 4 == 0, and
+//     M % 4 == 0 / N % 4 == 0 for an operand read along its row index.
+// Same LDS image, fragments, MFMA order (k ascending) and epilogue as gemm_f32_mfma_kernel<EPI, 4>: identical bits.
+template <int EPI, bool AK, bool BKF>
+__global__ __launch_bounds__(256, 2) void gemm_f32_mfma_fast_kernel(F32Args a) {
+  // LDS image per operand.  K-contiguous: [idx][g][kk] with k = 4 kk + g, rows of LDK = 20 floats (ds_read_b128 fragments,
+  // as gemm_f32_mfma_kernel).  Index-contiguous: k-major [16 k][LDI = 144] -- the thread's four consecutive rows of one k go
+  // out as ONE ds_write_b128 (written row by row into the [idx][..] image they were a 16-way bank conflict: all lanes of a
+  // wave 80 floats apart), fragments are four conflict-free ds_read_b32 (lane groups g = 0..3 read k rows 144 floats = 16
+  // banks apart).
+  constexpr int WT = 4, TB = 128, LDK = 20, LDI = 144;
+  constexpr int A_SZ = AK ? TB * LDK : 16 * LDI, B_SZ = BKF ? TB * LDK : 16 * LDI;
+  __shared__ __attribute__((aligned(16))) float As[2][A_SZ];
+  __shared__ __attribute__((aligned(16))) float Bs[2][B_SZ];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wr = wave >> 1, wc = wave & 1;
+  const int b1 = blockIdx.z / a.nb2, b2 = blockIdx.z % a.nb2;
+  const float* A = a.A + b1 * a.sa_b1 + b2 * a.sa_b2;
+  const float* B = a.B + b1 * a.sb_b1 + b2 * a.sb_b2;
+  float* C = a.C + b1 * a.sc_b1 + b2 * a.sc_b2;
+  const int m0 = blockIdx.y * TB, n0 = blockIdx.x * TB;
+
+  // K-contiguous operand: thread -> (row (tid >> 2) + 64 e, 16-byte chunk tid & 3 of the 16 k); index-contiguous operand:
+  // thread -> (k (tid >> 5) + 8 e, rows 4 (tid & 31) .. + 3).  One base pointer per element e, advanced by 16 k per step.
+  const float* pa[2];
+  const float* pb[2];
+  long a_adv, b_adv;
+  if constexpr (AK) {
+#pragma unroll
+    for (int e = 0; e < 2; ++e) {
+      int r = m0 + (tid >> 2) + 64 * e;
+      r = r < a.M ? r : a.M - 1;
+      pa[e] = A + (long)r * a.sa_m + 4 * (tid & 3);
+    }
+    a_adv = 16;
+  } else {
+    int r = m0 + 4 * (tid & 31);
+    r = r + 3 < a.M ? r : a.M - 4;
+#pragma unroll
+    for (int e = 0; e < 2; ++e) pa[e] = A + (long)((tid >> 5) + 8 * e) * a.sa_k + r;
+    a_adv = 16 * a.sa_k;
+  }
+  if constexpr (BKF) {
+#pragma unroll
+    for (int e = 0; e < 2; ++e) {
+      int r = n0 + (tid >> 2) + 64 * e;
+      r = r < a.N ? r : a.N - 1;
+      pb[e] = B + (long)r * a.sb_n + 4 * (tid & 3);
+    }
+    b_adv = 16;
+  } else {
+    int r = n0 + 4 * (tid & 31);
+    r = r + 3 < a.N ? r : a.N - 4;
+#pragma unroll
+    for (int e = 0; e < 2; ++e) pb[e] = B + (long)((tid >> 5) + 8 * e) * a.sb_k + r;
+    b_adv = 16 * a.sb_k;
+  }
+  f32x4 ra[2], rb[2];
+  auto load_tile = [&]() {
+#pragma unroll
+    for (int e = 0; e < 2; ++e) {
+      ra[e] = *reinterpret_cast<const f32x4*>(pa[e]);
+      rb[e] = *reinterpret_cast<const f32x4*>(pb[e]);
+      pa[e] += a_adv;
+      pb[e] += b_adv;
+    }
+  };
+  // LDS image [idx][g][kk] with k = 4 kk + g (see gemm_f32_mfma_kernel)
+  auto store_tile = [&](int buf) {
+#pragma unroll
+    for (int e = 0; e < 2; ++e) {
+      if constexpr (AK) {
+        float* d = &As[buf][((tid >> 2) + 64 * e) * LDK + (tid & 3)];          // k = 4 c + j  ->  g = j, kk = c
+#pragma unroll
+        for (int j = 0; j < 4; ++j) d[4 * j] = ra[e][j];
+      } else {
+        *reinterpret_cast<f32x4*>(&As[buf][((tid >> 5) + 8 * e) * LDI + 4 * (tid & 31)]) = ra[e];
+      }
+      if constexpr (BKF) {
+        float* d = &Bs[buf][((tid >> 2) + 64 * e) * LDK + (tid & 3)];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) d[4 * j] = rb[e][j];
+      } else {
+        *reinterpret_cast<f32x4*>(&Bs[buf][((tid >> 5) + 8 * e) * LDI + 4 * (tid & 31)]) = rb[e];
+      }
+    }
+  };
+
+  f32x4 acc[WT][WT];
+#pragma unroll
+  for (int i = 0; i < WT; ++i)
+#pragma unroll
+    for (int j = 0; j < WT; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  const int nk = a.K >> 4;
+  const int frag = (lane & 15) * LDK + (lane >> 4) * 4;
+  load_tile();
+  store_tile(0);
+  __syncthreads();
+  for (int kt = 0; kt < nk; ++kt) {
+    const int cur = kt & 1;
+    if (kt + 1 < nk) load_tile();
+    f32x4 af[WT], bf[WT];
+#pragma unroll
+    for (int i = 0; i < WT; ++i) {
+      if constexpr (AK) {
+        af[i] = *reinterpret_cast<const f32x4*>(&As[cur][(wr * WT + i) * 16 * LDK + frag]);
+      } else {
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) af[i][kk] = As[cur][(4 * kk + (lane >> 4)) * LDI + (wr * WT + i) * 16 + (lane & 15)];
+      }
+      if constexpr (BKF) {
+        bf[i] = *reinterpret_cast<const f32x4*>(&Bs[cur][(wc * WT + i) * 16 * LDK + frag]);
+      } else {
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) bf[i][kk] = Bs[cur][(4 * kk + (lane >> 4)) * LDI + (wc * WT + i) * 16 + (lane & 15)];
+      }
+    }
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk)
+#pragma unroll
+      for (int i = 0; i < WT; ++i)
+#pragma unroll
+        for (int j = 0; j < WT; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(bf[j][kk], af[i][kk], acc[i][j], 0, 0, 0);
+    if (kt + 1 < nk) store_tile(cur ^ 1);
+    __syncthreads();
+  }
+  f32_mfma_epilogue<EPI, WT>(a, C, acc, m0, n0, wr, wc, lane);
+}
+
 // one wave per row; row kept in registers when cols <= 64*VPL, else re-read (cols here: 197..257)
 __global__ __launch_bounds__(256) void softmax_fwd_kernel(const float* __restrict__ x, float* __restrict__ y, long rows,
                                                           int cols, float scale) {
@@ -336,11 +482,14 @@ __global__ __launch_bounds__(256) void softmax_bwd_kernel(const float* __restric
 
 // test / tuning hook: 1 = FMA kernel, 0 = matrix cores (initialised from MV_GEMM_F32=fma)
 std::atomic<int> g_f32_fma{getenv("MV_GEMM_F32") && !strcmp(getenv("MV_GEMM_F32"), "fma") ? 1 : 0};
+// 2 (mv_gemm_f32_force_fma(2)): matrix cores, but only the generic kernel (A/B of the fast form)
+std::atomic<int> g_f32_generic{0};
 
 }  // namespace
 
 extern "C" int mv_gemm_f32_force_fma(int on) {
-  g_f32_fma.store(on ? 1 : 0, std::memory_order_relaxed);
+  g_f32_fma.store(on == 1 ? 1 : 0, std::memory_order_relaxed);
+  g_f32_generic.store(on == 2 ? 1 : 0, std::memory_order_relaxed);
   return MV_OK;
 }
 
@@ -360,6 +509,38 @@ extern "C" int mv_gemm_f32(const float* A, long sa_m, long sa_k, long sa_b1, lon
   if (!g_f32_fma.load(std::memory_order_relaxed)) {
     const long pad128 = (long)mv_cdiv(M, 128) * 128 * mv_cdiv(N, 128) * 128, pad64 = (long)mv_cdiv(M, 64) * 64 * mv_cdiv(N, 64) * 64;
     const bool big = pad128 * 10 <= pad64 * 11;             // at most 10 % more padded work than the 64-tiles need
+    // fast form: K % 16 == 0, one unit stride per operand, everything 16-byte addressable
+    const bool ak = sa_k == 1, am = sa_m == 1, bk = sb_k == 1, bn = sb_n == 1;
+    auto al4 = [](long v) { return (v & 3) == 0; };
+    const bool fast = big && K >= 16 && K % 16 == 0 && M >= 4 && N >= 4 && (ak || am) && (bk || bn) && mv_aligned16(A) &&
+                      mv_aligned16(B) && al4(sa_b1) && al4(sa_b2) && al4(sb_b1) && al4(sb_b2) &&
+                      (ak ? al4(sa_m) : (al4(sa_k) && M % 4 == 0)) && (bk ? al4(sb_n) : (al4(sb_k) && N % 4 == 0)) &&
+                      !g_f32_generic.load(std::memory_order_relaxed);
+    if (fast) {
+      const dim3 fgrid(mv_cdiv(N, 128), mv_cdiv(M, 128), nb1 * nb2);
+#define MV_F32_FAST(E)                                                                     \
+      if (ak && bk) gemm_f32_mfma_fast_kernel<E, true, true><<<fgrid, 256, 0, s>>>(a);     \
+      else if (ak) gemm_f32_mfma_fast_kernel<E, true, false><<<fgrid, 256, 0, s>>>(a);     \
+      else if (bk) gemm_f32_mfma_fast_kernel<E, false, true><<<fgrid, 256, 0, s>>>(a);     \
+      else gemm_f32_mfma_fast_kernel<E, false, false><<<fgrid, 256, 0, s>>>(a);
+      switch (epilogue) {
+        case MV_EPI_NONE: MV_F32_FAST(MV_EPI_NONE) break;
+        case MV_EPI_GELU: MV_F32_FAST(MV_EPI_GELU) break;
+        case MV_EPI_RESIDUAL:
+          MV_REQUIRE(aux, MV_ERR_UNSUPPORTED);
+          MV_F32_FAST(MV_EPI_RESIDUAL) break;
+        case MV_EPI_DGELU:
+          MV_REQUIRE(aux, MV_ERR_UNSUPPORTED);
+          MV_F32_FAST(MV_EPI_DGELU) break;
+        case MV_EPI_EMBED:
+          MV_REQUIRE(aux && aux_i > 0, MV_ERR_UNSUPPORTED);
+          MV_F32_FAST(MV_EPI_EMBED) break;
+        default: return MV_ERR_UNSUPPORTED;
+      }
+#undef MV_F32_FAST
+      MV_CHECK_LAUNCH();
+      return MV_OK;
+    }
 #define MV_F32_LAUNCH(E)                                                                                    \
     if (big) gemm_f32_mfma_kernel<E, 4><<<dim3(mv_cdiv(N, 128), mv_cdiv(M, 128), nb1 * nb2), 256, 0, s>>>(a); \
     else gemm_f32_mfma_kernel<E, 2><<<dim3(mv_cdiv(N, 64), mv_cdiv(M, 64), nb1 * nb2), 256, 0, s>>>(a);

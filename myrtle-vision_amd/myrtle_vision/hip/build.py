@@ -15,7 +15,8 @@ CSRC = os.path.join(PKG_ROOT, "csrc")
 LIB_DIR = os.path.join(PKG_ROOT, "lib")
 LIB_PATH = os.environ.get("MV_LIB_PATH") or os.path.join(LIB_DIR, "libmyrtle_vision_hip.so")   # MV_LIB_PATH: diagnostic builds
 INCLUDE = os.path.join(os.path.dirname(PKG_ROOT), "include")
-SOURCES = ["layernorm.hip", "gemm_bf16.hip", "gemm_f32.hip", "attention.hip", "elementwise.hip", "seg_tail.hip", "image_prep.hip"]
+SOURCES = ["layernorm.hip", "gemm_bf16.hip", "gemm_f32.hip", "attention.hip", "attention_f32.hip", "elementwise.hip", "seg_tail.hip",
+           "image_prep.hip"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-fPIC", "-std=c++17", "-Wall", "-Wno-unused-function"]
 
 
@@ -83,7 +84,7 @@ def build(force: bool = False, verbose: bool = True) -> str:
             sys.stderr.write(r.stderr)
         return obj
 
-    with ThreadPoolExecutor(max_workers=min(7, os.cpu_count() or 1)) as ex:
+    with ThreadPoolExecutor(max_workers=min(8, os.cpu_count() or 1)) as ex:
         objs = list(ex.map(compile_one, SOURCES))
     r = subprocess.run(_link_command(hipcc, objs), capture_output=True, text=True)
     if r.returncode != 0:

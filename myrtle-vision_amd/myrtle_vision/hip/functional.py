@@ -282,6 +282,10 @@ def attention_core(qkv, heads, scale, probs_hook=None):
     dh = three_d // (3 * heads)
     if probs_hook is None and ops.attention_fused_supported(qkv.dtype, N, dh):
         return _AttentionFused.apply(qkv, heads, scale)
+    if (probs_hook is None and ops.attention_f32_fused_supported(qkv.dtype, N, dh)
+            and not (torch.is_grad_enabled() and qkv.requires_grad)):
+        # no gradient wanted (converted int8 model, fp32 evaluation): exact fp32 arithmetic without the probabilities
+        return ops.attention_fwd_f32(_c(qkv), B, N, heads, scale)
     src_dtype = qkv.dtype
     q32 = cast(qkv, torch.float32)
     probs = _AttentionProbs.apply(q32, heads, scale)
@@ -411,6 +415,9 @@ class _AttnBlock(Function):
         if ops.attention_fused_supported(adt, T, dh):
             o, lse = ops.attention_fwd(qkv, B, T, heads, scale)
             probs = None
+        elif ops.attention_f32_fused_supported(adt, T, dh) and not any(ctx.needs_input_grad):
+            # fp32 evaluation: nothing will run backward, so the probabilities need not exist
+            o, lse, probs = ops.attention_fwd_f32(qkv, B, T, heads, scale), None, None
         else:                                   # materialised fp32 probabilities (fp32 mode, or shapes the fused kernel lacks)
             q32 = ops.cast(qkv, torch.float32)
             probs = ops.attention_probs_fp32(q32, B, T, heads, dh, scale)
@@ -418,6 +425,8 @@ class _AttnBlock(Function):
             lse = None
         out = torch.empty_like(x)
         ops.linear_fwd(o.view(M, inner), M, inner, wo, bo, out, D, epi=EPI_RESIDUAL, aux=x, ld_aux=D)
+        if lse is None and probs is None:        # evaluation-only path above
+            probs = x.new_empty(0)
         ctx.save_for_backward(x, g, mean, rstd, y, qkv, o, lse if lse is not None else probs, wqkv, wo)
         ctx.cfg = (heads, scale, lse is not None)
         ctx.small = (b, bqkv, bo)

@@ -37,6 +37,7 @@ SIGNATURES = {
     "mv_sum_slabs": ("pli" "pli" "p", _I),
     "mv_attention_fwd": ("ppp" "iii" "f" "p", _I),
     "mv_attention_bwd": ("pppppp" "iii" "f" "p", _I),
+    "mv_attention_fwd_f32": ("pp" "iii" "f" "p", _I),
     "mv_softmax_fwd": ("pp" "li" "f" "p", _I),
     "mv_softmax_bwd": ("ppp" "li" "f" "p", _I),
     "mv_patchify": ("ppi" "iiiii" "p", _I),

@@ -390,6 +390,18 @@ def attention_bwd(qkv, out, dout, lse, B, N, H, scale, colsum=None):
     return dqkv
 
 
+def attention_f32_fused_supported(qkv_dtype, N, dim_head):
+    return qkv_dtype == torch.float32 and dim_head == 64 and N <= 272
+
+
+def attention_fwd_f32(qkv, B, N, H, scale):
+    """Exact fp32 attention core, forward only (no probabilities kept): qkv fp32 [B, N, 3*H*64] -> out fp32 [B, N, H*64]."""
+    require_cuda(qkv)
+    out = torch.empty(B, N, H * 64, dtype=torch.float32, device=qkv.device)
+    check(lib().mv_attention_fwd_f32(_p(qkv), _p(out), B, N, H, scale, _s()), "attention_fwd_f32", B=B, N=N, H=H)
+    return out
+
+
 def attention_probs_fp32(qkv, B, N, H, dh, scale):
     """Materialised path (fp32): probs[B, H, N, N] = softmax(q k^T * scale).  qkv fp32 [B, N, 3, H, dh]."""
     D = H * dh

@@ -321,7 +321,8 @@ def test_gemm_f32_linear_forms(ops):
     assert relerr(db, dy.double().sum(0)) < 2e-6
 
 
-@pytest.mark.parametrize("M,N,K", [(333, 77, 130), (1024, 768, 768), (197, 197, 64), (197, 64, 197), (130, 260, 19)])
+@pytest.mark.parametrize("M,N,K", [(333, 77, 130), (1024, 768, 768), (1576, 3072, 768), (1000, 768, 3072), (197, 197, 64),
+                                   (197, 64, 197), (130, 260, 19), (516, 388, 48)])
 def test_gemm_f32_mfma_is_bitwise_the_fma_chain(ops, M, N, K):
     """The f32-input MFMA kernel (v_mfma_f32_16x16x4_f32) computes, per output, the same k-ordered fmaf chain as the FMA
     kernel: every Linear form (forward / dX / dW: three stride patterns), the batched attention products and the fused
@@ -342,17 +343,20 @@ def test_gemm_f32_mfma_is_bitwise_the_fma_chain(ops, M, N, K):
         dw, db = ops.linear_dw(dy, x, M, N, K); outs += [dw, db]
         return outs
 
-    lib().mv_gemm_f32_force_fma(1)
     try:
+        lib().mv_gemm_f32_force_fma(1)
         fma = run_all()
+        lib().mv_gemm_f32_force_fma(2)               # matrix cores, generic kernel only
+        generic = run_all()
     finally:
         lib().mv_gemm_f32_force_fma(0)
-    mfma = run_all()
-    for i, (a, c) in enumerate(zip(fma, mfma)):
-        assert torch.equal(a, c), i
-    assert relerr(mfma[0], x.double().cpu() @ w.double().cpu().t() + b.double().cpu()) < 2e-6
-    assert relerr(mfma[4], dy.double().cpu() @ w.double().cpu()) < 2e-6
-    assert relerr(mfma[6], dy.double().cpu().t() @ x.double().cpu()) < 2e-6
+    mfma = run_all()                                 # matrix cores, fast kernel where the shape allows
+    for i, (a, c, d) in enumerate(zip(fma, mfma, generic)):
+        assert torch.equal(a, c) and torch.equal(a, d), i
+    tol = 2e-6 if max(M, N, K) <= 1024 else 6e-6        # a chain of K fp32 roundings (3.5e-7 sum|ab| at K = 4096)
+    assert relerr(mfma[0], x.double().cpu() @ w.double().cpu().t() + b.double().cpu()) < tol
+    assert relerr(mfma[4], dy.double().cpu() @ w.double().cpu()) < tol
+    assert relerr(mfma[6], dy.double().cpu().t() @ x.double().cpu()) < tol
 
 
 def test_attention_materialised_fp32_mfma_equals_fma(ops):
@@ -424,6 +428,42 @@ def test_attention_materialised_fp32(ops, B, N, H, dh):
     assert relerr(out, want) < 5e-6
     dqkv = ops.attention_bwd_fp32(probs, qkv.cuda(), dout.cuda(), B, N, H, dh, scale)
     assert relerr(dqkv, ref_in.grad) < 2e-5
+
+
+@pytest.mark.parametrize("B,N,H", [(2, 197, 3), (1, 257, 2), (3, 50, 1), (1, 17, 12), (2, 208, 2), (1, 272, 1)])
+def test_attention_fused_fp32_forward(ops, B, N, H):
+    """mv_attention_fwd_f32 (exact fp32 arithmetic on the f32 MFMA, no probabilities kept) against fp64 and against the
+    materialised fp32 path it replaces under no_grad: same products, only the summation order differs."""
+    scale = 64 ** -0.5
+    qkv = torch.randn(B, N, 3 * H * 64, generator=g(1)) * 1.5
+    want, _ = attn_ref(qkv, H, scale)
+    out = ops.attention_fwd_f32(qkv.cuda(), B, N, H, scale)
+    assert out.shape == (B, N, H * 64) and out.dtype == torch.float32
+    assert relerr(out, want) < 2e-6
+    probs = ops.attention_probs_fp32(qkv.cuda(), B, N, H, 64, scale)
+    mat = ops.attention_pv_fp32(probs, qkv.cuda(), B, N, H, 64)
+    assert relerr(out, mat.double().cpu()) < 2e-6
+    # a spiked score (softmax max far above the rest) and a second launch (deterministic)
+    qkv2 = qkv.clone()
+    qkv2[0, 3, :64] *= 30.0
+    want2, _ = attn_ref(qkv2, H, scale)
+    out2 = ops.attention_fwd_f32(qkv2.cuda(), B, N, H, scale)
+    # (scores of ~ +-300 here: one fp32 ulp of the score is 3e-5 absolute in the exponent)
+    assert relerr(out2, want2) < 5e-5 and torch.equal(out2, ops.attention_fwd_f32(qkv2.cuda(), B, N, H, scale))
+
+
+def test_attention_core_dispatch_fp32(ops):
+    """attention_core: fp32 input without gradient -> the fused fp32 kernel; with gradient -> the materialised path (its
+    backward needs the probabilities); a hook on attn_output always materialises."""
+    from myrtle_vision.hip import functional as F
+    qkv = torch.randn(2, 197, 3 * 2 * 64, generator=g(1)).cuda()
+    with torch.no_grad():
+        a = F.attention_core(qkv, 2, 0.125, None)
+    b = F.attention_core(qkv.clone().requires_grad_(True), 2, 0.125, None)
+    seen = []
+    c = F.attention_core(qkv, 2, 0.125, lambda p: (seen.append(p.shape), p)[1])
+    assert b.requires_grad and not a.requires_grad and seen == [(2, 2, 197, 197)]
+    assert relerr(a, b.detach().double().cpu()) < 2e-6 and torch.equal(b.detach(), c)
 
 
 # ---------------------------------------------------------------- elementwise / layout

@@ -85,8 +85,15 @@ def check_case(name, precision, tol_logits, tol_grad, q_format=None):
         want = arrays["logits_sub"]
         report(f"{tag} logits", rel(lg[:, :, ::7, ::7].numpy(), want))
         assert rel(lg[:, :, ::7, ::7].numpy(), want) < tol_logits
-        if precision == "fp32":
-            assert (lg.argmax(1)[:, ::7, ::7].numpy() == arrays["argmax_sub"]).all()
+        am = lg.argmax(1)[:, ::7, ::7].numpy()
+        if precision == "fp32" and q_format is None:
+            assert (am == arrays["argmax_sub"]).all()                          # bit-exact class indices
+        else:
+            # a fake-quantiser is discontinuous (fp32-ulp differences flip ~1e-3 of its roundings): class indices are
+            # compared wherever the reference's own top-2 margin exceeds the logit tolerance
+            top2 = np.sort(want, axis=1)[:, -2:]
+            margin_ok = (top2[:, 1] - top2[:, 0]) > 2 * tol_logits * np.abs(want).max()
+            assert margin_ok.mean() > 0.5 and (am == arrays["argmax_sub"])[margin_ok].all()
         s_got, s_want = summarize(lg).numpy(), arrays["logits_summary"]
         idx = slice(0, 4) if precision == "fp32" else slice(1, 3)     # bf16: norms only (correlated rounding, see below)
         assert np.abs(s_got[idx] - s_want[idx]).max() / s_want[1] < tol_logits

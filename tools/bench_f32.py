@@ -27,19 +27,19 @@ for name, N, K in [("qkv", 2304, 768), ("proj", 768, 768), ("fc1", 3072, 768), (
     for label, fn in [("fwd", lambda: ops.linear_fwd(x, M, K, w, b, out, N)), ("dx", lambda: ops.linear_dx(dy, M, N, w, dx, K)),
                       ("dw", lambda: ops.linear_dw(dy, x, M, N, K))]:
         t = {}
-        for mode in (1, 0):
+        for mode in (1, 2, 0):
             lib().mv_gemm_f32_force_fma(mode)
             t[mode] = timeit(fn)
         lib().mv_gemm_f32_force_fma(0)
         fl = 2.0 * M * N * K
-        rows.append((f"{name} {label}", fl / t[1] / 1e12, fl / t[0] / 1e12))
+        rows.append((f"{name} {label}", fl / t[1] / 1e12, fl / t[2] / 1e12, fl / t[0] / 1e12))
 B, H, N_, dh = 64, 12, 197, 64
 qkv = torch.randn(B, N_, 3 * H * dh, device="cuda")
 for mode in (1, 0):
     lib().mv_gemm_f32_force_fma(mode)
     t = timeit(lambda: ops.attention_probs_fp32(qkv, B, N_, H, dh, 0.125))
-    rows.append((f"attn probs ({'fma' if mode else 'mfma'})", 2.0 * B * H * N_ * N_ * dh / t / 1e12, 0.0))
+    rows.append((f"attn probs ({'fma' if mode else 'mfma'})", 2.0 * B * H * N_ * N_ * dh / t / 1e12, 0.0, 0.0))
 lib().mv_gemm_f32_force_fma(0)
-print(f"{'shape (M=%d)' % M:24s} {'FMA':>8s} {'MFMA':>8s}  TFLOP/s")
+print(f"{'shape (M=%d)' % M:24s} {'FMA':>8s} {'generic':>8s} {'fast':>8s}  TFLOP/s")
 for r in rows:
-    print(f"{r[0]:24s} {r[1]:8.1f} {r[2]:8.1f}")
+    print(f"{r[0]:24s} {r[1]:8.1f} {r[2]:8.1f} {r[3]:8.1f}")
