@@ -43,15 +43,41 @@ VIT_B = dict(decoder="classification", image_size=224, patch_size=16, num_classe
              mlp_dim=3072, dropout=0.0, emb_dropout=0.0)
 
 
+def _latest_profile(suffix):
+    """Newest committed profiles/rNN_<suffix> (rounds sort lexicographically), parsed, or None."""
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", f"r[0-9][0-9]_{suffix}")))
+    if not files:
+        return None
+    try:
+        with open(files[-1]) as f:
+            return json.load(f), os.path.basename(files[-1])
+    except (OSError, ValueError):
+        return None
+
+
 def pmc_traffic(kernel_family):
     """HBM-side bytes per launch of the dominant kernel family, from the committed rocprofv3 PMC passes
     (FETCH_SIZE and WRITE_SIZE in separate runs, FETCH_SIZE doubled per the gfx950 correction of
-    MI355X_MICROARCH.md section HBM; profiles/r01_pmc_traffic.json).  Counters cannot be read from inside this
-    process, so this is the last measured value for the same command, or None if no PMC pass has been committed."""
+    MI355X_MICROARCH.md section HBM; tools/pmc_traffic.py -> profiles/rNN_pmc_traffic.json).  Counters cannot be read from
+    inside this process, so this is the last measured value for the same command, or None if none has been committed."""
+    got = _latest_profile("pmc_traffic.json")
     try:
-        with open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")) as f:
-            return round(json.load(f)["kernels"][kernel_family]["hbm_bytes_per_launch"])
-    except (OSError, KeyError, ValueError):
+        return round(got[0]["kernels"][kernel_family]["hbm_bytes_per_launch"])
+    except (TypeError, KeyError, ValueError):
+        return None
+
+
+def pmc_mfma_util():
+    """MFMA utilisation (matrix-pipe busy cycles / SIMD-cycles) from the committed SQ counter pass
+    (tools/pmc_mfma_util.py -> profiles/rNN_mfma_util.json): the dominant kernel family and the attention + MLP blocks."""
+    got = _latest_profile("mfma_util.json")
+    try:
+        d, name = got
+        return {"gemm_nt": round(d["kernels"]["gemm_nt"]["mfma_util"], 4), "gemm_tn": round(d["kernels"]["gemm_tn"]["mfma_util"], 4),
+                "attention": round(d["kernels"]["attention"]["mfma_util"], 4),
+                "attention_mlp_block": round(d["block"]["mfma_util"], 4), "source": f"profiles/{name}"}
+    except (TypeError, KeyError, ValueError):
         return None
 
 
@@ -136,7 +162,8 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--batch", type=int, default=256, help="per-GPU batch")
+    ap.add_argument("--batch", type=int, default=None,
+                    help="per-GPU batch (default 256; 1024 for infer-int8: BASELINE config 5)")
     ap.add_argument("--precision", default="bf16")
     ap.add_argument("--workload", default="cls", choices=["cls", "seg", "seg256", "infer-int8"],
                     help="cls = the headline (SURVEY section 8d config 2/3); seg/seg256 = config 4 (segmentation "
@@ -156,6 +183,8 @@ def main():
                     help="no compute: only the multi-process launch, rendezvous, barriers and the JSON line (CPU test)")
     args = ap.parse_args()
 
+    if args.batch is None:
+        args.batch = 1024 if args.workload == "infer-int8" else 256
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         raise SystemExit(self_launch(args.gpus))         # one fresh process per GPU; this one never initialises a GPU
     if args.dry_run:
@@ -269,7 +298,9 @@ def main():
             "value": round(img_s, 2), "unit": "images/sec", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(1e3 * elapsed / args.steps, 3), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None,
-            "dtype": "int8 codes on bf16 MFMA, fp32 accumulate" if args.workload == "infer-int8" else args.precision,
+            "dtype": ("int8 (v_mfma_i32_16x16x64_i8, int32 accumulate; attention core "
+                      + ("bf16" if args.int8_bf16_attention else "fp32 on the f32 MFMA") + ")")
+            if args.workload == "infer-int8" else args.precision,
             "data": "synthetic",
             "config": {"workload": WORKLOAD[args.workload] + ("" if not args.no_optimizer else " [optimizer step OFF]")
                        + (" [attention core: fused bf16 kernel]" if args.int8_bf16_attention else ""),
@@ -288,6 +319,8 @@ def main():
                                    "launches": k["launches"], "timed_steps": f"every {args.timer_every}th of {args.steps}",
                                    "avg_launch_us": round(k["avg_us"], 1),
                                    "gflop_per_launch": round(k["flops_per_launch"] / 1e9, 2),
+                                   # SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE / 8 x 1024 SIMDs), separate PMC pass
+                                   "mfma_util": pmc_mfma_util(),
                                    # measured on this board class (profiles/r01_clock_power.md): what the 1400 W cap lets
                                    # an MFMA stream on random bf16 operands sustain -- context for frac, not its denominator
                                    "power_capped_tflops": {"mfma_from_registers": 1930, "mfma_fed_from_lds": 1600}}

@@ -35,17 +35,6 @@
 #ifndef MV_ABLATE
 #define MV_ABLATE 0   // diagnostic builds only (tools/ablate_gemm.sh); 0 in the product
 #endif
-// experiment switches of the 8-phase NT kernel (tools/nt_variants.sh builds one library per setting)
-#ifndef MV_NT_SC1
-#define MV_NT_SC1 0      // 1: C / out2 leave as write-through (sc1) stores that do not stay in the XCD's L2
-#endif
-#ifndef MV_NT_BAND
-#define MV_NT_BAND 0     // c > 0: an XCD owns whole row panels and walks them in column bands of c tiles
-#endif
-#ifndef MV_NT_STAGGER
-#define MV_NT_STAGGER 0  // n > 0: every other CU pair starts n x 8128 cycles late (de-phases the store bursts)
-#endif
-
 namespace {
 
 constexpr int BM = 128, BN = 128, BK = 64;
@@ -75,13 +64,7 @@ struct EpiArgs {
 };
 
 // 16-byte output store of the NT epilogues
-__device__ __forceinline__ void st16(void* p, u32x4 v) {
-#if MV_NT_SC1
-  asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" ::"v"(p), "v"(v) : "memory");
-#else
-  *reinterpret_cast<u32x4*>(p) = v;
-#endif
-}
+__device__ __forceinline__ void st16(void* p, u32x4 v) { *reinterpret_cast<u32x4*>(p) = v; }
 
 template <typename CT>
 __device__ __forceinline__ void store4(CT* p, const float v[4], bool vec, int nvalid) {
@@ -831,15 +814,11 @@ template <int EPI, typename CT, bool I8 = false>
 __global__ __launch_bounds__(512, 2) void gemm_nt_8phase_kernel(const bf16_t* __restrict__ A, int lda,
                                                                 const bf16_t* __restrict__ B, int ldb, CT* __restrict__ C,
                                                                 int ldc, int M, int N, int K, int tiles_n, EpiArgs ep,
-                                                                int full_tiles, int item0, int band) {
+                                                                int full_tiles, int item0) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave >> 2, wn = wave & 3;
   const int bid = blockIdx.x + item0;            // item0 > 0: only the items from item0 on (the half items)
-#if MV_NT_STAGGER
-  if (blockIdx.x < 256 && ((blockIdx.x >> 3) & 1))
-    for (int i = 0; i < MV_NT_STAGGER; ++i) __builtin_amdgcn_s_sleep(127);
-#endif
   // Work items [0, full_tiles) are whole 256x256 output tiles (full_tiles = a multiple of the CU count, or all tiles).
   // The remaining "tail" tiles would occupy only part of the chip for one more full round; each is split into two
   // 128x256 HALF items (rows [0,128) and [128,256) of the tile) that run the same pipeline with quadrant-row 0 only:
@@ -847,18 +826,7 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_8phase_kernel(const bf16_t* __
   // 591 tiles on 256 CUs: 3 rounds -> 2 + ~0.6, with no extra memory traffic.
   const int nk = K >> 6;                         // even, >= 2 (dispatch)
   int t, half = -1;
-  if (band > 0) {
-    // column-band order (all tiles are whole items, grid = 8 x the longest XCD run): XCD x owns whole row panels
-    // [row0, row0 + rows_x) and walks them band by band, so a band's slice of B stays in its L2 for rows_x panels
-    const int tiles_m = full_tiles / tiles_n, x = bid & 7, j = bid >> 3;
-    const int base = tiles_m >> 3, rem = tiles_m & 7;
-    const int rows_x = base + (x < rem ? 1 : 0), row0 = x * base + (x < rem ? x : rem);
-    if (j >= rows_x * tiles_n) return;
-    const int per_band = rows_x * band, nb_full = tiles_n / band;
-    int b = j / per_band, w = band, jj = j - b * per_band;
-    if (b >= nb_full) { b = nb_full; w = tiles_n - nb_full * band; jj = j - nb_full * per_band; }
-    t = (row0 + jj / w) * tiles_n + b * band + jj % w;
-  } else if (bid < full_tiles) {
+  if (bid < full_tiles) {
     t = xcd_remap(bid, full_tiles);
   } else {
     const int idx = bid - full_tiles;
@@ -1851,22 +1819,13 @@ int launch_nt(const void* A, int lda, const void* B, int ldb, void* C, int ldc, 
             (const bf16_t*)A, lda, (const bf16_t*)B, ldb, (CT*)C, ldc, M, N, K, t2n, ep, full);
         if (tiles > full)                       // the tail round's half items: the one-item-per-workgroup kernel
           gemm_nt_8phase_kernel<EPI, CT><<<2 * (tiles - full), 512, P8_SMEM, s>>>(
-              (const bf16_t*)A, lda, (const bf16_t*)B, ldb, (CT*)C, ldc, M, N, K, t2n, ep, full, full, 0);
+              (const bf16_t*)A, lda, (const bf16_t*)B, ldb, (CT*)C, ldc, M, N, K, t2n, ep, full, full);
         MV_CHECK_LAUNCH();
         return MV_OK;
       }
     }
-#if MV_NT_BAND
-    if (t2n > MV_NT_BAND && K <= 1024 && force == 0) {       // many column tiles, short K: B does not fit an XCD's L2
-      const int longest = ((t2m >> 3) + ((t2m & 7) ? 1 : 0)) * t2n;
-      gemm_nt_8phase_kernel<EPI, CT><<<8 * longest, 512, P8_SMEM, s>>>(
-          (const bf16_t*)A, lda, (const bf16_t*)B, ldb, (CT*)C, ldc, M, N, K, t2n, ep, tiles, 0, MV_NT_BAND);
-      MV_CHECK_LAUNCH();
-      return MV_OK;
-    }
-#endif
     gemm_nt_8phase_kernel<EPI, CT><<<full + 2 * (tiles - full), 512, P8_SMEM, s>>>(
-        (const bf16_t*)A, lda, (const bf16_t*)B, ldb, (CT*)C, ldc, M, N, K, t2n, ep, full, 0, 0);
+        (const bf16_t*)A, lda, (const bf16_t*)B, ldb, (CT*)C, ldc, M, N, K, t2n, ep, full, 0);
     MV_CHECK_LAUNCH();
     return MV_OK;
   }
@@ -1949,7 +1908,7 @@ int launch_nt_i8(const void* A, int lda, const void* B, int ldb, void* C, int ld
   const int tiles = t2m * t2n, full = nt_full_tiles(tiles);
   // bytes -> the bf16-element geometry the kernel is written in
   gemm_nt_8phase_kernel<EPI, CT, true><<<full + 2 * (tiles - full), 512, P8_SMEM, s>>>(
-      (const bf16_t*)A, lda / 2, (const bf16_t*)B, ldb / 2, (CT*)C, ldc, M, N, K / 2, t2n, ep, full, 0, 0);
+      (const bf16_t*)A, lda / 2, (const bf16_t*)B, ldb / 2, (CT*)C, ldc, M, N, K / 2, t2n, ep, full, 0);
   MV_CHECK_LAUNCH();
   return MV_OK;
 }
