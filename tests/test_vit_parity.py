@@ -95,7 +95,9 @@ def check_case(name, precision, tol_logits, tol_grad, q_format=None):
             margin_ok = (top2[:, 1] - top2[:, 0]) > 2 * tol_logits * np.abs(want).max()
             assert margin_ok.mean() > 0.5 and (am == arrays["argmax_sub"])[margin_ok].all()
         s_got, s_want = summarize(lg).numpy(), arrays["logits_summary"]
-        idx = slice(0, 4) if precision == "fp32" else slice(1, 3)     # bf16: norms only (correlated rounding, see below)
+        # bf16 and fake-quantised paths: norms only (their rounding errors are correlated, and a plain sum over 1.7 M logits
+        # compared against the l2 scale amplifies them 1000-fold: measured 3.7e-4 of the sum itself for FP16_32)
+        idx = slice(0, 4) if precision == "fp32" and q_format is None else slice(1, 3)
         assert np.abs(s_got[idx] - s_want[idx]).max() / s_want[1] < tol_logits
     assert abs(float(loss) - float(arrays["loss"])) < tol_logits * max(1.0, abs(float(arrays["loss"])))
     unused = []
