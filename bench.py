@@ -173,6 +173,9 @@ def main():
     ap.add_argument("--no-optimizer", action="store_true", help="fwd+bwd only (section 8d: report with and without)")
     ap.add_argument("--int8-bf16-attention", action="store_true",
                     help="infer-int8: ViT.convert(bf16_attention=True) -- fused bf16 attention core instead of exact fp32")
+    ap.add_argument("--q-format", default=None, choices=["FP16_16", "FP16_32", "TF32"],
+                    help="cls workload with a fake-quantised model (runs in fp32 precision by definition; the forward "
+                         "products of the FP16 formats go to the f16 matrix cores)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--per-shape", action="store_true", help="add the event-timed GEMM launches split by product shape")
     ap.add_argument("--no-kernel-timer", action="store_true")
@@ -226,7 +229,7 @@ def main():
     if args.workload in ("seg", "seg256"):
         size = 256 if args.workload == "seg256" else 224
         cfg.update(decoder="segmentation", num_classes=17, image_size=size)
-    q_format = "PyTorchINT8" if args.workload == "infer-int8" else "FP32"
+    q_format = "PyTorchINT8" if args.workload == "infer-int8" else (args.q_format or "FP32")
     vit = ViT(precision=args.precision, q_format=q_format, **cfg).to(dev)
     arena = ParamArena(vit.named_parameters(), skip=vit.unused_parameter_names())
     opt = AdamW(arena, lr=6.25e-5, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.05)      # vit_base.json
@@ -300,9 +303,11 @@ def main():
             "vs_baseline": None,
             "dtype": ("int8 (v_mfma_i32_16x16x64_i8, int32 accumulate; attention core "
                       + ("bf16" if args.int8_bf16_attention else "fp32 on the f32 MFMA") + ")")
-            if args.workload == "infer-int8" else args.precision,
+            if args.workload == "infer-int8" else (f"fp32 values fake-quantised to {args.q_format}" if args.q_format
+                                                   else args.precision),
             "data": "synthetic",
             "config": {"workload": WORKLOAD[args.workload] + ("" if not args.no_optimizer else " [optimizer step OFF]")
+                       + (f" [q_format {args.q_format}]" if args.q_format else "")
                        + (" [attention core: fused bf16 kernel]" if args.int8_bf16_attention else ""),
                        "per_gpu_batch": args.batch, "global_batch": args.batch * world,
                        "parallelism": f"dp{world}", "final_loss": round(final_loss, 4)},

@@ -191,6 +191,13 @@ int mv_quant_affine(const float* x, float* y, long n, float scale, int zero_poin
  * (vit.py:48-51) without the fp32 round trip; 0: none. */
 int mv_quant_affine_codes(const void* x, int x_dtype, void* codes, long rows, int cols, int ld, float scale, int zero_point,
                           int qmin, int qmax, int pre_op, mv_stream_t stream);
+/* float_quantize(exp 5, man 10) written as IEEE half (exact: every value of the format is a half), and the NT product of two
+ * such operands on v_mfma_f32_16x16x32_f16 with fp32 accumulation: the FORWARD products of the FP16_16 / FP16_32 formats
+ * (quantize.py:253-327: both the activation stub and weight_fake_quant round to (5, 10)), which the reference computes as an
+ * fp32 GEMM of the same values.  A [M, lda], B [N, ldb] half, K % 128 == 0; C fp32; epilogues MV_EPI_NONE / MV_EPI_RESIDUAL. */
+int mv_quant_float_f16(const float* x, void* y, long n, mv_stream_t stream);
+int mv_gemm_nt_f16(const void* A, int lda, const void* B, int ldb, void* C, int ldc, int M, int N, int K, const float* bias,
+                   int epilogue, const void* aux, int ld_aux, void* out2, int ld_out2, mv_stream_t stream);
 /* the same quantiser writing int8 codes q - 128 (quint8: qmin 0, qmax 255) for mv_gemm_nt_i8; ld = row stride in BYTES
  * (multiple of 16), columns [cols, ld) zero-filled */
 int mv_quant_affine_i8(const void* x, int x_dtype, void* codes, long rows, int cols, int ld, float scale, int zero_point,

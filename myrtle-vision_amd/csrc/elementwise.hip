@@ -912,6 +912,29 @@ extern "C" int mv_quant_float(const float* x, float* y, long n, int exp_bits, in
   return MV_OK;
 }
 
+// float_quantize(5, 10) written as IEEE half: every value of that format (subnormals included, saturation at 65504) is
+// exactly representable, so the conversion after the quantiser's own rounding is exact
+__global__ __launch_bounds__(256) void quant_float_f16_kernel(const float* __restrict__ x, _Float16* __restrict__ y, long n) {
+  const long n4 = n >> 2;
+  typedef __attribute__((ext_vector_type(4))) _Float16 f16x4_t;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long)gridDim.x * 256) {
+    const float4 v = reinterpret_cast<const float4*>(x)[i];
+    reinterpret_cast<f16x4_t*>(y)[i] = (f16x4_t){(_Float16)quant_float_one(v.x, 5, 10), (_Float16)quant_float_one(v.y, 5, 10),
+                                                 (_Float16)quant_float_one(v.z, 5, 10), (_Float16)quant_float_one(v.w, 5, 10)};
+  }
+  for (long i = (n4 << 2) + (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256)
+    y[i] = (_Float16)quant_float_one(x[i], 5, 10);
+}
+
+extern "C" int mv_quant_float_f16(const float* x, void* y, long n, mv_stream_t stream) {
+  MV_REQUIRE(n >= 0, MV_ERR_SHAPE);
+  if (n == 0) return MV_OK;
+  MV_REQUIRE(mv_aligned16(x) && mv_aligned16(y), MV_ERR_ALIGN);
+  quant_float_f16_kernel<<<ew_grid((n + 3) / 4), 256, 0, S_>>>(x, (_Float16*)y, n);
+  MV_CHECK_LAUNCH();
+  return MV_OK;
+}
+
 extern "C" int mv_quant_fixed(const float* x, float* y, long n, int wl, int fl, int clamp, int symmetric,
                               mv_stream_t stream) {
   MV_REQUIRE(n >= 0 && wl > 0 && wl <= 32, MV_ERR_SHAPE);

@@ -810,12 +810,18 @@ typedef __attribute__((ext_vector_type(4))) int i32x4;
 // operands alike, so staging, LDS image, swizzle and fragment reads are unchanged (the caller passes K/2, lda/2, ldb/2);
 // only the MFMA differs, and twice the MACs ride on every staged byte.  The int32 sums leave as floats through the same
 // epilogues, after the zero-point correction icorr[n] has been added in integer arithmetic.
-template <int EPI, typename CT, bool I8 = false>
+// OPK = NT_F16: the operands are IEEE half (v_mfma_f32_16x16x32_f16): same 2-byte geometry as bf16, only the MFMA differs.
+// Used for the forward products of the fake-quantised FP16 formats, whose operands are exactly representable in fp16.
+constexpr int NT_BF16 = 0, NT_I8 = 1, NT_F16 = 2;
+typedef __attribute__((ext_vector_type(8))) _Float16 f16x8;
+
+template <int EPI, typename CT, int OPK = NT_BF16>
 __global__ __launch_bounds__(512, 2) void gemm_nt_8phase_kernel(const bf16_t* __restrict__ A, int lda,
                                                                 const bf16_t* __restrict__ B, int ldb, CT* __restrict__ C,
                                                                 int ldc, int M, int N, int K, int tiles_n, EpiArgs ep,
                                                                 int full_tiles, int item0) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
+  constexpr bool I8 = OPK == NT_I8;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave >> 2, wn = wave & 3;
   const int bid = blockIdx.x + item0;            // item0 > 0: only the items from item0 on (the half items)
@@ -902,6 +908,10 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_8phase_kernel(const bf16_t* __
             acc[(mb_) + i][(nb_) + j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_mfma_i32_16x16x64_i8(     \
                 __builtin_bit_cast(i32x4, bfx_[j][ks]), __builtin_bit_cast(i32x4, af[i][ks]),                \
                 __builtin_bit_cast(i32x4, acc[(mb_) + i][(nb_) + j]), 0, 0, 0));                             \
+          else if constexpr (OPK == NT_F16)                                                                  \
+            acc[(mb_) + i][(nb_) + j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(                              \
+                __builtin_bit_cast(f16x8, bfx_[j][ks]), __builtin_bit_cast(f16x8, af[i][ks]),                \
+                acc[(mb_) + i][(nb_) + j], 0, 0, 0);                                                         \
           else                                                                                               \
             acc[(mb_) + i][(nb_) + j] =                                                                      \
                 __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfx_[j][ks], af[i][ks], acc[(mb_) + i][(nb_) + j], 0, 0, 0); \
@@ -1901,18 +1911,54 @@ namespace {
 template <int EPI, typename CT>
 int launch_nt_i8(const void* A, int lda, const void* B, int ldb, void* C, int ldc, int M, int N, int K, EpiArgs ep,
                  hipStream_t s) {
-  static const int a8 = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_nt_8phase_kernel<EPI, CT, true>),
+  static const int a8 = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_nt_8phase_kernel<EPI, CT, NT_I8>),
                                             hipFuncAttributeMaxDynamicSharedMemorySize, P8_SMEM) == hipSuccess ? 0 : -1;
   if (a8) return MV_ERR_LAUNCH;
   const int t2m = mv_cdiv(M, BM2), t2n = mv_cdiv(N, BN2);
   const int tiles = t2m * t2n, full = nt_full_tiles(tiles);
   // bytes -> the bf16-element geometry the kernel is written in
-  gemm_nt_8phase_kernel<EPI, CT, true><<<full + 2 * (tiles - full), 512, P8_SMEM, s>>>(
+  gemm_nt_8phase_kernel<EPI, CT, NT_I8><<<full + 2 * (tiles - full), 512, P8_SMEM, s>>>(
       (const bf16_t*)A, lda / 2, (const bf16_t*)B, ldb / 2, (CT*)C, ldc, M, N, K / 2, t2n, ep, full, 0);
   MV_CHECK_LAUNCH();
   return MV_OK;
 }
 }  // namespace
+
+namespace {
+template <int EPI, typename CT>
+int launch_nt_f16(const void* A, int lda, const void* B, int ldb, void* C, int ldc, int M, int N, int K, EpiArgs ep,
+                  hipStream_t s) {
+  static const int a8 = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_nt_8phase_kernel<EPI, CT, NT_F16>),
+                                            hipFuncAttributeMaxDynamicSharedMemorySize, P8_SMEM) == hipSuccess ? 0 : -1;
+  if (a8) return MV_ERR_LAUNCH;
+  const int t2m = mv_cdiv(M, BM2), t2n = mv_cdiv(N, BN2);
+  const int tiles = t2m * t2n, full = nt_full_tiles(tiles);
+  gemm_nt_8phase_kernel<EPI, CT, NT_F16><<<full + 2 * (tiles - full), 512, P8_SMEM, s>>>(
+      (const bf16_t*)A, lda, (const bf16_t*)B, ldb, (CT*)C, ldc, M, N, K, t2n, ep, full, 0);
+  MV_CHECK_LAUNCH();
+  return MV_OK;
+}
+}  // namespace
+
+extern "C" int mv_gemm_nt_f16(const void* A, int lda, const void* B, int ldb, void* C, int ldc, int M, int N, int K,
+                              const float* bias, int epilogue, const void* aux, int ld_aux, void* out2, int ld_out2,
+                              mv_stream_t stream) {
+  MV_REQUIRE(M >= 0 && N >= 0 && K > 0, MV_ERR_SHAPE);
+  if (M == 0 || N == 0) return MV_OK;
+  MV_REQUIRE(K % 128 == 0, MV_ERR_UNSUPPORTED);
+  MV_REQUIRE(lda % 8 == 0 && ldb % 8 == 0 && lda >= K && ldb >= K, MV_ERR_ALIGN);
+  MV_REQUIRE(mv_aligned16(A) && mv_aligned16(B) && mv_aligned16(C), MV_ERR_ALIGN);
+  MV_REQUIRE((long)M * lda < (1L << 31) && (long)N * ldb < (1L << 31), MV_ERR_SHAPE);
+  hipStream_t s = (hipStream_t)stream;
+  EpiArgs ep{1.0f, bias, aux, ld_aux, 0, out2, ld_out2, nullptr};
+  switch (epilogue) {
+    case MV_EPI_NONE: return launch_nt_f16<MV_EPI_NONE, float>(A, lda, B, ldb, C, ldc, M, N, K, ep, s);
+    case MV_EPI_RESIDUAL:
+      MV_REQUIRE(aux, MV_ERR_UNSUPPORTED);
+      return launch_nt_f16<MV_EPI_RESIDUAL, float>(A, lda, B, ldb, C, ldc, M, N, K, ep, s);
+    default: return MV_ERR_UNSUPPORTED;
+  }
+}
 
 extern "C" int mv_gemm_nt_i8(const void* A, int lda, const void* B, int ldb, void* C, int ldc, int c_dtype, int M, int N, int K,
                              float alpha, const float* bias, const int* icorr, int epilogue, const void* aux, int ld_aux,

@@ -106,6 +106,48 @@ def linear(x, weight, bias, out_dtype=None):
     return _Linear.apply(x, weight, bias, x.dtype if out_dtype is None else out_dtype)
 
 
+class _LinearQatF16(Function):
+    """nn.qat.Linear of the FP16 formats (utils/quantize.py:253-327) when its input already holds float_quantize(5, 10)
+    values: y = x W_q^T + b with W_q = weight_fake_quant(W).  Both operands are exactly representable in IEEE half, so the
+    forward product runs on the f16 matrix cores with fp32 accumulation -- the same numbers as the reference's fp32 GEMM of
+    the same values up to summation order.  Backward is the straight-through estimator's: dX = dY W_q, dW = dY^T x in fp32
+    (dY is not quantised, so those products stay on the f32 MFMA)."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias):
+        ops.require_cuda(x, weight, bias)
+        K, N = x.shape[-1], weight.shape[0]
+        x2 = _c(x.float()).view(-1, K)
+        M = x2.shape[0]
+        x16 = ops.quant_float_f16(x2)                          # idempotent on already-quantised values: an exact conversion
+        w16 = ops.quant_float_f16(weight)                      # weight_fake_quant and the half conversion in one pass
+        out = torch.empty(M, N, dtype=torch.float32, device=x.device)
+        ops.linear_f16(x16, w16, M, N, K, bias, out)
+        ctx.save_for_backward(x2, ops.quant_float(weight, 5, 10))
+        ctx.params = (weight, bias)
+        ctx.in_shape = x.shape
+        return out.view(*x.shape[:-1], N)
+
+    @staticmethod
+    def backward(ctx, dy):
+        x2, wq = ctx.saved_tensors
+        weight, bias = ctx.params
+        M, K = x2.shape
+        N = wq.shape[0]
+        dy2 = _c(dy.float()).view(M, N)
+        dx = None
+        if ctx.needs_input_grad[0]:
+            dx = torch.empty(M, K, dtype=torch.float32, device=dy.device)
+            ops.linear_dx(dy2, M, N, wq, dx, K)
+            dx = dx.view(ctx.in_shape)
+        dw, db = ops.linear_dw(dy2, x2, M, N, K, want_bias=bias is not None, weight=weight, bias=bias)
+        return dx, dw, db
+
+
+def linear_qat_f16(x, weight, bias):
+    return _LinearQatF16.apply(x, weight, bias)
+
+
 class _Gelu(Function):
     @staticmethod
     def forward(ctx, x):

@@ -29,6 +29,8 @@ SIGNATURES = {
     "mv_gemm_nt_bf16": ("pipipii" "iii" "pi" "pii" "pi" "p", _I),
     "mv_gemm_nt_bf16_scaled": ("pipipii" "iii" "f" "pi" "pii" "pi" "p", _I),
     "mv_quant_affine_codes": ("pip" "lii" "f" "iiii" "p", _I),
+    "mv_quant_float_f16": ("pp" "l" "p", _I),
+    "mv_gemm_nt_f16": ("pipipi" "iii" "p" "i" "pi" "pi" "p", _I),
     "mv_quant_affine_i8": ("pip" "lii" "f" "ii" "p", _I),
     "mv_gemm_nt_i8": ("pipipii" "iii" "f" "pp" "i" "pi" "p", _I),
     "mv_gemm_tn_bf16": ("pipipi" "iii" "i" "p" "pz" "p", _I),

@@ -524,6 +524,32 @@ def quant_float(x, exp_bits, man_bits):
     return y
 
 
+def quant_float_f16(x):
+    """float_quantize(x, exp=5, man=10) stored as IEEE half (exact) -- an operand of ``linear_f16``."""
+    require_cuda(x)
+    xf = x.detach().float().contiguous()
+    y = torch.empty(xf.shape, dtype=torch.float16, device=xf.device)
+    check(lib().mv_quant_float_f16(_p(xf), _p(y), xf.numel(), _s()), "quant_float_f16", n=xf.numel())
+    return y
+
+
+def linear_f16_supported(M, N, K):
+    """Shapes the f16 MFMA GEMM takes (the 8-phase kernel: K % 128 == 0 and a grid worth a launch)."""
+    return K % 128 == 0 and M >= 256 and N >= 256
+
+
+def linear_f16(x16, w16, M, N, K, bias, out, residual=None):
+    """out fp32 [M, N] = x16 [M, K] . w16 [N, K]^T + bias (+ residual): half operands on v_mfma_f32_16x16x32_f16, fp32
+    accumulation."""
+    t0 = _timer.begin() if _timer is not None else None
+    epi, aux, ld_aux = (EPI_RESIDUAL, _p(residual), N) if residual is not None else (EPI_NONE, None, 0)
+    check(lib().mv_gemm_nt_f16(_p(x16), K, _p(w16), K, _p(out), N, M, N, K, _p(bias), epi, aux, ld_aux, None, 0, _s()),
+          "gemm_nt_f16", M=M, N=N, K=K)
+    if t0 is not None:
+        _timer.end("gemm_nt_f16", t0, 2.0 * M * N * K, shape=f"f16 N{N} K{K} epi{epi}")
+    return out
+
+
 def quant_fixed(x, wl, fl, clamp=True, symmetric=False):
     require_cuda(x)
     xf = x.detach().float().contiguous()

@@ -837,6 +837,68 @@ def test_int8_vit_base_dim_matches_torch_fake_quant():
     assert relerr(fast, slow.detach().double().cpu()) < 2e-2
 
 
+@pytest.mark.parametrize("M,N,K", [(512, 768, 768), (1576, 3072, 768), (1000, 768, 3072)])
+def test_f16_mfma_gemm_of_quantised_operands(ops, M, N, K):
+    """mv_quant_float_f16 + mv_gemm_nt_f16: float_quantize(5, 10) values are exact IEEE halves, so the f16 MFMA with fp32
+    accumulation gives the fp32 product of the quantised operands (what the reference's nn.qat.Linear computes)."""
+    from oracle import quant_oracle
+    x = torch.randn(M, K, generator=g(1)) * 3
+    w = torch.randn(N, K, generator=g(2)) * K ** -0.5
+    b = torch.randn(N, generator=g(3))
+    x[0, :8] = torch.tensor([1e-7, -3e-6, 6.1e-5, 7e4, -1e5, 0.0, 65504.0, 2.0 ** -24])      # subnormals, saturation
+    xq = torch.from_numpy(quant_oracle.float_quantize(x.numpy(), 5, 10))
+    wq = torch.from_numpy(quant_oracle.float_quantize(w.numpy(), 5, 10))
+    x16, w16 = ops.quant_float_f16(x.cuda()), ops.quant_float_f16(w.cuda())
+    assert x16.dtype == torch.float16 and torch.equal(x16.float().cpu(), xq) and torch.equal(w16.float().cpu(), wq)
+    assert torch.equal(ops.quant_float_f16(xq.cuda()), x16)                                   # idempotent
+    out = torch.empty(M, N, device="cuda")
+    ops.linear_f16(x16, w16, M, N, K, b.cuda(), out)
+    assert relerr(out, xq.double() @ wq.double().t() + b.double()) < 2e-6
+    res = torch.randn(M, N, generator=g(4)).cuda()
+    out2 = torch.empty(M, N, device="cuda")
+    ops.linear_f16(x16, w16, M, N, K, b.cuda(), out2, residual=res)
+    assert relerr(out2, xq.double() @ wq.double().t() + b.double() + res.double().cpu()) < 2e-6
+
+
+def test_fp16_qat_model_f16_forward_equals_fp32_path():
+    """FP16_32-prepared ViT at ViT-B width: forward products on the f16 matrix cores == the fp32-GEMM path on the same
+    quantised values (fp32 summation order apart; quantisers downstream are discontinuous, hence 3e-3 as for the goldens),
+    same gradients through the straight-through estimator."""
+    from myrtle_vision.hip.functional import cross_entropy
+    from myrtle_vision.models.vit import ViT
+    from myrtle_vision.utils.quantize import QATLinear
+    from myrtle_vision.utils.utils import seed_everything
+    kw = dict(decoder="classification", image_size=224, patch_size=16, num_classes=1000, dim=768, depth=2, heads=12, mlp_dim=3072)
+    gen = torch.Generator().manual_seed(4)
+    img, labels = torch.randn(4, 3, 224, 224, generator=gen).cuda(), torch.randint(0, 1000, (4,), generator=gen).cuda()
+    res = {}
+    for use in (True, False):
+        seed_everything(3)
+        vit = ViT(q_format="FP16_32", **kw).cuda()
+        QATLinear.use_f16 = use
+        try:
+            logits = vit(img)
+            cross_entropy(logits, labels).backward()
+        finally:
+            QATLinear.use_f16 = True
+        res[use] = (logits.detach().double().cpu(), {n: p.grad.double().cpu() for n, p in vit.named_parameters() if p.grad is not None})
+    assert relerr(res[True][0], res[False][0]) < 3e-3
+    for n, gr in res[False][1].items():
+        assert float((res[True][1][n] - gr).norm() / gr.norm().clamp_min(1e-30)) < 2e-2, n
+    # and the f16 path is actually taken at this width
+    from myrtle_vision.hip import ops as _ops
+    seen, orig = [], _ops.linear_f16
+    _ops.linear_f16 = lambda *a, **k: (seen.append(a[2:5]), orig(*a, **k))[1]
+    try:
+        seed_everything(3)
+        vit = ViT(q_format="FP16_32", **kw).cuda()
+        with torch.no_grad():
+            vit(img)
+    finally:
+        _ops.linear_f16 = orig
+    assert len(seen) == 1 + 4 * 2                    # patch embedding + (qkv, proj, fc1, fc2) x 2 blocks; the head has M = 4
+
+
 def test_int8_converted_model_fast_path_equals_fake_quant_path():
     """ViT.convert() for PyTorchINT8 installs Int8Linear: under no_grad it runs integer codes through the MFMA GEMM; with
     grad enabled it runs the fp32 fake-quant (straight-through) path.  Same numbers up to fp32 summation order."""

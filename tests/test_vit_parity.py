@@ -235,8 +235,10 @@ def test_block_taps_and_attention_hook_fp32():
 @pytest.mark.parametrize("name,fmt", [("micro_cls_fp16_32", "FP16_32"), ("micro_cls_tf32", "TF32"),
                                       ("micro_cls_fp16_16", "FP16_16"), ("micro_seg_fp16_32", "FP16_32")])
 def test_fake_quant_paths_match_reference_plumbing(name, fmt):
-    # quantised paths are compared at 3e-3: rounding flips of the discontinuous quantiser (see tests/test_oracle_golden.py)
-    check_case(name, "fp32", 3e-3, 2e-2, q_format=fmt)
+    # quantised paths: rounding flips of the discontinuous quantiser (see tests/test_oracle_golden.py) put the floor near
+    # 1e-3; measured after round 2's fix of the skipped weight quantisers: logits <= 8.1e-4, gradient summaries <= 2.1e-3
+    # (they were 1.1e-2 while the weights went unquantised: the old 2e-2 bound hid that)
+    check_case(name, "fp32", 2e-3, 6e-3, q_format=fmt)
 
 
 def test_fake_quant_convert_matches_reference():
