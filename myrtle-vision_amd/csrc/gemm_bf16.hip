@@ -1984,8 +1984,8 @@ extern "C" int mv_gemm_nt_i8(const void* A, int lda, const void* B, int ldb, voi
 }
 
 extern "C" int mv_gemm_force_variant(int nt_variant, int tn_variant) {
-  const bool nt_ok = nt_variant == 0 || nt_variant == 128 || nt_variant == 256 || nt_variant == 2564 || nt_variant == 2568 ||
-                     nt_variant == 25680 || nt_variant == 2569;
+  const bool nt_ok = nt_variant == 0 || nt_variant == 128 || nt_variant == 256 || nt_variant == 2564 ||
+                     nt_variant == 2568 || nt_variant == 25680 || nt_variant == 2569;
   const bool tn_ok = tn_variant == 0 || tn_variant == 128 || tn_variant == 256;
   MV_REQUIRE(nt_ok && tn_ok, MV_ERR_UNSUPPORTED);
   g_force_nt.store(nt_variant, std::memory_order_relaxed);
