@@ -29,7 +29,7 @@ extern "C" {
 
 typedef void* mv_stream_t; /* hipStream_t */
 
-enum { MV_F32 = 0, MV_BF16 = 1 };
+enum { MV_F32 = 0, MV_BF16 = 1, MV_I8 = 2 /* mv_gemm_nt_i8 with MV_EPI_GELU_Q8 only */ };
 
 enum {
   MV_OK = 0,
@@ -51,6 +51,9 @@ enum {
                            backward needs, so that its epilogue is MV_EPI_MUL instead of re-evaluating erf */
   MV_EPI_MUL = 6,      /* bf16 kernel only: C = acc * aux (aux: dtype of A, e.g. the gelu' left by MV_EPI_GELU_GRAD);
                           out2 as MV_EPI_DGELU (per-64-row column sums of C) */
+  MV_EPI_GELU_Q8 = 7,  /* mv_gemm_nt_i8 only: C (int8) = quint8 code - 128 of gelu_erf(acc + bias) under the NEXT layer's
+                          quantiser (q_scale, q_zero_point): FeedForward's Linear -> GELU -> next Linear's QuantStub
+                          (vit.py:48-51) without the fp32 hidden activations ever reaching memory */
   MV_EPI_EMBED = 4     /* patch-embedding: row m of the GEMM is patch (m % aux_i) of image (m / aux_i);
                           C row = img*(aux_i+1) + 1 + patch;  C = acc + bias + aux[1 + patch]  (aux: fp32 [aux_i+1, N]) */
 };
@@ -207,10 +210,19 @@ int mv_quant_affine_i8(const void* x, int x_dtype, void* codes, long rows, int c
  *   C[m][n] = alpha * ( sum_k A8[m][k] * B8[n][k] + icorr[n] ) + bias[n]  (+ aux[m][n] for MV_EPI_RESIDUAL)
  * With A8 = q_x - 128, B8 = q_w and icorr[n] = (128 - zero_point_x) * sum_k q_w[n][k] the bracket is the exact integer dot
  * product of (q_x - zero_point_x) and q_w; alpha = scale_x * scale_w.  A8 [M, lda], B8 [N, ldb] int8, strides in bytes
- * (multiples of 16), K % 256 == 0; C fp32 or bf16; epilogues MV_EPI_NONE / MV_EPI_RESIDUAL (fp32). */
+ * (multiples of 16), K % 256 == 0; C fp32 or bf16; epilogues MV_EPI_NONE / MV_EPI_RESIDUAL (fp32) / MV_EPI_GELU_Q8 (C int8
+ * [M, ldc bytes], c_dtype MV_I8, M % 256 == N % 256 == 0; q_scale / q_zero_point: the next layer's quantiser). */
 int mv_gemm_nt_i8(const void* A, int lda, const void* B, int ldb, void* C, int ldc, int c_dtype, int M, int N, int K,
                   float alpha, const float* bias, const int* icorr, int epilogue, const void* aux, int ld_aux,
-                  mv_stream_t stream);
+                  float q_scale, int q_zero_point, mv_stream_t stream);
+/* Producers with the NEXT layer's quint8 quantiser fused in (converted PyTorchINT8 model; bit-identical to producer +
+ * mv_quant_affine_i8): LayerNorm (vit.py:37,41) and the exact-fp32 attention core (vit.py:92-97, quant_out) writing int8
+ * codes q - 128 [rows, dim] / [B, N, H*64] directly.  With MV_EPI_GELU_Q8 above they remove every fp32 activation tensor
+ * between an int8 model's Linear layers except the q/k/v projections and the residual stream. */
+int mv_layernorm_fwd_q8(const float* x, long ldx, const float* gamma, const float* beta, void* codes, int rows, int dim,
+                        float eps, float scale, int zero_point, mv_stream_t stream);
+int mv_attention_fwd_f32_q8(const float* qkv, void* codes, int B, int N, int H, float scale, float q_scale, int q_zero_point,
+                            mv_stream_t stream);
 /* running min/max observer: minmax[0] = min(minmax[0], min x), minmax[1] = max(minmax[1], max x);
  * minmax points at FOUR floats: [2..3] are scratch for the reduction */
 int mv_minmax(const float* x, long n, float* minmax, mv_stream_t stream);

@@ -26,9 +26,10 @@ namespace {
 constexpr int AF_DH = 64;
 
 // NT = key/query tiles of 16 (13: N <= 208, i.e. 197 tokens; 17: N <= 272, i.e. 257 tokens)
-template <int NT>
+// Q8 = true: the result goes straight into to_out's quint8 quantiser and leaves as int8 codes q - 128 ([B, N, H*64] int8)
+template <int NT, bool Q8 = false>
 __global__ __launch_bounds__(512) void attn_fwd_f32_kernel(const float* __restrict__ qkv, float* __restrict__ out, int N,
-                                                           int H, float scale) {
+                                                           int H, float scale, float q_inv = 0.f, float q_zp = 0.f) {
   constexpr int NK = NT * 16;
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float* const Ks = smem;                    // [NK][64]
@@ -143,20 +144,27 @@ __global__ __launch_bounds__(512) void attn_fwd_f32_kernel(const float* __restri
       __builtin_amdgcn_sched_barrier(0);
     }
     if (q < N) {
-      float* op = out + ((long)b * N + q) * H * AF_DH + (long)h * AF_DH + 4 * g;
+      if constexpr (Q8) {
+        int8_t* op = reinterpret_cast<int8_t*>(out) + ((long)b * N + q) * H * AF_DH + (long)h * AF_DH + 4 * g;
 #pragma unroll
-      for (int dt = 0; dt < 4; ++dt) *reinterpret_cast<f32x4*>(op + 16 * dt) = o[dt];
+        for (int dt = 0; dt < 4; ++dt)
+          *reinterpret_cast<unsigned*>(op + 16 * dt) = affine_i8_pack4<0>(o[dt][0], o[dt][1], o[dt][2], o[dt][3], q_inv, q_zp);
+      } else {
+        float* op = out + ((long)b * N + q) * H * AF_DH + (long)h * AF_DH + 4 * g;
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt) *reinterpret_cast<f32x4*>(op + 16 * dt) = o[dt];
+      }
     }
   }
 }
 
-template <int NT>
-int launch_attn_f32(const float* qkv, float* out, int B, int N, int H, float scale, hipStream_t s) {
+template <int NT, bool Q8>
+int launch_attn_f32(const float* qkv, void* out, int B, int N, int H, float scale, float q_inv, float q_zp, hipStream_t s) {
   constexpr size_t lds = (size_t)2 * NT * 16 * AF_DH * sizeof(float);
-  static const int attr = hipFuncSetAttribute(reinterpret_cast<const void*>(attn_fwd_f32_kernel<NT>),
+  static const int attr = hipFuncSetAttribute(reinterpret_cast<const void*>(attn_fwd_f32_kernel<NT, Q8>),
                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) == hipSuccess ? 0 : -1;
   if (attr) return MV_ERR_LAUNCH;
-  attn_fwd_f32_kernel<NT><<<B * H, 512, lds, s>>>(qkv, out, N, H, scale);
+  attn_fwd_f32_kernel<NT, Q8><<<B * H, 512, lds, s>>>(qkv, (float*)out, N, H, scale, q_inv, q_zp);
   MV_CHECK_LAUNCH();
   return MV_OK;
 }
@@ -169,5 +177,18 @@ extern "C" int mv_attention_fwd_f32(const float* qkv, float* out, int B, int N, 
   MV_REQUIRE(mv_aligned16(qkv) && mv_aligned16(out), MV_ERR_ALIGN);
   if (B == 0) return MV_OK;
   hipStream_t s = (hipStream_t)stream;
-  return N <= 208 ? launch_attn_f32<13>(qkv, out, B, N, H, scale, s) : launch_attn_f32<17>(qkv, out, B, N, H, scale, s);
+  return N <= 208 ? launch_attn_f32<13, false>(qkv, out, B, N, H, scale, 0.f, 0.f, s)
+                  : launch_attn_f32<17, false>(qkv, out, B, N, H, scale, 0.f, 0.f, s);
+}
+
+extern "C" int mv_attention_fwd_f32_q8(const float* qkv, void* codes, int B, int N, int H, float scale, float q_scale,
+                                       int q_zero_point, mv_stream_t stream) {
+  MV_REQUIRE(B >= 0 && N > 0 && H > 0 && (long)B * H < (1L << 31) && q_scale > 0.f, MV_ERR_SHAPE);
+  MV_REQUIRE(N <= 272 && q_zero_point >= 0 && q_zero_point <= 255, MV_ERR_UNSUPPORTED);
+  MV_REQUIRE(mv_aligned16(qkv) && mv_aligned16(codes), MV_ERR_ALIGN);
+  if (B == 0) return MV_OK;
+  hipStream_t s = (hipStream_t)stream;
+  const float inv = 1.0f / q_scale, fz = (float)q_zero_point;
+  return N <= 208 ? launch_attn_f32<13, true>(qkv, codes, B, N, H, scale, inv, fz, s)
+                  : launch_attn_f32<17, true>(qkv, codes, B, N, H, scale, inv, fz, s);
 }

@@ -287,13 +287,7 @@ __global__ void quant_affine_kernel(const float* __restrict__ x, float* __restri
 // [qmin - zp, qmax - zp] (|c| <= 255 for 8-bit), written as bf16 -- exactly representable, so a bf16 MFMA GEMM of two
 // code tensors with fp32 accumulation IS the integer dot product (mv_gemm_nt_bf16_scaled applies scale_x * scale_w).
 // Rows are written with leading dimension ld (>= cols, padding zeroed) so the result is a valid MFMA operand.
-template <int PRE>  // PRE = 1: GELU (erf form, the unfused gelu kernel's function) applied to x first
-__device__ __forceinline__ float affine_code_one(float x, float inv, float zp, float qmin, float qmax) {
-  if (PRE == 1) x = gelu_f(x);
-  float q = rintf(x * inv) + zp;
-  q = fminf(fmaxf(q, qmin), qmax);
-  return q - zp;
-}
+// (affine_code_one / affine_i8_pack4: mv_common.h -- shared with the fused producers)
 template <int PRE, typename XT>
 __global__ void quant_affine_codes_kernel(const XT* __restrict__ x, bf16_t* __restrict__ y, long rows, int cols, int ld,
                                           float inv, int zp, int qmin, int qmax) {

@@ -61,6 +61,7 @@ struct EpiArgs {
   void* out2;
   int ld_out2;
   const int* icorr;     // int8 GEMM only: per-output-column integer added to the int32 dot product before scaling
+  float q_inv, q_zp;    // MV_EPI_GELU_Q8: 1 / scale and zero point of the next layer's quint8 quantiser
 };
 
 // 16-byte output store of the NT epilogues
@@ -192,6 +193,21 @@ __device__ __forceinline__ void nt_epilogue(f32x4 (&acc)[4][4], CT* __restrict__
         prow[i] = 1 + (m - img * ep.aux_i);
         crow[i] = (long)img * (ep.aux_i + 1) + prow[i];
       }
+    }
+    if constexpr (EPI == MV_EPI_GELU_Q8) {
+      // Linear -> GELU -> the next Linear's quint8 quantiser, on the accumulators: v is the fp32 Linear output exactly as the
+      // MV_EPI_NONE epilogue would store it, affine_i8_pack4<1> is the standalone quantiser's own function (erf GELU, rint,
+      // clamp): same int8 codes, and the [M, N] fp32 hidden tensor (2.5 GB at batch 1024) never exists
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const float v0 = fmaf(acc[i][j][0], ep.alpha, bv[j].x), v1 = fmaf(acc[i][j][1], ep.alpha, bv[j].y);
+          const float v2 = fmaf(acc[i][j][2], ep.alpha, bv[j].z), v3 = fmaf(acc[i][j][3], ep.alpha, bv[j].w);
+          *reinterpret_cast<unsigned*>(reinterpret_cast<char*>(C) + (long)(mb + i * 16) * ldc + nb + j * 16) =
+              affine_i8_pack4<1>(v0, v1, v2, v3, ep.q_inv, ep.q_zp);
+        }
+      return;
     }
     float4 ax[4][4];
     if constexpr (EPI == MV_EPI_RESIDUAL || EPI == MV_EPI_EMBED) {
@@ -1879,7 +1895,7 @@ extern "C" int mv_gemm_nt_bf16_scaled(const void* A, int lda, const void* B, int
   MV_REQUIRE(lda % 8 == 0 && ldb % 8 == 0 && lda >= ((K + 7) & ~7) && ldb >= ((K + 7) & ~7), MV_ERR_ALIGN);
   MV_REQUIRE(mv_aligned16(A) && mv_aligned16(B) && mv_aligned16(C), MV_ERR_ALIGN);
   hipStream_t s = (hipStream_t)stream;
-  EpiArgs ep{alpha, bias, aux, ld_aux, aux_i, out2, ld_out2, nullptr};
+  EpiArgs ep{alpha, bias, aux, ld_aux, aux_i, out2, ld_out2, nullptr, 0.f, 0.f};
   switch (epilogue) {
     case MV_EPI_NONE:
       return c_dtype == MV_F32 ? launch_nt<MV_EPI_NONE, float>(A, lda, B, ldb, C, ldc, M, N, K, ep, s)
@@ -1950,7 +1966,7 @@ extern "C" int mv_gemm_nt_f16(const void* A, int lda, const void* B, int ldb, vo
   MV_REQUIRE(mv_aligned16(A) && mv_aligned16(B) && mv_aligned16(C), MV_ERR_ALIGN);
   MV_REQUIRE((long)M * lda < (1L << 31) && (long)N * ldb < (1L << 31), MV_ERR_SHAPE);
   hipStream_t s = (hipStream_t)stream;
-  EpiArgs ep{1.0f, bias, aux, ld_aux, 0, out2, ld_out2, nullptr};
+  EpiArgs ep{1.0f, bias, aux, ld_aux, 0, out2, ld_out2, nullptr, 0.f, 0.f};
   switch (epilogue) {
     case MV_EPI_NONE: return launch_nt_f16<MV_EPI_NONE, float>(A, lda, B, ldb, C, ldc, M, N, K, ep, s);
     case MV_EPI_RESIDUAL:
@@ -1962,7 +1978,7 @@ extern "C" int mv_gemm_nt_f16(const void* A, int lda, const void* B, int ldb, vo
 
 extern "C" int mv_gemm_nt_i8(const void* A, int lda, const void* B, int ldb, void* C, int ldc, int c_dtype, int M, int N, int K,
                              float alpha, const float* bias, const int* icorr, int epilogue, const void* aux, int ld_aux,
-                             mv_stream_t stream) {
+                             float q_scale, int q_zero_point, mv_stream_t stream) {
   MV_REQUIRE(M >= 0 && N >= 0 && K > 0, MV_ERR_SHAPE);
   if (M == 0 || N == 0) return MV_OK;
   MV_REQUIRE(K % 256 == 0, MV_ERR_UNSUPPORTED);                       // two whole 128-byte K-tiles per 8-phase iteration
@@ -1970,9 +1986,14 @@ extern "C" int mv_gemm_nt_i8(const void* A, int lda, const void* B, int ldb, voi
   MV_REQUIRE(mv_aligned16(A) && mv_aligned16(B) && mv_aligned16(C), MV_ERR_ALIGN);
   MV_REQUIRE((long)M * lda < (1L << 32) && (long)N * ldb < (1L << 32), MV_ERR_SHAPE);
   hipStream_t s = (hipStream_t)stream;
-  EpiArgs ep{alpha, bias, aux, ld_aux, 0, nullptr, 0, icorr};
+  EpiArgs ep{alpha, bias, aux, ld_aux, 0, nullptr, 0, icorr, q_scale > 0.f ? 1.0f / q_scale : 0.f, (float)q_zero_point};
   switch (epilogue) {
+    case MV_EPI_GELU_Q8:
+      MV_REQUIRE(c_dtype == MV_I8 && q_scale > 0.f && q_zero_point >= 0 && q_zero_point <= 255, MV_ERR_UNSUPPORTED);
+      MV_REQUIRE(M % 256 == 0 && N % 256 == 0 && ldc % 4 == 0 && (reinterpret_cast<uintptr_t>(bias) & 15) == 0, MV_ERR_UNSUPPORTED);
+      return launch_nt_i8<MV_EPI_GELU_Q8, int8_t>(A, lda, B, ldb, C, ldc, M, N, K, ep, s);
     case MV_EPI_NONE:
+      MV_REQUIRE(c_dtype == MV_F32 || c_dtype == MV_BF16, MV_ERR_UNSUPPORTED);
       return c_dtype == MV_F32 ? launch_nt_i8<MV_EPI_NONE, float>(A, lda, B, ldb, C, ldc, M, N, K, ep, s)
                                : launch_nt_i8<MV_EPI_NONE, bf16_t>(A, lda, B, ldb, C, ldc, M, N, K, ep, s);
     case MV_EPI_RESIDUAL:

@@ -9,12 +9,15 @@
 
 namespace {
 
+// YT = int8_t: the output goes straight into the NEXT layer's quint8 quantiser (q_inv = 1 / scale, q_zp) and leaves as int8
+// MFMA operands q - 128: the fp32 LayerNorm output of the converted int8 model (620 MB at batch 1024) is neither written
+// nor read back.  Same expressions as the float path followed by affine_code_one: bit-identical to LayerNorm + quantiser.
 template <int VPL, typename YT>
 __global__ __launch_bounds__(256) void ln_fwd_kernel(const float* __restrict__ x, long ldx,
                                                      const float* __restrict__ gamma,
                                                      const float* __restrict__ beta, YT* __restrict__ y,
                                                      float* __restrict__ mean, float* __restrict__ rstd, int rows,
-                                                     int dim, float eps) {
+                                                     int dim, float eps, float q_inv = 0.f, float q_zp = 0.f) {
   const int lane = threadIdx.x & 63;
   const int wave = threadIdx.x >> 6;
   const int nvec = dim >> 2;
@@ -40,7 +43,7 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const float* __restrict__ x
       }
     }
     const float rs = rsqrtf(wave_sum(q) * inv_dim + eps);
-    if (lane == 0) {
+    if (lane == 0 && mean) {
       mean[row] = mu;
       rstd[row] = rs;
     }
@@ -53,7 +56,9 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const float* __restrict__ x
         const float4 b = reinterpret_cast<const float4*>(beta)[c];
         const float o0 = (v[i].x - mu) * rs * g.x + b.x, o1 = (v[i].y - mu) * rs * g.y + b.y;
         const float o2 = (v[i].z - mu) * rs * g.z + b.z, o3 = (v[i].w - mu) * rs * g.w + b.w;
-        if constexpr (sizeof(YT) == 4) {
+        if constexpr (sizeof(YT) == 1) {
+          reinterpret_cast<unsigned*>(yr)[c] = affine_i8_pack4<0>(o0, o1, o2, o3, q_inv, q_zp);
+        } else if constexpr (sizeof(YT) == 4) {
           reinterpret_cast<float4*>(yr)[c] = make_float4(o0, o1, o2, o3);
         } else {
           bf16x4 o = {(bf16_t)o0, (bf16_t)o1, (bf16_t)o2, (bf16_t)o3};
@@ -219,6 +224,26 @@ extern "C" int mv_layernorm_fwd(const float* x, long ldx, const float* gamma, co
         ln_fwd_kernel<16, float><<<grid, 256, 0, s>>>(x, ldx, gamma, beta, (float*)y, mean, rstd, rows, dim, eps);
       else
         ln_fwd_kernel<16, bf16_t><<<grid, 256, 0, s>>>(x, ldx, gamma, beta, (bf16_t*)y, mean, rstd, rows, dim, eps);
+  }
+  MV_CHECK_LAUNCH();
+  return MV_OK;
+}
+
+extern "C" int mv_layernorm_fwd_q8(const float* x, long ldx, const float* gamma, const float* beta, void* codes, int rows,
+                                   int dim, float eps, float scale, int zero_point, mv_stream_t stream) {
+  MV_REQUIRE(rows >= 0 && dim > 0 && dim % 16 == 0 && dim <= 1024 && ldx % 4 == 0 && scale > 0.f, MV_ERR_SHAPE);
+  MV_REQUIRE(zero_point >= 0 && zero_point <= 255, MV_ERR_UNSUPPORTED);
+  MV_REQUIRE(mv_aligned16(x) && mv_aligned16(gamma) && mv_aligned16(beta) && mv_aligned16(codes), MV_ERR_ALIGN);
+  if (rows == 0) return MV_OK;
+  hipStream_t s = (hipStream_t)stream;
+  int grid = mv_cdiv(rows, 4);
+  if (grid > 2048) grid = 2048;
+  const float inv = 1.0f / scale, fz = (float)zero_point;
+  switch (mv_cdiv(dim / 4, 64)) {
+    case 1: ln_fwd_kernel<1, int8_t><<<grid, 256, 0, s>>>(x, ldx, gamma, beta, (int8_t*)codes, nullptr, nullptr, rows, dim, eps, inv, fz); break;
+    case 2: ln_fwd_kernel<2, int8_t><<<grid, 256, 0, s>>>(x, ldx, gamma, beta, (int8_t*)codes, nullptr, nullptr, rows, dim, eps, inv, fz); break;
+    case 3: ln_fwd_kernel<3, int8_t><<<grid, 256, 0, s>>>(x, ldx, gamma, beta, (int8_t*)codes, nullptr, nullptr, rows, dim, eps, inv, fz); break;
+    default: ln_fwd_kernel<4, int8_t><<<grid, 256, 0, s>>>(x, ldx, gamma, beta, (int8_t*)codes, nullptr, nullptr, rows, dim, eps, inv, fz); break;
   }
   MV_CHECK_LAUNCH();
   return MV_OK;

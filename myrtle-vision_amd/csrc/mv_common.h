@@ -70,6 +70,29 @@ __device__ __forceinline__ float dgelu_f(float x) {
   return cdf + x * pdf;
 }
 
+// Per-tensor affine quantiser (torch.fake_quantize_per_tensor_affine / MinMaxObserver qparams): the integer code q - zp of x.
+// PRE = 1: GELU (erf form, the unfused gelu kernel's function) applied to x first.  ONE definition for the standalone
+// quantiser kernels and for the producers that fuse it into their epilogue, so fused and unfused paths agree bit for bit.
+template <int PRE>
+__device__ __forceinline__ float affine_code_one(float x, float inv, float zp, float qmin, float qmax) {
+  if (PRE == 1) x = gelu_f(x);
+  float q = rintf(x * inv) + zp;
+  q = fminf(fmaxf(q, qmin), qmax);
+  return q - zp;
+}
+// four quint8 values as int8 operands q - 128 of the int8 MFMA, packed little-endian into one dword
+template <int PRE>
+__device__ __forceinline__ unsigned affine_i8_pack4(float a, float b, float c, float d, float inv, float fz) {
+  const float e[4] = {a, b, c, d};
+  unsigned w = 0u;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int code = (int)(affine_code_one<PRE>(e[j], inv, fz, 0.f, 255.f) + fz) - 128;
+    w |= ((unsigned)code & 0xFFu) << (8 * j);
+  }
+  return w;
+}
+
 // Direct global -> LDS copy (LDS-DMA), 16 bytes per lane: the LDS destination is a WAVE-UNIFORM base (M0) + lane * 16,
 // so a wave-instruction fills 1 KiB of consecutive LDS; any swizzle goes on the per-lane SOURCE address.  Counted in
 // vmcnt; nothing orders it against ds_reads except an explicit s_waitcnt vmcnt + barrier.

@@ -12,8 +12,8 @@ import torch  # noqa: F401  -- FIRST: brings PyTorch-ROCm's HIP runtime into the
 
 from .build import LIB_PATH
 
-MV_F32, MV_BF16 = 0, 1
-EPI_NONE, EPI_GELU, EPI_RESIDUAL, EPI_DGELU, EPI_EMBED, EPI_GELU_GRAD, EPI_MUL = 0, 1, 2, 3, 4, 5, 6
+MV_F32, MV_BF16, MV_I8 = 0, 1, 2
+EPI_NONE, EPI_GELU, EPI_RESIDUAL, EPI_DGELU, EPI_EMBED, EPI_GELU_GRAD, EPI_MUL, EPI_GELU_Q8 = 0, 1, 2, 3, 4, 5, 6, 7
 
 _P, _I, _L, _F, _Z = ctypes.c_void_p, ctypes.c_int, ctypes.c_long, ctypes.c_float, ctypes.c_size_t
 _KIND = {"p": _P, "i": _I, "l": _L, "f": _F, "z": _Z, "Q": ctypes.c_uint64}
@@ -32,7 +32,9 @@ SIGNATURES = {
     "mv_quant_float_f16": ("pp" "l" "p", _I),
     "mv_gemm_nt_f16": ("pipipi" "iii" "p" "i" "pi" "pi" "p", _I),
     "mv_quant_affine_i8": ("pip" "lii" "f" "ii" "p", _I),
-    "mv_gemm_nt_i8": ("pipipii" "iii" "f" "pp" "i" "pi" "p", _I),
+    "mv_gemm_nt_i8": ("pipipii" "iii" "f" "pp" "i" "pi" "fi" "p", _I),
+    "mv_layernorm_fwd_q8": ("plppp" "ii" "ff" "i" "p", _I),
+    "mv_attention_fwd_f32_q8": ("pp" "iii" "f" "f" "i" "p", _I),
     "mv_gemm_tn_bf16": ("pipipi" "iii" "i" "p" "pz" "p", _I),
     "mv_gemm_f32": ("pllll" "pllll" "pllll" "iii" "ii" "fi" "pi" "pli" "pl" "p", _I),
     "mv_gemm_f32_force_fma": ("i", _I),

@@ -621,16 +621,40 @@ def linear_i8_supported(M, N, K):
     return K % 256 == 0 and M >= 256 and N >= 256
 
 
-def linear_i8(x8, w8, M, N, K, alpha, bias, icorr, out, residual=None):
+def linear_i8(x8, w8, M, N, K, alpha, bias, icorr, out, residual=None, gelu_q8=None):
     """out (fp32 or bf16) [M, N] = alpha * (x8 [M, pad16(K)] . w8 [N, pad16(K)]^T + icorr[N]) + bias (+ residual fp32):
-    int8 operands on v_mfma_i32_16x16x64_i8, int32 accumulation."""
+    int8 operands on v_mfma_i32_16x16x64_i8, int32 accumulation.  ``gelu_q8 = (scale, zero_point)`` of the NEXT layer's
+    quint8 quantiser: ``out`` is int8 [M, N] and receives that quantiser's codes (q - 128) of gelu(the product)."""
     t0 = _timer.begin() if _timer is not None else None
     epi, aux, ld_aux = (EPI_RESIDUAL, _p(residual), N) if residual is not None else (EPI_NONE, None, 0)
-    check(lib().mv_gemm_nt_i8(_p(x8), x8.shape[1], _p(w8), w8.shape[1], _p(out), N, _DT[out.dtype], M, N, K, float(alpha),
-                              _p(bias), _p(icorr), epi, aux, ld_aux, _s()), "gemm_nt_i8", M=M, N=N, K=K)
+    cdt, qs, qz = _DT.get(out.dtype), 0.0, 0
+    if gelu_q8 is not None:
+        if residual is not None or out.dtype != torch.int8:
+            raise ValueError("gelu_q8 needs an int8 output and no residual")
+        epi, cdt, qs, qz = _l.EPI_GELU_Q8, _l.MV_I8, float(gelu_q8[0]), int(gelu_q8[1])
+    check(lib().mv_gemm_nt_i8(_p(x8), x8.shape[1], _p(w8), w8.shape[1], _p(out), N, cdt, M, N, K, float(alpha),
+                              _p(bias), _p(icorr), epi, aux, ld_aux, qs, qz, _s()), "gemm_nt_i8", M=M, N=N, K=K, epi=epi)
     if t0 is not None:
         _timer.end("gemm_nt_i8", t0, 2.0 * M * N * K, shape=f"i8 N{N} K{K} epi{epi}")
     return out
+
+
+def layernorm_q8(x, ldx, rows, dim, gamma, beta, eps, scale, zero_point):
+    """LayerNorm whose output goes straight into a quint8 quantiser: -> int8 codes (q - 128) [rows, dim]."""
+    require_cuda(x, gamma, beta)
+    codes = torch.empty(rows, dim, dtype=torch.int8, device=x.device)
+    check(lib().mv_layernorm_fwd_q8(_p(x), ldx, _p(gamma), _p(beta), _p(codes), rows, dim, float(eps), float(scale),
+                                    int(zero_point), _s()), "layernorm_fwd_q8", rows=rows, dim=dim)
+    return codes
+
+
+def attention_fwd_f32_q8(qkv, B, N, H, scale, q_scale, q_zero_point):
+    """Exact fp32 attention core whose output goes straight into a quint8 quantiser: -> int8 codes [B, N, H*64]."""
+    require_cuda(qkv)
+    codes = torch.empty(B, N, H * 64, dtype=torch.int8, device=qkv.device)
+    check(lib().mv_attention_fwd_f32_q8(_p(qkv), _p(codes), B, N, H, scale, float(q_scale), int(q_zero_point), _s()),
+          "attention_fwd_f32_q8", B=B, N=N, H=H)
+    return codes
 
 
 def minmax_update(x, state):

@@ -91,6 +91,13 @@ def _int8_linear(m):
     return m
 
 
+def _int8_fusable(x, norm, first, second, M):
+    """Both Int8Linears of a converted block take int8 codes, nothing needs a gradient, the norm is a plain LayerNorm."""
+    return (type(first).fuse_quant and not (torch.is_grad_enabled() and x.requires_grad) and x.is_cuda
+            and x.dtype == torch.float32 and _plain(norm, LayerNorm) and norm.weight.shape[0] % 16 == 0
+            and norm.weight.shape[0] <= 1024 and first.takes_codes(M) and second.takes_codes(M))
+
+
 # ---- reference vit.py:17-27 ---------------------------------------------------------------------------------
 class Residual(nn.Module):
     def __init__(self, fn: nn.Module):
@@ -122,10 +129,15 @@ class Residual(nn.Module):
         if type(inner) is FeedForward and inner.fusable():
             fc1, fc2 = inner.net[0], inner.net[3]
             return F.mlp_block(x, pn.norm.weight, pn.norm.bias, fc1.weight, fc1.bias, fc2.weight, fc2.bias, prec)
-        # converted PyTorchINT8 blocks: the residual add rides in the second GEMM's epilogue
+        # converted PyTorchINT8 blocks: the residual add rides in the second GEMM's epilogue, and without autograd every
+        # quantiser is fused into the kernel that produces its input (int8_fused_forward)
         if type(inner) is Attention and inner.int8_pair() is not None:
-            return inner.int8_forward(pn.norm(x), residual=x)
+            fused = inner.int8_fused_forward(x, pn.norm)
+            return fused if fused is not None else inner.int8_forward(pn.norm(x), residual=x)
         if type(inner) is FeedForward and inner.int8_pair() is not None:
+            fused = inner.int8_fused_forward(x, pn.norm)
+            if fused is not None:
+                return fused
             fc1, fc2 = inner.int8_pair()
             return fc2(fc1(pn.norm(x)), pre_gelu=True, residual=x)
         return None
@@ -171,6 +183,20 @@ class FeedForward(nn.Module):
             return fc1, fc2
         return None
 
+    def int8_fused_forward(self, x, norm):
+        """Converted PyTorchINT8 MLP block without autograd, quantisers fused into their producers (bit-identical to the
+        module path): LayerNorm writes fc1's int8 codes, fc1's epilogue applies GELU and fc2's quantiser and writes int8,
+        fc2's epilogue adds the residual.  No fp32 activation but the residual stream touches memory.  None if n/a."""
+        fc1, fc2 = self.int8_pair()
+        B, T, D = x.shape
+        M = B * T
+        if (not _int8_fusable(x, norm, fc1, fc2, M)) or M % 256 != 0 or fc1.weight.shape[0] % 256 != 0:
+            return None
+        x = x.contiguous()
+        x8 = ops.layernorm_q8(x, D, M, D, norm.weight, norm.bias, norm.eps, *fc1.qparams)
+        h8 = fc1.forward_codes(x8, M, gelu_q8=fc2.qparams)
+        return fc2.forward_codes(h8, M, residual=x).view(B, T, D)
+
     def forward(self, x: torch.Tensor):
         pair = self.int8_pair()
         if pair is not None:
@@ -215,6 +241,22 @@ class Attention(nn.Module):
                 and not self.attn_output._forward_hooks and self.dequant_qkv.plain() and self.quant_out.plain()):
             return lq, lo
         return None
+
+    def int8_fused_forward(self, x, norm):
+        """Converted PyTorchINT8 attention block without autograd, quantisers fused into their producers (bit-identical to
+        the module path): LayerNorm writes to_qkv's int8 codes, the exact-fp32 attention core writes to_out's, to_out's
+        epilogue adds the residual.  None if not applicable."""
+        lq, lo = self.int8_pair()
+        B, T, D = x.shape
+        M = B * T
+        dh = lq.weight.shape[0] // (3 * self.heads)
+        if (not _int8_fusable(x, norm, lq, lo, M)) or self.bf16_core or not ops.attention_f32_fused_supported(torch.float32, T, dh):
+            return None
+        x = x.contiguous()
+        x8 = ops.layernorm_q8(x, D, M, D, norm.weight, norm.bias, norm.eps, *lq.qparams)
+        qkv = lq.forward_codes(x8, M)
+        o8 = ops.attention_fwd_f32_q8(qkv, B, T, self.heads, self.scale, *lo.qparams)
+        return lo.forward_codes(o8.view(M, -1), M, residual=x).view(B, T, D)
 
     def int8_forward(self, x, residual=None):
         """Converted PyTorchINT8 attention in three GEMM-side fusions: to_qkv writes bf16 directly when the bf16 core is

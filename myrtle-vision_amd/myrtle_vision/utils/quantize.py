@@ -277,6 +277,29 @@ class Int8Linear(nn.Linear):
 
     precision = "fp32"
     use_i8 = True          # False: integer codes on the bf16 MFMA for every shape (the round-1 path; A/B tests)
+    fuse_quant = True      # False: never fuse the neighbouring quantisers into LayerNorm / attention / fc1 (A/B tests)
+
+    @property
+    def qparams(self):
+        """(scale, zero_point) of this layer's input quantiser (frozen quint8 MinMaxObserver)."""
+        return self.act_observer.frozen
+
+    def takes_codes(self, M):
+        """True if ``forward_codes`` applies: int8 MFMA path, quint8 input quantiser, K a multiple of 16 (no padding)."""
+        N, K = self.weight.shape
+        return (Int8Linear.use_i8 and getattr(self, "weight_i8", None) is not None and self.act_observer.qmin == 0
+                and self.act_observer.qmax == 255 and K % 16 == 0 and ops.linear_i8_supported(M, N, K))
+
+    def forward_codes(self, x8, M, residual=None, gelu_q8=None):
+        """The layer on an input that already IS this layer's int8 codes (a producer fused the quantiser): [M, K] int8 ->
+        fp32 [M, N] (+ residual), or with ``gelu_q8 = next.qparams`` the next layer's codes of gelu(output), int8 [M, N]."""
+        N, K = self.weight.shape
+        s_x, _ = self.act_observer.frozen
+        out = torch.empty(M, N, dtype=torch.int8 if gelu_q8 is not None else torch.float32, device=x8.device)
+        res = None if residual is None else residual.detach().float().contiguous().view(M, N)
+        ops.linear_i8(x8, self.weight_i8, M, N, K, s_x * self.weight_scale, self.bias, self.weight_icorr, out, residual=res,
+                      gelu_q8=gelu_q8)
+        return out
 
     @classmethod
     def from_observed(cls, lin, act_observer, weight_scale):

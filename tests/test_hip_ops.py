@@ -899,6 +899,70 @@ def test_fp16_qat_model_f16_forward_equals_fp32_path():
     assert len(seen) == 1 + 4 * 2                    # patch embedding + (qkv, proj, fc1, fc2) x 2 blocks; the head has M = 4
 
 
+def test_fused_quantiser_producers_are_bit_identical(ops):
+    """LayerNorm / exact-fp32 attention / int8-GEMM+GELU with the NEXT layer's quint8 quantiser fused in produce the same
+    int8 codes as producer + mv_quant_affine_i8 (one shared device function, same expressions)."""
+    M, D, H = 1024, 768, 12
+    x = (torch.randn(M, D, generator=g(1)) * 2 + 0.5).cuda()
+    gam, bet = (1 + 0.1 * torch.randn(D, generator=g(2))).cuda(), (0.1 * torch.randn(D, generator=g(3))).cuda()
+    s, z = 0.0123, 117
+    y, _, _ = ops.layernorm_fwd(x, D, M, D, gam, bet, torch.float32)
+    assert torch.equal(ops.layernorm_q8(x, D, M, D, gam, bet, 1e-5, s, z), ops.quant_affine_i8(y, M, D, s, z))
+    B, N = 4, 197
+    qkv = (torch.randn(B, N, 3 * H * 64, generator=g(4)) * 1.5).cuda()
+    o = ops.attention_fwd_f32(qkv, B, N, H, 0.125)
+    s2, z2 = 0.004, 131
+    assert torch.equal(ops.attention_fwd_f32_q8(qkv, B, N, H, 0.125, s2, z2).view(B * N, H * 64),
+                       ops.quant_affine_i8(o.view(B * N, H * 64), B * N, H * 64, s2, z2))
+    # int8 GEMM -> GELU -> next quantiser
+    Mg, Ng, K = 1024, 3072, 768
+    x8 = torch.randint(-128, 128, (Mg, K), generator=g(5), dtype=torch.int8).cuda()
+    w8 = torch.randint(-127, 128, (Ng, K), generator=g(6), dtype=torch.int8).cuda()
+    bias, icorr = torch.randn(Ng, generator=g(7)).cuda(), torch.randint(-5000, 5000, (Ng,), generator=g(8), dtype=torch.int32).cuda()
+    alpha = 3.1e-4
+    h = torch.empty(Mg, Ng, device="cuda")
+    ops.linear_i8(x8, w8, Mg, Ng, K, alpha, bias, icorr, h)
+    s3, z3 = 0.02, 9
+    h8 = torch.empty(Mg, Ng, dtype=torch.int8, device="cuda")
+    ops.linear_i8(x8, w8, Mg, Ng, K, alpha, bias, icorr, h8, gelu_q8=(s3, z3))
+    assert torch.equal(h8, ops.quant_affine_i8(h, Mg, Ng, s3, z3, pre_gelu=True))
+
+
+def test_int8_blocks_with_fused_quantisers_equal_module_path():
+    """Converted PyTorchINT8 ViT at ViT-B width, batch 256 (M = 50 432 = 197 x 256 rows): with every quantiser fused into its
+    producer (LayerNorm -> int8, attention -> int8, fc1 epilogue GELU -> int8) the logits are bit-identical to the path that
+    writes fp32 activations and quantises them in separate kernels."""
+    from myrtle_vision.models.vit import ViT
+    from myrtle_vision.utils.quantize import Int8Linear
+    from myrtle_vision.utils.utils import seed_everything
+    from myrtle_vision.hip import ops as _ops
+    seed_everything(3)
+    vit = ViT(precision="bf16", q_format="PyTorchINT8", decoder="classification", image_size=224, patch_size=16, num_classes=1000,
+              dim=768, depth=2, heads=12, mlp_dim=3072, dropout=0.0, emb_dropout=0.0).cuda()
+    gen = torch.Generator().manual_seed(4)
+    vit.train()
+    with torch.no_grad():
+        vit(torch.randn(8, 3, 224, 224, generator=gen).cuda())
+    vit.convert()
+    vit.eval()
+    img = torch.randn(256, 3, 224, 224, generator=gen).cuda()
+    seen, orig = [], _ops.layernorm_q8
+    _ops.layernorm_q8 = lambda *a, **k: (seen.append(1), orig(*a, **k))[1]
+    try:
+        with torch.no_grad():
+            fused = vit(img)
+            assert len(seen) == 4                        # two blocks x (attention, MLP)
+            Int8Linear.fuse_quant = False
+            try:
+                plain = vit(img)
+            finally:
+                Int8Linear.fuse_quant = True
+            assert len(seen) == 4
+    finally:
+        _ops.layernorm_q8 = orig
+    assert torch.equal(fused, plain)
+
+
 def test_int8_converted_model_fast_path_equals_fake_quant_path():
     """ViT.convert() for PyTorchINT8 installs Int8Linear: under no_grad it runs integer codes through the MFMA GEMM; with
     grad enabled it runs the fp32 fake-quant (straight-through) path.  Same numbers up to fp32 summation order."""
