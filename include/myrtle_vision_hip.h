@@ -115,6 +115,8 @@ int mv_gemm_f32(const float* A, long sa_m, long sa_k, long sa_b1, long sa_b2, co
 /* out[i] (+)= sum_s slabs[s * stride + i], s in fixed order: the deterministic reduce of a product whose contraction was
  * split over mv_gemm_f32's batch dimension (dW = dY^T X has 50 432 contraction rows and only 36-144 output tiles) */
 int mv_sum_slabs(const float* slabs, long stride, int S, float* out, long n, int accumulate, mv_stream_t stream);
+/* out[i] = (add ? add[i] : 0) + sum over s of slabs[s * stride + i]; add may alias out */
+int mv_sum_slabs_add(const float* slabs, long stride, int S, const float* add, float* out, long n, mv_stream_t stream);
 /* Test / tuning hook (no reference counterpart; the second piece of process-global state next to mv_gemm_force_variant):
  * 1 = mv_gemm_f32 runs its FMA kernel, 0 (default; MV_GEMM_F32=fma in the environment starts with 1) = the f32-input MFMA
  * kernels, 2 = matrix cores but only the generic (any stride, any size) kernel.  All compute the same k-ordered fmaf chain
@@ -154,6 +156,25 @@ int mv_gather_patch_rows(const float* src, void* dst, int dst_dtype, int B, int 
 /* ---- casts / layout ---- */
 /* dst (dst_dtype) = src (src_dtype), n elements */
 int mv_cast(const void* src, int src_dtype, void* dst, int dst_dtype, long n, mv_stream_t stream);
+/* fp32 -> three bf16 pieces for the "bf16x6" fp32 product (the fp32 arithmetic mode of nn.Linear, vit.py:48-51,72-74, on
+ * the bf16 matrix cores): x = p0 + p1 + p2 to 2^-26 |x|; writes the six segments of one operand, ``seg`` elements apart,
+ * in the order role 0 (left operand): p0 p0 p1 p0 p1 p2, role 1 (right operand): p0 p1 p0 p2 p1 p0, so that a bf16 product
+ * contracting over all six segments equals the fp32 product to 2^-25 relative.  out row stride ldo; seg = cols with
+ * ldo = 6 * cols lays the segments side by side along the contraction axis of an NT product, seg = rows * ldo stacks
+ * them along the rows (TN product).  cols, ldx, ldo, seg multiples of 4; x and out 16-byte aligned. */
+int mv_split3_bf16(const float* x, long ldx, void* out, long ldo, long seg, long rows, int cols, int role,
+                   mv_stream_t stream);
+/* K-split form of mv_gemm_nt_bf16 for products with few output tiles and a long contraction (the bf16x6 products with a
+ * 768-wide output at batch 64: 150 tiles of 256x256 on 256 CUs): slabs[s] (fp32 [M, N], dense, s < splits) = A[:, slice s]
+ * B[:, slice s]^T, the bias added to slab 0; sum with mv_sum_slabs_add.  K % (128 * splits) == 0, N % 4 == 0. */
+int mv_gemm_nt_bf16_ksplit(const void* A, int lda, const void* B, int ldb, float* slabs, int M, int N, int K, int splits,
+                           const float* bias, mv_stream_t stream);
+/* dW of an fp32 nn.Linear as a bf16x6 product: A6 = the role-0 side-by-side split (seg = cols, ldo = 6 * cols) of dY
+ * [rows, M], B6 = that of X [rows, N]; C[M, N] (fp32, row stride ldc) = dY^T X to fp32 accuracy.  The kernel addresses the
+ * six piece pairings inside the two buffers itself, so the splits made for the dX / forward products are reused as they
+ * are.  M, N multiples of 8, rows a multiple of 32; workspace as mv_gemm_tn_workspace_bytes(M, N, 6 * rows). */
+int mv_gemm_tn_bf16_x6(const void* A6, const void* B6, float* C, int ldc, int M, int N, int rows, float* workspace,
+                       size_t workspace_bytes, mv_stream_t stream);
 /* weight prep for the MFMA path: w fp32 [R, C] -> w_bf16 [R, ldw] and wt_bf16 [C, ldt] (transposed), pads zeroed;
  * either output may be NULL */
 int mv_weight_prep(const float* w, void* w_bf16, int ldw, void* wt_bf16, int ldt, int R, int C, mv_stream_t stream);

@@ -626,11 +626,12 @@ __global__ void upsample_bwd_kernel(const float* __restrict__ dout, float* __res
 }
 
 // ---- out[i] (+)= sum over s of slabs[s * stride + i], fixed order (deterministic): the reduce of a K-split product ----
+// (`add`: optional addend read before the slabs; may alias out)
 __global__ __launch_bounds__(256) void sum_slabs_kernel(const float* __restrict__ slabs, long stride, int S,
-                                                        float* __restrict__ out, long n, int accumulate) {
+                                                        const float* add, float* out, long n) {
   const long n4 = n >> 2;
   for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long)gridDim.x * 256) {
-    float4 t = accumulate ? reinterpret_cast<const float4*>(out)[i] : make_float4(0.f, 0.f, 0.f, 0.f);
+    float4 t = add ? reinterpret_cast<const float4*>(add)[i] : make_float4(0.f, 0.f, 0.f, 0.f);
     for (int k = 0; k < S; ++k) {
       const float4 v = reinterpret_cast<const float4*>(slabs + (long)k * stride)[i];
       t.x += v.x; t.y += v.y; t.z += v.z; t.w += v.w;
@@ -638,7 +639,7 @@ __global__ __launch_bounds__(256) void sum_slabs_kernel(const float* __restrict_
     reinterpret_cast<float4*>(out)[i] = t;
   }
   for (long i = (n4 << 2) + (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
-    float t = accumulate ? out[i] : 0.f;
+    float t = add ? add[i] : 0.f;
     for (int k = 0; k < S; ++k) t += slabs[(long)k * stride + i];
     out[i] = t;
   }
@@ -830,6 +831,58 @@ extern "C" int mv_cast(const void* src, int src_dtype, void* dst, int dst_dtype,
     cast_kernel<float, float><<<grid, 256, 0, S_>>>((const float*)src, (float*)dst, n);
   else
     return MV_ERR_UNSUPPORTED;
+  MV_CHECK_LAUNCH();
+  return MV_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// fp32 -> three bf16 pieces for the bf16x6 fp32 product.  x = p0 + p1 + p2 with p0 = bf16(x), p1 = bf16(x - p0),
+// p2 = bf16(x - p0 - p1) (each subtraction exact in fp32): 3 x 8 significand bits + signs cover fp32's 24, residual
+// <= 2^-26 |x|.  a*b = sum over i + j <= 2 of a_i * b_j to 2^-25 relative (the three dropped cross terms), so one bf16 MFMA
+// product over a SIX-segment contraction axis
+//     A' = [a0 | a0 | a1 | a0 | a1 | a2]     B' = [b0 | b1 | b0 | b2 | b1 | b0]
+// is an fp32-accurate product (bf16 x bf16 is exact in the MFMA's fp32 accumulator) at 1/6 of the bf16 rate, 2.7x the
+// f32 MFMA's.  The kernel writes all six segments of one operand, `seg` elements apart: seg = cols with ldo = 6 * cols puts them
+// side by side along K (NT operands), seg = rows * ldo stacks them along the rows (TN operands, contraction over rows).
+// ---------------------------------------------------------------------------------------------------------------------
+template <int ROLE>
+__global__ __launch_bounds__(256) void split3_kernel(const float* __restrict__ x, long ldx, bf16_t* __restrict__ out, long ldo,
+                                                     long seg, long rows, int cols4) {
+  const long total = rows * cols4;
+  for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long)gridDim.x * 256) {
+    const long r = idx / cols4;
+    const int c = (int)(idx - r * cols4) * 4;
+    const float4 v = *reinterpret_cast<const float4*>(x + r * ldx + c);
+    const float in[4] = {v.x, v.y, v.z, v.w};
+    bf16x4 p[3];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const bf16_t p0 = (bf16_t)in[e];
+      const float r1 = in[e] - (float)p0;
+      const bf16_t p1 = (bf16_t)r1;
+      const float r2 = r1 - (float)p1;
+      p[0][e] = p0;
+      p[1][e] = p1;
+      p[2][e] = (bf16_t)r2;
+    }
+    constexpr int order[2][6] = {{0, 0, 1, 0, 1, 2}, {0, 1, 0, 2, 1, 0}};
+    bf16_t* o = out + r * ldo + c;
+#pragma unroll
+    for (int s = 0; s < 6; ++s) *reinterpret_cast<bf16x4*>(o + s * seg) = p[order[ROLE][s]];
+  }
+}
+
+extern "C" int mv_split3_bf16(const float* x, long ldx, void* out, long ldo, long seg, long rows, int cols, int role,
+                              mv_stream_t stream) {
+  MV_REQUIRE(rows >= 0 && cols >= 0 && (role == 0 || role == 1), MV_ERR_SHAPE);
+  if (rows == 0 || cols == 0) return MV_OK;
+  MV_REQUIRE(cols % 4 == 0 && ldx % 4 == 0 && ldo % 4 == 0 && seg % 4 == 0 && ldx >= cols && ldo >= cols, MV_ERR_ALIGN);
+  MV_REQUIRE(mv_aligned16(x) && mv_aligned16(out), MV_ERR_ALIGN);
+  const int grid = ew_grid(rows * (cols / 4));
+  if (role == 0)
+    split3_kernel<0><<<grid, 256, 0, S_>>>(x, ldx, (bf16_t*)out, ldo, seg, rows, cols / 4);
+  else
+    split3_kernel<1><<<grid, 256, 0, S_>>>(x, ldx, (bf16_t*)out, ldo, seg, rows, cols / 4);
   MV_CHECK_LAUNCH();
   return MV_OK;
 }
@@ -1087,7 +1140,17 @@ extern "C" int mv_sum_slabs(const float* slabs, long stride, int S, float* out, 
   MV_REQUIRE(S >= 1 && n >= 0 && stride >= n && (stride & 3) == 0, MV_ERR_SHAPE);
   MV_REQUIRE(mv_aligned16(slabs) && mv_aligned16(out), MV_ERR_ALIGN);
   if (n == 0) return MV_OK;
-  sum_slabs_kernel<<<ew_grid((n + 3) / 4), 256, 0, S_>>>(slabs, stride, S, out, n, accumulate);
+  sum_slabs_kernel<<<ew_grid((n + 3) / 4), 256, 0, S_>>>(slabs, stride, S, accumulate ? out : nullptr, out, n);
+  MV_CHECK_LAUNCH();
+  return MV_OK;
+}
+
+extern "C" int mv_sum_slabs_add(const float* slabs, long stride, int S, const float* add, float* out, long n,
+                                mv_stream_t stream) {
+  MV_REQUIRE(S >= 1 && n >= 0 && stride >= n && (stride & 3) == 0, MV_ERR_SHAPE);
+  MV_REQUIRE(mv_aligned16(slabs) && mv_aligned16(out) && mv_aligned16(add), MV_ERR_ALIGN);
+  if (n == 0) return MV_OK;
+  sum_slabs_kernel<<<ew_grid((n + 3) / 4), 256, 0, S_>>>(slabs, stride, S, add, out, n);
   MV_CHECK_LAUNCH();
   return MV_OK;
 }

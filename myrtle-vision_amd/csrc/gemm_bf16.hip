@@ -62,6 +62,10 @@ struct EpiArgs {
   int ld_out2;
   const int* icorr;     // int8 GEMM only: per-output-column integer added to the int32 dot product before scaling
   float q_inv, q_zp;    // MV_EPI_GELU_Q8: 1 / scale and zero point of the next layer's quint8 quantiser
+  // K-split launches of gemm_nt_8phase_kernel<.., KSPLIT = true>: work item t covers output tile t % ks_tiles over the
+  // contraction slice t / ks_tiles (ks_len elements long) and writes slab t / ks_tiles (ks_slab elements apart)
+  int ks_tiles, ks_len;
+  long ks_slab;
 };
 
 // 16-byte output store of the NT epilogues
@@ -831,7 +835,7 @@ typedef __attribute__((ext_vector_type(4))) int i32x4;
 constexpr int NT_BF16 = 0, NT_I8 = 1, NT_F16 = 2;
 typedef __attribute__((ext_vector_type(8))) _Float16 f16x8;
 
-template <int EPI, typename CT, int OPK = NT_BF16>
+template <int EPI, typename CT, int OPK = NT_BF16, bool KSPLIT = false>
 __global__ __launch_bounds__(512, 2) void gemm_nt_8phase_kernel(const bf16_t* __restrict__ A, int lda,
                                                                 const bf16_t* __restrict__ B, int ldb, CT* __restrict__ C,
                                                                 int ldc, int M, int N, int K, int tiles_n, EpiArgs ep,
@@ -856,6 +860,14 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_8phase_kernel(const bf16_t* __
     half = idx & 1;
   }
   const bool is_half = half >= 0;                // wave-uniform
+  if constexpr (KSPLIT) {                        // K = the slice length; the bias rides on slice 0 only
+    const int ks = t / ep.ks_tiles;
+    t -= ks * ep.ks_tiles;
+    A += (long)ks * ep.ks_len;
+    B += (long)ks * ep.ks_len;
+    C += (long)ks * ep.ks_slab;
+    if (ks) ep.bias = nullptr;
+  }
   const int m0 = (t / tiles_n) * BM2 + (is_half ? 128 * half : 0), n0 = (t % tiles_n) * BN2;
 
   // staging: wave w moves pieces 2w and 2w+1 of a slot (1 KiB = 8 slot rows of 128 B each); lane l -> row l>>3, 16-byte
@@ -1564,11 +1576,18 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_glds_kernel(const bf16_t* __re
 // ------------------------------------------------------------------------------------------------
 // Same structure as gemm_nt_ring_kernel.  Each operand stage is two PANELS of [32 kc][128 cols] (256-byte rows, the
 // sw256 image, transposed fragment reads conflict-free); wave (wm, wn) reads A panel wm and half of B panel wn>>1.
-template <int S>
+// SEG (the bf16x6 fp32 product, mv_gemm_tn_bf16_x6): the contraction runs over six SEGMENTS of `seg.tiles` stages each; segment
+// s of A starts seg.a[s] elements into A (a column block of the side-by-side split3 layout), likewise B -- the stage
+// addresses follow the table instead of one linear walk, nothing else changes.
+struct TnSeg {
+  int tiles;
+  int a[6], b[6];
+};
+template <int S, bool SEG = false>
 __global__ __launch_bounds__(512, 2) void gemm_tn_ring_kernel(const bf16_t* __restrict__ A, int lda,
                                                               const bf16_t* __restrict__ B, int ldb, float* __restrict__ C,
                                                               long ldc, long slab_stride, int M, int N, int Kc, int tiles_n,
-                                                              int tiles_mn, int steps_per_split) {
+                                                              int tiles_mn, int steps_per_split, TnSeg seg) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave >> 2, wn = wave & 3;
@@ -1590,19 +1609,34 @@ __global__ __launch_bounds__(512, 2) void gemm_tn_ring_kernel(const bf16_t* __re
     const int row = 8 * (wave & 3) + 4 * i + (lane >> 4);
     const int ch = (lane & 15) ^ (((row & 3) << 2) | ((row >> 2) & 3));
     const int col = 128 * (wave >> 2) + ch * 8;
-    const int ca = (m0 + col + 8 <= lda) ? m0 + col : 0, cb = (n0 + col + 8 <= ldb) ? n0 + col : 0;
-    pa[i] = A + (long)(kt0 * BKR + row) * lda + ca;
-    pb[i] = B + (long)(kt0 * BKR + row) * ldb + cb;
+    // SEG: a segment is M (N) columns wide, the row stride covers all six
+    const int wa = SEG ? ((M + 7) & ~7) : lda, wb = SEG ? ((N + 7) & ~7) : ldb;
+    const int ca = (m0 + col + 8 <= wa) ? m0 + col : 0, cb = (n0 + col + 8 <= wb) ? n0 + col : 0;
+    pa[i] = A + (long)((SEG ? 0 : kt0 * BKR) + row) * lda + ca;
+    pb[i] = B + (long)((SEG ? 0 : kt0 * BKR) + row) * ldb + cb;
   }
   char* const wave_lds = smem + (wave >> 2) * 8192 + 8 * (wave & 3) * 256;
   const long astep = (long)BKR * lda, bstep = (long)BKR * ldb;
+  // SEG: running (segment, stage-in-segment) of the NEXT stage to issue; stages are issued strictly in order
+  int seg_s = SEG ? kt0 / seg.tiles : 0, seg_r = SEG ? kt0 - seg_s * seg.tiles : 0;
+  long seg_ao = SEG ? seg.a[seg_s] + seg_r * astep : 0, seg_bo = SEG ? seg.b[seg_s] + seg_r * bstep : 0;
 #define TNR_ISSUE(slot_, kt_)                                                          \
   {                                                                                    \
     char* la_ = wave_lds + (slot_) * RSTAGE_BYTES;                                     \
     char* lb_ = la_ + 16384;                                                           \
-    const long ao_ = (kt_) * astep, bo_ = (kt_) * bstep;                               \
+    const long ao_ = SEG ? seg_ao : (kt_) * astep, bo_ = SEG ? seg_bo : (kt_) * bstep; \
     glds16_hidden(pa[0] + ao_, la_);   glds16_hidden(pa[1] + ao_, la_ + 1024);         \
     glds16_hidden(pb[0] + bo_, lb_);   glds16_hidden(pb[1] + bo_, lb_ + 1024);         \
+    if constexpr (SEG) {                                                               \
+      seg_ao += astep;                                                                 \
+      seg_bo += bstep;                                                                 \
+      if (++seg_r == seg.tiles) {                                                      \
+        seg_r = 0;                                                                     \
+        seg_s = seg_s < 5 ? seg_s + 1 : 5;                                             \
+        seg_ao = seg.a[seg_s];                                                         \
+        seg_bo = seg.b[seg_s];                                                         \
+      }                                                                                \
+    }                                                                                  \
   }
 
   f32x4 acc[8][4];
@@ -1923,6 +1957,68 @@ extern "C" int mv_gemm_nt_bf16_scaled(const void* A, int lda, const void* B, int
   }
 }
 
+// K-split NT product for outputs with too few 256x256 tiles to fill the chip (768-wide outputs at batch 64: 150 tiles on
+// 256 CUs) and a long contraction (the bf16x6 products: 6 K): slabs[s][M][N] (fp32, dense) = A[:, s-th slice] B[:, s-th
+// slice]^T, bias added to slab 0; the caller sums the slabs (mv_sum_slabs_add).  K % (128 * splits) == 0.
+extern "C" int mv_gemm_nt_bf16_ksplit(const void* A, int lda, const void* B, int ldb, float* slabs, int M, int N, int K,
+                                      int splits, const float* bias, mv_stream_t stream) {
+  MV_REQUIRE(M > 0 && N > 0 && K > 0 && splits >= 1, MV_ERR_SHAPE);
+  MV_REQUIRE(K % (128 * splits) == 0 && N % 4 == 0, MV_ERR_UNSUPPORTED);
+  MV_REQUIRE(lda % 8 == 0 && ldb % 8 == 0 && lda >= K && ldb >= K, MV_ERR_ALIGN);
+  MV_REQUIRE(mv_aligned16(A) && mv_aligned16(B) && mv_aligned16(slabs), MV_ERR_ALIGN);
+  MV_REQUIRE((long)M * lda < (1L << 32) && (long)N * ldb < (1L << 32), MV_ERR_UNSUPPORTED);   // 32-bit staging offsets
+  static const int a8 = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_nt_8phase_kernel<MV_EPI_NONE, float, NT_BF16, true>),
+                                            hipFuncAttributeMaxDynamicSharedMemorySize, P8_SMEM) == hipSuccess ? 0 : -1;
+  if (a8) return MV_ERR_LAUNCH;
+  const int t2m = mv_cdiv(M, BM2), t2n = mv_cdiv(N, BN2);
+  const int tiles = t2m * t2n, items = tiles * splits, full = nt_full_tiles(items);
+  EpiArgs ep{1.0f, bias, nullptr, 0, 0, nullptr, 0, nullptr, 0.f, 0.f, tiles, K / splits, (long)M * N};
+  gemm_nt_8phase_kernel<MV_EPI_NONE, float, NT_BF16, true><<<full + 2 * (items - full), 512, P8_SMEM, (hipStream_t)stream>>>(
+      (const bf16_t*)A, lda, (const bf16_t*)B, ldb, slabs, N, M, N, K / splits, t2n, ep, full, 0);
+  MV_CHECK_LAUNCH();
+  return MV_OK;
+}
+
+// dW of an fp32 nn.Linear as a bf16x6 product (see mv_split3_bf16): A6 = split3(dY) [rows, 6 M], B6 = split3(X) [rows, 6 N],
+// both in the role-0 side-by-side layout (pieces p0 p0 p1 p0 p1 p2 at column blocks 0..5, so p0 / p1 / p2 sit at blocks
+// 0 / 2 / 5); C[M, N] = sum over the six pairings (0,0) (0,1) (1,0) (0,2) (1,1) (2,0) of piece_i(dY)^T piece_j(X).  The ring
+// kernel walks 6 * rows contraction rows through the segment table -- the SAME splits the dX and forward products use, no
+// stacked copies.
+extern "C" int mv_gemm_tn_bf16_x6(const void* A6, const void* B6, float* C, int ldc, int M, int N, int rows, float* workspace,
+                                  size_t workspace_bytes, mv_stream_t stream) {
+  MV_REQUIRE(M > 0 && N > 0 && rows > 0, MV_ERR_SHAPE);
+  MV_REQUIRE(M % 8 == 0 && N % 8 == 0 && rows % BKR == 0, MV_ERR_UNSUPPORTED);
+  MV_REQUIRE(mv_aligned16(A6) && mv_aligned16(B6) && mv_aligned16(C) && mv_aligned16(workspace), MV_ERR_ALIGN);
+  const int Kc = 6 * rows;
+  MV_REQUIRE(workspace_bytes >= mv_gemm_tn_workspace_bytes(M, N, Kc), MV_ERR_WORKSPACE);
+  hipStream_t s = (hipStream_t)stream;
+  const TnPlan pl = tn_plan256(M, N, Kc);
+  const int tiles_mn = pl.tiles_m * pl.tiles_n;
+  const bool direct = pl.splits == 1;
+  const long slab_stride = (long)M * N;
+  static const int a4 = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_tn_ring_kernel<4, true>),
+                                            hipFuncAttributeMaxDynamicSharedMemorySize, 4 * RSTAGE_BYTES) == hipSuccess ? 0 : -1;
+  if (a4) return MV_ERR_LAUNCH;
+  TnSeg seg;
+  seg.tiles = rows / BKR;
+  const int pa[6] = {0, 0, 1, 0, 1, 2}, pb[6] = {0, 1, 0, 2, 1, 0}, block[3] = {0, 2, 5};
+  for (int i = 0; i < 6; ++i) {
+    seg.a[i] = block[pa[i]] * M;
+    seg.b[i] = block[pb[i]] * N;
+  }
+  gemm_tn_ring_kernel<4, true><<<tiles_mn * pl.splits, 512, 4 * RSTAGE_BYTES, s>>>(
+      (const bf16_t*)A6, 6 * M, (const bf16_t*)B6, 6 * N, direct ? C : workspace, direct ? (long)ldc : (long)N,
+      direct ? 0 : slab_stride, M, N, Kc, pl.tiles_n, tiles_mn, pl.steps_per_split, seg);
+  MV_CHECK_LAUNCH();
+  if (!direct) {
+    int grid = mv_cdiv(slab_stride, 256);
+    if (grid > 2048) grid = 2048;
+    splitk_reduce_kernel<<<grid, 256, 0, s>>>(workspace, slab_stride, pl.splits, C, ldc, M, N, 0);
+    MV_CHECK_LAUNCH();
+  }
+  return MV_OK;
+}
+
 namespace {
 template <int EPI, typename CT>
 int launch_nt_i8(const void* A, int lda, const void* B, int ldb, void* C, int ldc, int M, int N, int K, EpiArgs ep,
@@ -2072,7 +2168,7 @@ extern "C" int mv_gemm_tn_bf16(const void* A, int lda, const void* B, int ldb, f
     if (a4) return MV_ERR_LAUNCH;
     gemm_tn_ring_kernel<4><<<tiles_mn * pl.splits, 512, 4 * RSTAGE_BYTES, s>>>(
         (const bf16_t*)A, lda, (const bf16_t*)B, ldb, direct ? C : workspace, direct ? (long)ldc : (long)N,
-        direct ? 0 : slab_stride, M, N, Kc, pl.tiles_n, tiles_mn, pl.steps_per_split);
+        direct ? 0 : slab_stride, M, N, Kc, pl.tiles_n, tiles_mn, pl.steps_per_split, TnSeg{});
   } else if (Kc > 0 && Kc % BK == 0)
     gemm_tn_glds_kernel<<<tiles_mn * pl.splits, 256, SMEM_BYTES, s>>>(
         (const bf16_t*)A, lda, (const bf16_t*)B, ldb, direct ? C : workspace, direct ? (long)ldc : (long)N,

@@ -14,6 +14,7 @@ The residual stream and all gradients w.r.t. parameters are fp32; activations ar
 (``prec='fp32'``: exact-parity mode).  Backward runs on autograd's worker thread: everything here is stateless
 apart from caches keyed by tensor identity.
 """
+import functools
 import weakref
 
 import torch
@@ -25,6 +26,16 @@ from .ops import EPI_DGELU, EPI_EMBED, EPI_GELU, EPI_GELU_GRAD, EPI_MUL, EPI_NON
 
 def _c(t):
     return t if t.is_contiguous() else t.contiguous()
+
+
+def _scoped(backward):
+    """Run one backward function inside ``ops.split_scope()``: its dX and dW products share the bf16x6 split of dY (fp32
+    mode; a no-op for the bf16 path)."""
+    @functools.wraps(backward)
+    def run(*args, **kwargs):
+        with ops.split_scope():
+            return backward(*args, **kwargs)
+    return run
 
 
 # ------------------------------------------------------------------------------------------------------------
@@ -45,6 +56,7 @@ class _LayerNorm(Function):
         return y.view(x.shape)
 
     @staticmethod
+    @_scoped
     def backward(ctx, dy):
         x, gamma, mean, rstd = ctx.saved_tensors
         dim = x.shape[-1]
@@ -80,6 +92,7 @@ class _Linear(Function):
         return out.view(*x.shape[:-1], N)
 
     @staticmethod
+    @_scoped
     def backward(ctx, dy):
         x2, weight = ctx.saved_tensors
         M, K = x2.shape
@@ -129,6 +142,7 @@ class _LinearQatF16(Function):
         return out.view(*x.shape[:-1], N)
 
     @staticmethod
+    @_scoped
     def backward(ctx, dy):
         x2, wq = ctx.saved_tensors
         weight, bias = ctx.params
@@ -157,6 +171,7 @@ class _Gelu(Function):
         return ops.gelu_fwd(x)
 
     @staticmethod
+    @_scoped
     def backward(ctx, dy):
         (x,) = ctx.saved_tensors
         dy = _c(dy)
@@ -176,6 +191,7 @@ class _Cast(Function):
         return ops.cast(_c(x), dtype)
 
     @staticmethod
+    @_scoped
     def backward(ctx, dy):
         return ops.cast(_c(dy), ctx.src_dtype), None
 
@@ -193,6 +209,7 @@ class _Add(Function):
         return ops.add_f32(_c(a.float()), _c(b.float()))
 
     @staticmethod
+    @_scoped
     def backward(ctx, d):
         return d, d
 
@@ -213,6 +230,7 @@ class _Dropout(Function):
         return ops.dropout(_c(x), p, seed, offset)
 
     @staticmethod
+    @_scoped
     def backward(ctx, dy):
         p, seed, offset = ctx.rng
         return ops.dropout(_c(dy), p, seed, offset), None
@@ -241,6 +259,7 @@ class _AttentionFused(Function):
         return out
 
     @staticmethod
+    @_scoped
     def backward(ctx, dout):
         qkv, out, lse = ctx.saved_tensors
         B, N, _ = qkv.shape
@@ -264,6 +283,7 @@ class _AttentionProbs(Function):
         return probs
 
     @staticmethod
+    @_scoped
     def backward(ctx, dprobs):
         qkv, probs = ctx.saved_tensors
         B, N, _ = qkv.shape
@@ -296,6 +316,7 @@ class _AttentionPV(Function):
         return ops.attention_pv_fp32(probs, qkv, B, N, heads, dh)
 
     @staticmethod
+    @_scoped
     def backward(ctx, dout):
         probs, qkv = ctx.saved_tensors
         B, N, _ = qkv.shape
@@ -362,6 +383,7 @@ class _PatchEmbed(Function):
         return x
 
     @staticmethod
+    @_scoped
     def backward(ctx, dx):
         (patches,) = ctx.saved_tensors
         B, T, D, pd, npatch = ctx.dims
@@ -476,6 +498,7 @@ class _AttnBlock(Function):
         return out
 
     @staticmethod
+    @_scoped
     def backward(ctx, dout):
         x, g, mean, rstd, y, qkv, o, lse_or_probs, wqkv, wo = ctx.saved_tensors
         heads, scale, fused = ctx.cfg
@@ -539,6 +562,7 @@ class _MlpBlock(Function):
         return out
 
     @staticmethod
+    @_scoped
     def backward(ctx, dout):
         x, g, mean, rstd, y, h, a, w1, w2 = ctx.saved_tensors
         B, T, D = x.shape
@@ -592,6 +616,7 @@ class _ClsHead(Function):
         return logits
 
     @staticmethod
+    @_scoped
     def backward(ctx, dlogits):
         x, g, mean, rstd, y, w = ctx.saved_tensors
         B, T, D = x.shape
@@ -661,6 +686,7 @@ class _UpsampleBilinear(Function):
         return ops.upsample_bilinear_fwd(small, hw * C, 1, C, B, C, grid, grid, size, size)
 
     @staticmethod
+    @_scoped
     def backward(ctx, dbig):
         B, C, grid, size = ctx.dims
         dsmall = torch.empty(B, grid * grid, C, dtype=torch.float32, device=dbig.device)
@@ -687,6 +713,7 @@ class _SegHead(Function):
         return big
 
     @staticmethod
+    @_scoped
     def backward(ctx, dbig):
         saved = ctx.saved_tensors
         B, T, D, C, grid, size = ctx.dims
@@ -727,6 +754,7 @@ class _SegHeadLoss(Function):
         return stats[0], stats[1].detach(), pred
 
     @staticmethod
+    @_scoped
     def backward(ctx, gloss, _gacc, _gpred):
         dl, *saved = ctx.saved_tensors
         B, T, D, C, ld = ctx.dims
@@ -757,6 +785,7 @@ class _CrossEntropy(Function):
         return loss.view(())
 
     @staticmethod
+    @_scoped
     def backward(ctx, g):
         (dl,) = ctx.saved_tensors
         return (dl.view(ctx.shape) * g), None
@@ -789,6 +818,7 @@ class _FakeQuant(Function):
         return y.to(dtype).view(x.shape)
 
     @staticmethod
+    @_scoped
     def backward(ctx, g):
         return g, None, None, None
 

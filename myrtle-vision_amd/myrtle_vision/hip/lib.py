@@ -39,6 +39,8 @@ SIGNATURES = {
     "mv_gemm_f32": ("pllll" "pllll" "pllll" "iii" "ii" "fi" "pi" "pli" "pl" "p", _I),
     "mv_gemm_f32_force_fma": ("i", _I),
     "mv_sum_slabs": ("pli" "pli" "p", _I),
+    "mv_sum_slabs_add": ("pli" "ppl" "p", _I),
+    "mv_gemm_nt_bf16_ksplit": ("pipip" "iiii" "p" "p", _I),
     "mv_attention_fwd": ("ppp" "iii" "f" "p", _I),
     "mv_attention_bwd": ("pppppp" "iii" "f" "p", _I),
     "mv_attention_fwd_f32": ("pp" "iii" "f" "p", _I),
@@ -49,6 +51,8 @@ SIGNATURES = {
     "mv_embed_bwd": ("ppp" "i" "iii" "p", _I),
     "mv_gather_patch_rows": ("ppi" "iii" "p", _I),
     "mv_cast": ("pipi" "l" "p", _I),
+    "mv_split3_bf16": ("plpll" "lii" "p", _I),
+    "mv_gemm_tn_bf16_x6": ("ppp" "iiii" "pz" "p", _I),
     "mv_weight_prep": ("ppipi" "ii" "p", _I),
     "mv_weight_prep_batch": ("pii" "p", _I),
     "mv_colsum": ("pil" "pi" "li" "pz" "p", _I),

@@ -8,6 +8,7 @@ Precision: ``"bf16"`` = bf16 activations and weights on MFMA with fp32 accumulat
 (the benchmark configuration); ``"fp32"`` = every contraction in fp32 FMA chains (exact-parity mode).
 """
 import ctypes
+import os
 import weakref
 
 import torch
@@ -270,6 +271,134 @@ def layernorm_bwd(dy, x, ldx, gamma, mean, rstd, dx_add, dx, lddx, rows, dim, dx
 
 
 # ------------------------------------------------------------------------------------------------------------
+# fp32 Linear products on the bf16 matrix cores ("bf16x6"): each fp32 operand is split into three bf16 pieces
+# (mv_split3_bf16) and ONE bf16 MFMA product contracts over the six piece pairings that matter; fp32-accurate (2^-25
+# relative per product, fp32 accumulation) at ~2x the f32-MFMA kernel's rate.  mv_gemm_f32 (bit-exact k-ordered fmaf
+# chain) stays the path for everything the shape rules below exclude, and for MV_F32_GEMM=mfma.
+# ------------------------------------------------------------------------------------------------------------
+_f32_gemm_mode = os.environ.get("MV_F32_GEMM", "bf16x6")
+
+
+def set_f32_gemm(mode: str) -> str:
+    """'bf16x6' (default) or 'mfma' (every fp32 product on mv_gemm_f32).  Returns the previous mode."""
+    global _f32_gemm_mode
+    if mode not in ("bf16x6", "mfma"):
+        raise ValueError(f"f32 gemm mode {mode!r}")
+    prev, _f32_gemm_mode = _f32_gemm_mode, mode
+    return prev
+
+
+def split3(x, rows, cols, ldx, role, stack=False):
+    """fp32 [rows, cols] (row stride ldx) -> its six bf16 segments: [rows, 6 * cols] side by side, or stacked
+    [6 * rows, cols] (``stack``).  role 0 = left operand of the product, 1 = right operand."""
+    require_cuda(x)
+    if stack:
+        out = torch.empty(6 * rows, cols, dtype=torch.bfloat16, device=x.device)
+        ldo, seg = cols, rows * cols
+    else:
+        out = torch.empty(rows, 6 * cols, dtype=torch.bfloat16, device=x.device)
+        ldo, seg = 6 * cols, cols
+    check(lib().mv_split3_bf16(_p(x), ldx, _p(out), ldo, seg, rows, cols, role, _s()), "split3_bf16", rows=rows, cols=cols)
+    return out
+
+
+# Activation splits shared between the dX and dW products of one backward function: inside ``split_scope()`` the last
+# two role-0 side-by-side splits are kept (with a reference to their source tensor) and reused when the same tensor and
+# geometry come again.  Nothing is remembered outside a scope, and a scope must not write into a tensor it has already
+# split (the kernels write through raw pointers: no version counter would notice).
+_split_memo = None
+
+
+class split_scope:
+    def __enter__(self):
+        global _split_memo
+        self.prev, _split_memo = _split_memo, []
+        return self
+
+    def __exit__(self, *exc):
+        global _split_memo
+        _split_memo = self.prev
+        return False
+
+
+def split_act(x, rows, cols, ldx):
+    """Role-0 side-by-side split [rows, 6 * cols] of an activation / gradient, memoised inside a ``split_scope``."""
+    if _split_memo is None:
+        return split3(x, rows, cols, ldx, 0)
+    for ent in _split_memo:
+        if ent[1] == (rows, cols, ldx, x.data_ptr()):        # ent[0] keeps that storage alive: the address cannot be reused
+            return ent[2]
+    out = split3(x, rows, cols, ldx, 0)
+    _split_memo.append((x, (rows, cols, ldx, x.data_ptr()), out))
+    if len(_split_memo) > 2:
+        _split_memo.pop(0)
+    return out
+
+
+class _SplitWeight:
+    __slots__ = ("version", "ptr", "fwd", "dx")
+
+
+_split_weights = {}
+
+
+def split_weight(weight: torch.Tensor, which: str) -> torch.Tensor:
+    """Cached right-operand splits of an nn.Linear weight [N, K]: 'fwd' -> [N, 6K] (y = x W^T), 'dx' -> [K, 6N] (the
+    transposed weight, dx = dy W); refreshed when the parameter changed."""
+    key = id(weight)
+    sw = _split_weights.get(key)
+    if sw is None or sw.version != weight._version or sw.ptr != weight.data_ptr():
+        if sw is None:
+            weakref.finalize(weight, _split_weights.pop, key, None)
+        sw = _split_weights[key] = _SplitWeight()
+        sw.version, sw.ptr, sw.fwd, sw.dx = weight._version, weight.data_ptr(), None, None
+    n_out, k_in = weight.shape
+    if which == "fwd":
+        if sw.fwd is None:
+            sw.fwd = split3(weight.detach().contiguous(), n_out, k_in, k_in, 1)
+        return sw.fwd
+    if sw.dx is None:
+        sw.dx = split3(weight.detach().t().contiguous(), k_in, n_out, n_out, 1)
+    return sw.dx
+
+
+def _x6_nt_ok(M, N, Kc):
+    """[M, N] = A[M, Kc] B[N, Kc]^T through the 8-phase kernel with a 6 * Kc contraction."""
+    return _f32_gemm_mode == "bf16x6" and M >= 128 and N % 16 == 0 and N >= 64 and Kc % 64 == 0
+
+
+def _x6_tn_ok(M, N, K):
+    """dW[N, K] = dY[M, N]^T X[M, K] through the segmented TN ring kernel with a 6 * M contraction."""
+    return _f32_gemm_mode == "bf16x6" and M % 32 == 0 and M >= 512 and N % 8 == 0 and K % 8 == 0
+
+
+def _x6_ksplits(M, N):
+    """K-split count of a bf16x6 NT product: 3 (two of the six segments per slice) when that shortens the schedule on
+    the 256 CUs by a quarter or more -- 150 tiles: one round of 6 segments -> two rounds of 2."""
+    tiles = ((M + 255) // 256) * ((N + 255) // 256)
+    r1, r3 = -(-tiles // 256), -(-(3 * tiles) // 256) / 3.0
+    return 3 if r3 <= 0.75 * r1 else 1
+
+
+def _nt_x6(a6, b6, out, ldc, M, N, Kc, bias, epi, aux=None, ld_aux=0, aux_i=0, tag="fwd"):
+    t0 = _timer.begin() if _timer is not None else None
+    S = _x6_ksplits(M, N) if epi in (EPI_NONE, EPI_RESIDUAL) and ldc == N and (aux is None or ld_aux == N) else 1
+    if S > 1:
+        slabs = workspace(S * M * N * 4, out.device)
+        check(lib().mv_gemm_nt_bf16_ksplit(_p(a6), 6 * Kc, _p(b6), 6 * Kc, _p(slabs), M, N, 6 * Kc, S, _p(bias), _s()),
+              "gemm_nt_bf16_ksplit(x6)", M=M, N=N, K=6 * Kc, S=S)
+        check(lib().mv_sum_slabs_add(_p(slabs), M * N, S, _p(aux) if epi == EPI_RESIDUAL else None, _p(out), M * N, _s()),
+              "sum_slabs_add", n=M * N)
+        if t0 is not None:
+            _timer.end("gemm_nt_bf16x6", t0, 2.0 * M * N * Kc, shape=f"{tag} N{N} K{Kc} epi{epi} S{S}")
+        return
+    check(lib().mv_gemm_nt_bf16(_p(a6), 6 * Kc, _p(b6), 6 * Kc, _p(out), ldc, MV_F32, M, N, 6 * Kc, _p(bias), epi, _p(aux),
+                                ld_aux, aux_i, None, 0, _s()), "gemm_nt_bf16(x6)", M=M, N=N, K=6 * Kc, epi=epi)
+    if t0 is not None:
+        _timer.end("gemm_nt_bf16x6", t0, 2.0 * M * N * Kc, shape=f"{tag} N{N} K{Kc} epi{epi}")
+
+
+# ------------------------------------------------------------------------------------------------------------
 # contractions.  Logical shapes: x [M, K], W [N, K] (nn.Linear layout), y [M, N]
 # ------------------------------------------------------------------------------------------------------------
 def linear_fwd(x, M, K, weight, bias, out, ldc, *, lda=None, epi=EPI_NONE, aux=None, ld_aux=0, aux_i=0, out2=None,
@@ -285,6 +414,17 @@ def linear_fwd(x, M, K, weight, bias, out, ldc, *, lda=None, epi=EPI_NONE, aux=N
               "gemm_nt_bf16", M=M, N=N, K=K, epi=epi)
         if t0 is not None:
             _timer.end("gemm_nt_bf16", t0, 2.0 * M * N * K, shape=f"fwd N{N} K{K} epi{epi}")
+    elif (_x6_nt_ok(M, N, K) and out.dtype == torch.float32 and weight.dtype == torch.float32
+          and (epi in (EPI_NONE, EPI_RESIDUAL, EPI_EMBED) and out2 is None
+               or epi == EPI_GELU and ldc == N and (out2 is None or ld_out2 == N))):
+        a6, b6 = split_act(x, M, K, lda), split_weight(weight, "fwd")
+        if epi == EPI_GELU:
+            # pre-activation (out2 when the caller keeps it) then the exact erf GELU as its own pass
+            pre = out if out2 is None else out2
+            _nt_x6(a6, b6, pre, N, M, N, K, bias, EPI_NONE)
+            check(lib().mv_gelu_fwd(_p(pre), _p(out), MV_F32, M * N, _s()), "gelu_fwd", n=M * N)
+        else:
+            _nt_x6(a6, b6, out, ldc, M, N, K, bias, epi, aux, ld_aux, aux_i)
     else:
         w = weight.detach()
         check(lib().mv_gemm_f32(_p(x), lda, 1, 0, 0, _p(w), 1, w.stride(0), 0, 0, _p(out), ldc, 1, 0, 0, M, N, K, 1, 1,
@@ -306,6 +446,11 @@ def linear_dx(dy, M, N, weight, out, ldc, *, ld_dy=None, epi=EPI_NONE, aux=None,
               "gemm_nt_bf16(dx)", M=M, N=K, K=N, epi=epi)
         if t0 is not None:
             _timer.end("gemm_nt_bf16", t0, 2.0 * M * N * K, shape=f"dx N{K} K{N} epi{epi}")
+    elif (_x6_nt_ok(M, K, N) and out.dtype == torch.float32 and weight.dtype == torch.float32
+          and (epi == EPI_NONE or epi == EPI_DGELU and ldc == K and ld_aux == K)):
+        _nt_x6(split_act(dy, M, N, ld_dy), split_weight(weight, "dx"), out, ldc, M, K, N, None, EPI_NONE, tag="dx")
+        if epi == EPI_DGELU:
+            check(lib().mv_gelu_bwd(_p(aux), _p(out), _p(out), MV_F32, M * K, _s()), "gelu_bwd", n=M * K)
     else:
         w = weight.detach()
         check(lib().mv_gemm_f32(_p(dy), ld_dy, 1, 0, 0, _p(w), w.stride(0), 1, 0, 0, _p(out), ldc, 1, 0, 0, M, K, N, 1,
@@ -329,6 +474,16 @@ def linear_dw(dy, x, M, N, K, *, ld_dy=None, ldx=None, want_bias=True, weight=No
               "gemm_tn_bf16", M=N, N=K, Kc=M)
         if t0 is not None:
             _timer.end("gemm_tn_bf16(+reduce+colsum)", t0, 2.0 * M * N * K, shape=f"dw N{N} K{K} bias{int(want_bias)}")
+    elif _x6_tn_ok(M, N, K) and dy.dtype == torch.float32 and x.dtype == torch.float32:
+        a6, b6 = split_act(dy, M, N, ld_dy), split_act(x, M, K, ldx)
+        ws = workspace(lib().mv_gemm_tn_workspace_bytes(N, K, 6 * M), x.device)
+        t0 = _timer.begin() if _timer is not None else None
+        check(lib().mv_gemm_tn_bf16_x6(_p(a6), _p(b6), _p(dw), K, N, K, M, _p(ws), ws.numel(), _s()),
+              "gemm_tn_bf16_x6", M=N, N=K, rows=M)
+        if t0 is not None:
+            _timer.end("gemm_tn_bf16x6", t0, 2.0 * M * N * K, shape=f"dw N{N} K{K}")
+        if want_bias:
+            colsum(dy, M, N, ld_dy, db)
     else:
         S = f32_dw_splits(M, N, K)
         if S == 1:

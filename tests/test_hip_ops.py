@@ -343,20 +343,86 @@ def test_gemm_f32_mfma_is_bitwise_the_fma_chain(ops, M, N, K):
         dw, db = ops.linear_dw(dy, x, M, N, K); outs += [dw, db]
         return outs
 
+    prev = ops.set_f32_gemm("mfma")                  # this test is about mv_gemm_f32, not the bf16x6 products
     try:
         lib().mv_gemm_f32_force_fma(1)
         fma = run_all()
         lib().mv_gemm_f32_force_fma(2)               # matrix cores, generic kernel only
         generic = run_all()
+        lib().mv_gemm_f32_force_fma(0)
+        mfma = run_all()                             # matrix cores, fast kernel where the shape allows
     finally:
         lib().mv_gemm_f32_force_fma(0)
-    mfma = run_all()                                 # matrix cores, fast kernel where the shape allows
+        ops.set_f32_gemm(prev)
     for i, (a, c, d) in enumerate(zip(fma, mfma, generic)):
         assert torch.equal(a, c) and torch.equal(a, d), i
     tol = 2e-6 if max(M, N, K) <= 1024 else 6e-6        # a chain of K fp32 roundings (3.5e-7 sum|ab| at K = 4096)
     assert relerr(mfma[0], x.double().cpu() @ w.double().cpu().t() + b.double().cpu()) < tol
     assert relerr(mfma[4], dy.double().cpu() @ w.double().cpu()) < tol
     assert relerr(mfma[6], dy.double().cpu().t() @ x.double().cpu()) < tol
+
+
+def test_split3_bf16_pieces_reconstruct_fp32(ops):
+    """mv_split3_bf16: the three bf16 pieces sum back to the fp32 value to 2^-26 |x| (exactly, for most values), and the six
+    segments come out in the documented order for both roles and both layouts."""
+    rows, cols = 37, 64
+    x = (torch.randn(rows, cols + 4, generator=g(1)) * torch.logspace(-12, 12, cols + 4)).cuda()
+    for role, order in ((0, (0, 0, 1, 0, 1, 2)), (1, (0, 1, 0, 2, 1, 0))):
+        side = ops.split3(x, rows, cols, cols + 4, role).view(rows, 6, cols)
+        stacked = ops.split3(x, rows, cols, cols + 4, role, stack=True).view(6, rows, cols)
+        assert torch.equal(side.permute(1, 0, 2), stacked)
+        pieces = {}
+        for s_, pi in enumerate(order):
+            pieces.setdefault(pi, stacked[s_])
+            assert torch.equal(pieces[pi], stacked[s_])
+        total = pieces[0].double() + pieces[1].double() + pieces[2].double()
+        xr = x[:, :cols].double()
+        assert ((total - xr).abs() <= xr.abs() * 2.0 ** -26).all()
+        assert torch.equal(pieces[0], x[:, :cols].to(torch.bfloat16))
+
+
+@pytest.mark.parametrize("M,N,K", [(394, 192, 192), (1600, 768, 768), (1600, 3072, 768), (1024, 768, 3072), (4096, 2304, 768)])
+def test_gemm_f32_bf16x6_is_fp32_accurate(ops, M, N, K):
+    """The bf16x6 products (three-piece bf16 split, six pairings, one bf16 MFMA product) against fp64 and against the bit-exact
+    fmaf-chain kernel: forward (+bias, +residual, +GELU with kept pre-activation), dX (+GELU'), dW/db.  Error bound: the
+    2^-25 of the dropped cross terms plus fp32 accumulation, i.e. what an fp32 product of the same length carries."""
+    x, w, b = torch.randn(M, K, generator=g(1)).cuda(), torch.randn(N, K, generator=g(2)).cuda(), torch.randn(N, generator=g(3)).cuda()
+    dy, res = torch.randn(M, N, generator=g(4)).cuda(), torch.randn(M, N, generator=g(5)).cuda()
+
+    def run_all():
+        outs = []
+        o = torch.empty(M, N, device="cuda"); ops.linear_fwd(x, M, K, w, b, o, N); outs.append(o)
+        o = torch.empty(M, N, device="cuda"); ops.linear_fwd(x, M, K, w, b, o, N, epi=ops.EPI_RESIDUAL, aux=res, ld_aux=N); outs.append(o)
+        o, h = torch.empty(M, N, device="cuda"), torch.empty(M, N, device="cuda")
+        ops.linear_fwd(x, M, K, w, b, o, N, epi=ops.EPI_GELU, out2=h, ld_out2=N); outs += [o, h]
+        o = torch.empty(M, K, device="cuda"); ops.linear_dx(dy, M, N, w, o, K); outs.append(o)
+        o = torch.empty(M, K, device="cuda"); ops.linear_dx(dy, M, N, w, o, K, epi=ops.EPI_DGELU, aux=x, ld_aux=K); outs.append(o)
+        dw, db = ops.linear_dw(dy, x, M, N, K); outs += [dw, db]
+        return outs
+
+    assert ops.set_f32_gemm("bf16x6") in ("bf16x6", "mfma")
+    x6 = run_all()
+    prev = ops.set_f32_gemm("mfma")
+    try:
+        chain = run_all()
+    finally:
+        ops.set_f32_gemm("bf16x6")
+    ref64 = [x.double() @ w.double().t() + b.double(), None, None, None, dy.double() @ w.double(), None,
+             dy.double().t() @ x.double(), dy.double().sum(0)]
+    for i, (a, c) in enumerate(zip(x6, chain)):
+        assert relerr(a, c.double()) < 5e-6, i                     # the two fp32 paths agree to fp32 accuracy
+        if ref64[i] is not None:
+            # and bf16x6 is at least as close to fp64 as twice the fmaf chain's own error
+            assert relerr(a, ref64[i]) <= max(2.0 * relerr(c, ref64[i]), 3e-7), i
+    # inside a split_scope the dX and dW products share dY's split: same bits as without sharing
+    with ops.split_scope():
+        o = torch.empty(M, K, device="cuda"); ops.linear_dx(dy, M, N, w, o, K)
+        dw, db = ops.linear_dw(dy, x, M, N, K)
+    assert torch.equal(o, x6[4]) and torch.equal(dw, x6[6]) and torch.equal(db, x6[7])
+    # weights are re-split when the parameter changes in place
+    w.mul_(2.0)
+    o = torch.empty(M, N, device="cuda"); ops.linear_fwd(x, M, K, w, b, o, N)
+    assert relerr(o, x.double() @ w.double().t() + b.double()) < 4e-6
 
 
 def test_attention_materialised_fp32_mfma_equals_fma(ops):
