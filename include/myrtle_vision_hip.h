@@ -164,6 +164,14 @@ int mv_cast(const void* src, int src_dtype, void* dst, int dst_dtype, long n, mv
  * them along the rows (TN product).  cols, ldx, ldo, seg multiples of 4; x and out 16-byte aligned. */
 int mv_split3_bf16(const float* x, long ldx, void* out, long ldo, long seg, long rows, int cols, int role,
                    mv_stream_t stream);
+/* The role-0 side-by-side split (out [rows, 6 * cols] bf16) of v, behind a producer's last elementwise step: op 0: v = x;
+ * op 1: v = gelu(x) (nn.GELU, vit.py:49: fc1's activation as the fc2 operand, the fp32 activation never stored); op 2:
+ * v = x * gelu'(h) (fc2's dX times the activation derivative).  colsum (optional, fp32 [cols]) receives the column sums of v
+ * = the bias gradient of the Linear that v is the output gradient of (deterministic two-stage sum; workspace of
+ * mv_split3_ex_workspace_bytes(rows, cols) bytes, needed only with colsum). */
+size_t mv_split3_ex_workspace_bytes(long rows, int cols);
+int mv_split3_bf16_ex(const float* x, long ldx, const float* h, long ldh, int op, void* out, long rows, int cols,
+                      float* colsum, float* workspace, size_t workspace_bytes, mv_stream_t stream);
 /* K-split form of mv_gemm_nt_bf16 for products with few output tiles and a long contraction (the bf16x6 products with a
  * 768-wide output at batch 64: 150 tiles of 256x256 on 256 CUs): slabs[s] (fp32 [M, N], dense, s < splits) = A[:, slice s]
  * B[:, slice s]^T, the bias added to slab 0; sum with mv_sum_slabs_add.  K % (128 * splits) == 0, N % 4 == 0. */

@@ -872,6 +872,85 @@ __global__ __launch_bounds__(256) void split3_kernel(const float* __restrict__ x
   }
 }
 
+// The same split behind a producer's last elementwise step, with the consumer's bias gradient as a by-product: one pass
+// instead of three or four over the 2304- / 3072-wide tensors of a block.  OP 0: v = x; OP 1: v = gelu(x) (fc1's activation:
+// the fp32 activation itself is never stored); OP 2: v = x * gelu'(h) (fc2's dX times the activation derivative).
+// A thread owns 4 columns and walks the rows of its row part (coalesced: the block's threads cover consecutive columns), so
+// the column sums of v accumulate in registers; partial[part][cols] is reduced by mv_reduce_rows_kernel (fixed order).
+template <int OP>
+__global__ __launch_bounds__(256) void split3_ex_kernel(const float* __restrict__ x, long ldx, const float* __restrict__ h,
+                                                        long ldh, bf16_t* __restrict__ out, long ldo, long seg, long rows,
+                                                        int cols4, int rows_per_part, float* __restrict__ partial) {
+  const int c4 = blockIdx.x * 256 + threadIdx.x;
+  if (c4 >= cols4) return;
+  const int c = c4 * 4;
+  const long r0 = (long)blockIdx.y * rows_per_part;
+  long r1 = r0 + rows_per_part;
+  if (r1 > rows) r1 = rows;
+  float cs[4] = {0.f, 0.f, 0.f, 0.f};
+  for (long r = r0; r < r1; ++r) {
+    const float4 v = *reinterpret_cast<const float4*>(x + r * ldx + c);
+    float in[4] = {v.x, v.y, v.z, v.w};
+    if constexpr (OP == 1) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) in[e] = gelu_f(in[e]);
+    } else if constexpr (OP == 2) {
+      const float4 hv = *reinterpret_cast<const float4*>(h + r * ldh + c);
+      in[0] *= dgelu_f(hv.x); in[1] *= dgelu_f(hv.y); in[2] *= dgelu_f(hv.z); in[3] *= dgelu_f(hv.w);
+    }
+    bf16x4 p[3];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      cs[e] += in[e];
+      const bf16_t p0 = (bf16_t)in[e];
+      const float e1 = in[e] - (float)p0;
+      const bf16_t p1 = (bf16_t)e1;
+      p[0][e] = p0;
+      p[1][e] = p1;
+      p[2][e] = (bf16_t)(e1 - (float)p1);
+    }
+    constexpr int order[6] = {0, 0, 1, 0, 1, 2};
+    bf16_t* o = out + r * ldo + c;
+#pragma unroll
+    for (int sg = 0; sg < 6; ++sg) *reinterpret_cast<bf16x4*>(o + sg * seg) = p[order[sg]];
+  }
+  if (partial) *reinterpret_cast<float4*>(partial + (long)blockIdx.y * (cols4 * 4) + c) = make_float4(cs[0], cs[1], cs[2], cs[3]);
+}
+
+inline int split3_parts(long rows) {
+  long p = rows / 16;
+  return (int)(p < 1 ? 1 : (p > 1024 ? 1024 : p));
+}
+
+extern "C" size_t mv_split3_ex_workspace_bytes(long rows, int cols) { return (size_t)split3_parts(rows) * cols * sizeof(float) + 256; }
+
+extern "C" int mv_split3_bf16_ex(const float* x, long ldx, const float* h, long ldh, int op, void* out, long rows, int cols,
+                                 float* colsum, float* workspace, size_t workspace_bytes, mv_stream_t stream) {
+  MV_REQUIRE(rows >= 0 && cols >= 0 && op >= 0 && op <= 2 && (op != 2 || h), MV_ERR_SHAPE);
+  if (rows == 0 || cols == 0) return MV_OK;
+  MV_REQUIRE(cols % 4 == 0 && ldx % 4 == 0 && ldx >= cols && (op != 2 || (ldh % 4 == 0 && ldh >= cols)), MV_ERR_ALIGN);
+  MV_REQUIRE(mv_aligned16(x) && mv_aligned16(out) && mv_aligned16(h) && mv_aligned16(workspace), MV_ERR_ALIGN);
+  const int parts = split3_parts(rows);
+  MV_REQUIRE(!colsum || workspace_bytes >= (size_t)parts * cols * sizeof(float), MV_ERR_WORKSPACE);
+  const int rpp = (int)((rows + parts - 1) / parts);
+  dim3 grid(mv_cdiv(cols / 4, 256), mv_cdiv(rows, rpp));
+  float* partial = colsum ? workspace : nullptr;
+  const long ldo = 6L * cols, seg = cols;
+  if (op == 0)
+    split3_ex_kernel<0><<<grid, 256, 0, S_>>>(x, ldx, h, ldh, (bf16_t*)out, ldo, seg, rows, cols / 4, rpp, partial);
+  else if (op == 1)
+    split3_ex_kernel<1><<<grid, 256, 0, S_>>>(x, ldx, h, ldh, (bf16_t*)out, ldo, seg, rows, cols / 4, rpp, partial);
+  else
+    split3_ex_kernel<2><<<grid, 256, 0, S_>>>(x, ldx, h, ldh, (bf16_t*)out, ldo, seg, rows, cols / 4, rpp, partial);
+  MV_CHECK_LAUNCH();
+  if (colsum) {
+    mv_reduce_rows_kernel<<<mv_reduce_rows_grid(cols), 1024, 0, S_>>>(workspace, (int)grid.y, cols, (long)cols, colsum, colsum,
+                                                                        colsum, cols, cols, 0);
+    MV_CHECK_LAUNCH();
+  }
+  return MV_OK;
+}
+
 extern "C" int mv_split3_bf16(const float* x, long ldx, void* out, long ldo, long seg, long rows, int cols, int role,
                               mv_stream_t stream) {
   MV_REQUIRE(rows >= 0 && cols >= 0 && (role == 0 || role == 1), MV_ERR_SHAPE);

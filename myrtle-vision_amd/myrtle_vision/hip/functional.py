@@ -473,6 +473,27 @@ class _AttnBlock(Function):
         y, mean, rstd = ops.layernorm_fwd(x, D, M, D, g, b, adt)
         inner3 = wqkv.shape[0]
         inner = inner3 // 3
+        ctx.x6 = adt == torch.float32 and ops.x6_block_ok(M, D, inner3, inner)
+        if ctx.x6:
+            # fp32 mode, every Linear product on the bf16x6 path: the block keeps the SPLITS of LN(x) and of the attention
+            # output (what the forward and the dW products both read), not the tensors themselves
+            dh = inner // heads
+            y6 = ops.split_ex(y, M, D)
+            qkv = torch.empty(B, T, inner3, dtype=adt, device=x.device)
+            ops.nt_x6(y6, wqkv, "fwd", M, qkv.view(M, inner3), bias=bqkv)
+            if ops.attention_f32_fused_supported(adt, T, dh) and not any(ctx.needs_input_grad):
+                o, probs = ops.attention_fwd_f32(qkv, B, T, heads, scale), x.new_empty(0)      # evaluation: no probabilities kept
+            else:
+                probs = ops.attention_probs_fp32(qkv, B, T, heads, dh, scale)
+                o = ops.attention_pv_fp32(probs, qkv, B, T, heads, dh)
+            o6 = ops.split_ex(o.view(M, inner), M, inner)
+            out = torch.empty_like(x)
+            ops.nt_x6(o6, wo, "fwd", M, out.view(M, D), bias=bo, residual=x.view(M, D))
+            ctx.save_for_backward(x, g, mean, rstd, y6, qkv, o6, probs, wqkv, wo)
+            ctx.cfg = (heads, scale, False)
+            ctx.small = (b, bqkv, bo)
+            _chain_set(out, bo)
+            return out
         qkv = torch.empty(B, T, inner3, dtype=adt, device=x.device)
         ops.linear_fwd(y, M, D, wqkv, bqkv, qkv, inner3)
         dh = inner // heads
@@ -506,6 +527,23 @@ class _AttnBlock(Function):
         M = B * T
         inner3 = wqkv.shape[0]
         inner = inner3 // 3
+        if ctx.x6:
+            y6, o6, probs = y, o, lse_or_probs
+            dout = _c(dout)
+            b, bqkv, bo = ctx.small
+            dbo = ops.grad_out(bo, (D,), x.device)
+            d6 = ops.split_ex(dout.view(M, D), M, D, colsum_out=dbo)          # one pass: the split and the bias gradient
+            dwo = ops.tn_x6(d6, o6, M, wo)
+            do = torch.empty(B, T, inner, dtype=torch.float32, device=x.device)
+            ops.nt_x6(d6, wo, "dx", M, do.view(M, inner))
+            dqkv = ops.attention_bwd_fp32(probs, qkv, do, B, T, heads, inner // heads, scale)
+            dbqkv = ops.grad_out(bqkv, (inner3,), x.device)
+            dq6 = ops.split_ex(dqkv.view(M, inner3), M, inner3, colsum_out=dbqkv)
+            dwqkv = ops.tn_x6(dq6, y6, M, wqkv)
+            dy = torch.empty(M, D, dtype=torch.float32, device=x.device)
+            ops.nt_x6(dq6, wqkv, "dx", M, dy)
+            dx, dg, db = _ln_bwd_with_side(dy, x, D, g, b, mean, rstd, dout, M, torch.float32, ctx.up_bias)
+            return dx, dg, db, dwqkv, dbqkv, dwo, dbo, None, None, None
         adt = y.dtype
         dout = _c(dout)
         d_act, dbo = _take_side(dout, M, D) if adt == torch.bfloat16 else (None, None)
@@ -549,6 +587,20 @@ class _MlpBlock(Function):
         x = _c(x)
         ctx.up_bias = _chain_take(x)
         y, mean, rstd = ops.layernorm_fwd(x, D, M, D, g, b, adt)
+        ctx.x6 = adt == torch.float32 and ops.x6_block_ok(M, D, Hd)
+        if ctx.x6:
+            # fp32 mode on the bf16x6 path: keeps the splits of LN(x) and of gelu(h) plus the pre-activation h; the fp32
+            # activation gelu(h) is never stored (the split kernel applies the GELU on its way)
+            y6 = ops.split_ex(y, M, D)
+            h = torch.empty(M, Hd, dtype=adt, device=x.device)
+            ops.nt_x6(y6, w1, "fwd", M, h, bias=b1)
+            a6 = ops.split_ex(h, M, Hd, op=1)
+            out = torch.empty_like(x)
+            ops.nt_x6(a6, w2, "fwd", M, out.view(M, D), bias=b2, residual=x.view(M, D))
+            ctx.save_for_backward(x, g, mean, rstd, y6, h, a6, w1, w2)
+            ctx.small = (b, b1, b2)
+            _chain_set(out, b2)
+            return out
         # bf16: the fc1 epilogue leaves gelu'(pre-activation) for the backward pass (one multiply there instead of another
         # erf evaluation per element); fp32 exact mode keeps the pre-activation itself
         h = torch.empty(M, Hd, dtype=adt, device=x.device)
@@ -568,6 +620,22 @@ class _MlpBlock(Function):
         B, T, D = x.shape
         M = B * T
         Hd = w1.shape[0]
+        if ctx.x6:
+            y6, a6 = y, a
+            dout = _c(dout)
+            b, b1, b2 = ctx.small
+            db2 = ops.grad_out(b2, (D,), x.device)
+            d6 = ops.split_ex(dout.view(M, D), M, D, colsum_out=db2)
+            dw2 = ops.tn_x6(d6, a6, M, w2)
+            dh = torch.empty(M, Hd, dtype=torch.float32, device=x.device)
+            ops.nt_x6(d6, w2, "dx", M, dh)
+            db1 = ops.grad_out(b1, (Hd,), x.device)
+            dh6 = ops.split_ex(dh, M, Hd, op=2, h=h, colsum_out=db1)         # (dY W2) * gelu'(h), its split and its column sums
+            dw1 = ops.tn_x6(dh6, y6, M, w1)
+            dy = torch.empty(M, D, dtype=torch.float32, device=x.device)
+            ops.nt_x6(dh6, w1, "dx", M, dy)
+            dx, dg, db = _ln_bwd_with_side(dy, x, D, g, b, mean, rstd, dout, M, torch.float32, ctx.up_bias)
+            return dx, dg, db, dw1, db1, dw2, db2, None
         adt = y.dtype
         dout = _c(dout)
         d_act, db2 = _take_side(dout, M, D) if adt == torch.bfloat16 else (None, None)

@@ -372,6 +372,47 @@ def _x6_tn_ok(M, N, K):
     return _f32_gemm_mode == "bf16x6" and M % 32 == 0 and M >= 512 and N % 8 == 0 and K % 8 == 0
 
 
+def x6_block_ok(M, *dims):
+    """Whether every Linear product of a transformer block with M token rows and these feature widths takes the bf16x6
+    path (forward, dX and dW): the block functions then keep the SPLITS of their activations instead of the activations."""
+    return _f32_gemm_mode == "bf16x6" and M % 32 == 0 and M >= 512 and all(d % 64 == 0 for d in dims)
+
+
+def split_ex(x, rows, cols, *, ldx=None, op=0, h=None, ldh=None, colsum_out=None):
+    """Role-0 side-by-side split [rows, 6 * cols] of v = x (op 0), gelu(x) (op 1) or x * gelu'(h) (op 2); ``colsum_out``
+    (fp32 [cols]) receives the column sums of v."""
+    require_cuda(x)
+    out = torch.empty(rows, 6 * cols, dtype=torch.bfloat16, device=x.device)
+    ws = workspace(lib().mv_split3_ex_workspace_bytes(rows, cols), x.device) if colsum_out is not None else None
+    check(lib().mv_split3_bf16_ex(_p(x), cols if ldx is None else ldx, _p(h), cols if ldh is None else ldh, op, _p(out), rows,
+                                  cols, _p(colsum_out), _p(ws), ws.numel() if ws is not None else 0, _s()),
+          "split3_bf16_ex", rows=rows, cols=cols, mode=op)
+    return out
+
+
+def nt_x6(a6, weight, which, M, out, *, bias=None, residual=None):
+    """out[M, N] = a (given as its split a6) times the Linear weight: which = 'fwd' -> a W^T (+bias) (+residual),
+    'dx' -> a W.  out / residual dense fp32 [M, N]."""
+    n_out, k_in = weight.shape
+    N, Kc = (n_out, k_in) if which == "fwd" else (k_in, n_out)
+    _nt_x6(a6, split_weight(weight, which), out, N, M, N, Kc, bias, EPI_RESIDUAL if residual is not None else EPI_NONE,
+           residual, N, tag=which)
+    return out
+
+
+def tn_x6(dy6, x6, M, weight):
+    """dW[N, K] = dY^T X from the two splits, into the weight's gradient slot."""
+    N, K = weight.shape
+    dw = grad_out(weight, (N, K), dy6.device)
+    ws = workspace(lib().mv_gemm_tn_workspace_bytes(N, K, 6 * M), dy6.device)
+    t0 = _timer.begin() if _timer is not None else None
+    check(lib().mv_gemm_tn_bf16_x6(_p(dy6), _p(x6), _p(dw), K, N, K, M, _p(ws), ws.numel(), _s()),
+          "gemm_tn_bf16_x6", M=N, N=K, rows=M)
+    if t0 is not None:
+        _timer.end("gemm_tn_bf16x6", t0, 2.0 * M * N * K, shape=f"dw N{N} K{K}")
+    return dw
+
+
 def _x6_ksplits(M, N):
     """K-split count of a bf16x6 NT product: 3 (two of the six segments per slice) when that shortens the schedule on
     the 256 CUs by a quarter or more -- 150 tiles: one round of 6 segments -> two rounds of 2."""

@@ -965,6 +965,62 @@ def test_fp16_qat_model_f16_forward_equals_fp32_path():
     assert len(seen) == 1 + 4 * 2                    # patch embedding + (qkv, proj, fc1, fc2) x 2 blocks; the head has M = 4
 
 
+def test_split3_ex_fuses_gelu_and_column_sums(ops):
+    """mv_split3_bf16_ex: op 0 == the plain split bit for bit; ops 1 / 2 reconstruct gelu(x) / x * gelu'(h) of the standalone
+    kernels to an ulp; the column sums are the bias gradient."""
+    rows, cols = 1024 + 32, 768
+    x, h = torch.randn(rows, cols, generator=g(1)).cuda(), torch.randn(rows, cols, generator=g(2)).cuda()
+    cs = torch.empty(cols, device="cuda")
+    assert torch.equal(ops.split_ex(x, rows, cols, colsum_out=cs), ops.split3(x, rows, cols, cols, 0))
+    assert relerr(cs, x.double().sum(0)) < 2e-6
+
+    def value(s6):                                   # p0 + p1 + p2 (segments 0, 2, 5), and the duplicated segments agree
+        v = s6.view(rows, 6, cols).double()
+        assert torch.equal(v[:, 0], v[:, 1]) and torch.equal(v[:, 0], v[:, 3]) and torch.equal(v[:, 2], v[:, 4])
+        return v[:, 0] + v[:, 2] + v[:, 5]
+
+    # the GELU inside the split kernel may contract its multiplies differently from the standalone kernel: 1 ulp
+    a = ops.gelu_fwd(x).double()
+    assert ((value(ops.split_ex(x, rows, cols, op=1)) - a).abs() <= a.abs() * 2.0 ** -22 + 1e-30).all()
+    dh = ops.gelu_bwd(h, x).double()
+    assert ((value(ops.split_ex(x, rows, cols, op=2, h=h, colsum_out=cs)) - dh).abs() <= dh.abs() * 2.0 ** -22 + 1e-30).all()
+    assert relerr(cs, dh.sum(0)) < 2e-6
+
+
+def test_fp32_blocks_on_bf16x6_match_the_fmaf_chain_path():
+    """fp32-mode ViT at batch 32 (M = 6304 = 32 x 197 rows: the transformer blocks take the bf16x6 route that keeps operand
+    splits instead of activations): logits and every gradient against the same model on mv_gemm_f32 (k-ordered fmaf chain)."""
+    from myrtle_vision.hip import ops as _ops
+    from myrtle_vision.hip.functional import cross_entropy
+    from myrtle_vision.models.vit import ViT
+    from myrtle_vision.utils.utils import seed_everything
+    kw = dict(decoder="classification", image_size=224, patch_size=16, num_classes=45, dim=192, depth=3, heads=3, mlp_dim=768)
+    gen = torch.Generator().manual_seed(5)
+    img, labels = torch.randn(32, 3, 224, 224, generator=gen).cuda(), torch.randint(0, 45, (32,), generator=gen).cuda()
+    res, taken = {}, []
+    orig = _ops.tn_x6
+    _ops.tn_x6 = lambda *a, **k: (taken.append(1), orig(*a, **k))[1]
+    try:
+        for mode in ("bf16x6", "mfma"):
+            prev = _ops.set_f32_gemm(mode)
+            try:
+                seed_everything(3)
+                vit = ViT(precision="fp32", **kw).cuda()
+                logits = vit(img)
+                cross_entropy(logits, labels).backward()
+            finally:
+                _ops.set_f32_gemm(prev)
+            res[mode] = (logits.detach().double().cpu(), {n: p.grad.double().cpu() for n, p in vit.named_parameters() if p.grad is not None})
+    finally:
+        _ops.tn_x6 = orig
+    assert len(taken) == 4 * 3                       # (qkv, proj, fc1, fc2) dW x 3 blocks went through the split-keeping path
+    assert relerr(res["bf16x6"][0], res["mfma"][0]) < 2e-5
+    assert torch.equal(res["bf16x6"][0].argmax(1), res["mfma"][0].argmax(1))
+    assert set(res["bf16x6"][1]) == set(res["mfma"][1])
+    for n, gr in res["mfma"][1].items():
+        assert float((res["bf16x6"][1][n] - gr).norm() / gr.norm().clamp_min(1e-30)) < 2e-5, n
+
+
 def test_fused_quantiser_producers_are_bit_identical(ops):
     """LayerNorm / exact-fp32 attention / int8-GEMM+GELU with the NEXT layer's quint8 quantiser fused in produce the same
     int8 codes as producer + mv_quant_affine_i8 (one shared device function, same expressions)."""
@@ -1049,10 +1105,19 @@ def test_int8_converted_model_fast_path_equals_fake_quant_path():
     img = torch.randn(4, 3, 224, 224, generator=gen).cuda()
     with torch.no_grad():
         fast = vit(img)
-    slow = vit(img)                                                       # grad mode: fake-quant fp32 path
+    from myrtle_vision.hip import ops as _ops0
+    prev = _ops0.set_f32_gemm("mfma")
+    try:
+        slow = vit(img)                                                   # grad mode: fake-quant fp32 path (fmaf-chain GEMMs)
+    finally:
+        _ops0.set_f32_gemm(prev)
     assert slow.requires_grad and not fast.requires_grad
     assert relerr(fast, slow.detach().double().cpu()) < 1e-4
     assert torch.equal(fast.argmax(1), slow.argmax(1))
+    # the default fp32 products (bf16x6) round differently (5e-7): a quantiser downstream may land on the other side of a
+    # code boundary, and one flipped code in the class-token row moves a logit by ~1e-3
+    slow6 = vit(img)
+    assert relerr(fast, slow6.detach().double().cpu()) < 5e-3 and torch.equal(fast.argmax(1), slow6.argmax(1))
     # FeedForward folds nn.GELU into fc2's input quantiser: taken (2 blocks), and bit-identical to the unfolded path
     from myrtle_vision.hip import ops as _ops
     from myrtle_vision.models.vit import GELU
