@@ -10,7 +10,7 @@
  *   - return 0 on success, a negative MV_ERR_* otherwise; never throw, never synchronise,
  *     never allocate (callers pass workspaces); work is enqueued on `stream`
  *   - re-entrant, no thread-local state (autograd calls backward from a worker thread); the ONLY process-global
- *     state is the kernel-variant overrides of mv_gemm_force_variant / mv_gemm_f32_force_fma (tuning / test hooks, atomic,
+ *     state is the kernel-variant overrides of mv_gemm_force_variant / mv_gemm_f32_force_fma / mv_attention_bwd_force (tuning / test hooks, atomic,
  *     default 0 = automatic): they change which kernel computes a product, never what is computed
  *   - "rows x dim" tensors are row-major; `ld*` are leading dimensions in ELEMENTS
  *   - dtype codes: MV_F32 / MV_BF16
@@ -133,6 +133,11 @@ int mv_attention_fwd(const void* qkv, void* out, float* lse, int B, int N, int H
  * so no separate pass over dqkv is needed for it. */
 int mv_attention_bwd(const void* qkv, const void* out, const void* dout, const float* lse, void* dqkv, float* colsum,
                      int B, int N, int H, float scale, mv_stream_t stream);
+/* Test / tuning hook (process-global, atomic, like mv_gemm_force_variant): backward kernel for the following
+ * mv_attention_bwd calls -- 0 auto (N <= 208: 4; N <= 288: 2; else 8), 4 = dS exchanged through LDS (N <= 208), 2 = two
+ * barrier-free passes (N <= 288), 8 = the eight-wave kernel (N <= 320).  A variant that cannot take the length falls back
+ * to auto. */
+int mv_attention_bwd_force(int variant);
 /* The same attention core in EXACT fp32 arithmetic on the f32-input matrix cores, forward only: qkv fp32 [B, N, 3, H, 64],
  * out fp32 [B, N, H*64]; N <= 272.  For the paths that need fp32 values and no gradient (converted PyTorchINT8 model,
  * precision="fp32" evaluation): same products and sums as mv_gemm_f32 + mv_softmax_fwd + mv_gemm_f32 up to summation order,

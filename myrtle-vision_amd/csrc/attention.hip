@@ -18,6 +18,8 @@
 // conflict-free order for transposed reads of 128-byte rows in the sw128 image (tools/lds_bank_sim.py).
 #include "mv_common.h"
 
+#include <atomic>
+
 #ifndef MV_ATTN_ABLATE
 #define MV_ATTN_ABLATE 0   // diagnostic builds only (tools/ablate_attn.sh): bit k removes one phase of attn_bwd4_kernel
 #endif
@@ -436,20 +438,9 @@ __global__ __launch_bounds__(256, 2) void attn_bwd4_kernel(const bf16_t* __restr
   for (int idx = tid; idx < NPK * 4; idx += 256) reinterpret_cast<u32x4*>(sDS)[idx] = zero4;   // padding key rows stay 0
   if (tid < NPK) {
     const int row = tid;
-    float dl = 0.f, l2 = INFINITY;
-    if (row < N && !(MV_ATTN_ABLATE & 8)) {
-      l2 = lse[((long)b * H + h) * N + row] * LOG2E;
-#pragma unroll
-      for (int c = 0; c < 8; ++c) {
-        const u32x4 a = *reinterpret_cast<const u32x4*>(dobase + (long)row * D + c * 8);
-        const u32x4 o = *reinterpret_cast<const u32x4*>(obase + (long)row * D + c * 8);
-        const bf16x8 av = __builtin_bit_cast(bf16x8, a), ov = __builtin_bit_cast(bf16x8, o);
-#pragma unroll
-        for (int e = 0; e < 8; ++e) dl += (float)av[e] * (float)ov[e];
-      }
-    }
+    float l2 = INFINITY;
+    if (row < N && !(MV_ATTN_ABLATE & 8)) l2 = lse[((long)b * H + h) * N + row] * LOG2E;
     sLse[row] = l2;
-    sDelta[row] = dl;
   }
 
   // pair staging: 2 tiles x 32 rows x 8 chunks = 512 chunks, two per thread
@@ -468,6 +459,24 @@ __global__ __launch_bounds__(256, 2) void attn_bwd4_kernel(const bf16_t* __restr
     const int which = idx >> 8, row = (idx >> 3) & 31, ch = idx & 7;
     *reinterpret_cast<u32x4*>(sPair + which * 4096 + sw128(row, ch)) = v;
   };
+  // delta[q] = sum_d dO[q][d] O[q][d] rides on the pair prefetch: thread (row = tid >> 3, chunk = tid & 7) already holds its
+  // 8 elements of dO (load_pair(u, 1)), loads the same 8 of O, and the row's 8 threads (consecutive lanes) add up.  (Computed
+  // for all 208 rows before the loop, this cost 53 of the kernel's 282 us: 16 dependent-latency loads per thread with
+  // nothing to hide under.)
+  auto load_o = [&](int u) -> u32x4 {
+    const int q = 32 * u + (tid >> 3);
+    return *reinterpret_cast<const u32x4*>(obase + (long)(q < N ? q : N - 1) * D + (tid & 7) * 8);
+  };
+  auto put_delta = [&](int u, u32x4 dov, u32x4 ov) {
+    const bf16x8 av = __builtin_bit_cast(bf16x8, dov), bv = __builtin_bit_cast(bf16x8, ov);
+    float dl = 0.f;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) dl += (float)av[e] * (float)bv[e];
+    dl += __shfl_xor(dl, 1);
+    dl += __shfl_xor(dl, 2);
+    dl += __shfl_xor(dl, 4);
+    if ((tid & 7) == 0) sDelta[32 * u + (tid >> 3)] = (MV_ATTN_ABLATE & 8) ? 0.f : dl;
+  };
 
   f32x4 adk[KPW][4], adv[KPW][4];
 #pragma unroll
@@ -478,8 +487,12 @@ __global__ __launch_bounds__(256, 2) void attn_bwd4_kernel(const bf16_t* __restr
       adv[i][dt] = (f32x4){0.f, 0.f, 0.f, 0.f};
     }
 
-  store_pair(0, load_pair(0, 0));
-  store_pair(1, load_pair(0, 1));
+  {
+    const u32x4 q0 = load_pair(0, 0), d0 = load_pair(0, 1), o0 = load_o(0);
+    store_pair(0, q0);
+    store_pair(1, d0);
+    put_delta(0, d0, o0);
+  }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // this wave's K/V DMA pieces have landed
   __syncthreads();
 
@@ -488,10 +501,11 @@ __global__ __launch_bounds__(256, 2) void attn_bwd4_kernel(const bf16_t* __restr
   const int nkt_valid = (N + 15) >> 4;
   f32x4 dqs0 = {0.f, 0.f, 0.f, 0.f}, dqs1 = {0.f, 0.f, 0.f, 0.f};   // running column sums of this wave's two dQ tiles
   for (int u = 0; u < NQP; ++u) {
-    u32x4 nx0 = zero4, nx1 = zero4;
+    u32x4 nx0 = zero4, nx1 = zero4, nxo = zero4;
     if (u + 1 < NQP && !(MV_ATTN_ABLATE & 4)) {
       nx0 = load_pair(u + 1, 0);
       nx1 = load_pair(u + 1, 1);
+      nxo = load_o(u + 1);
     }
     if (32 * u < N && !(MV_ATTN_ABLATE & 16)) {
       // The query pair's TRANSPOSED fragments (operands of the dV / dK products) do not depend on the key tile: read them
@@ -550,6 +564,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd4_kernel(const bf16_t* __restr
     if (u + 1 < NQP && !(MV_ATTN_ABLATE & 4)) {
       store_pair(0, nx0);
       store_pair(1, nx1);
+      put_delta(u + 1, nx1, nxo);                      // read by the next iteration's S-phase, after the barrier below
     }
     // dQ^T[d][q] = sum_key K^T[d][key] dS^T[key][q]: 2 q-tiles x 4 d-tiles = 8 output tiles, two per wave
     if (32 * u < N && !(MV_ATTN_ABLATE & 1)) {
@@ -623,6 +638,290 @@ __global__ __launch_bounds__(256, 2) void attn_bwd4_kernel(const bf16_t* __restr
   }
 }
 
+// ------------------------------------------------------------------------------------------------
+// backward, two passes without barriers inside: one 256-thread workgroup per (image, head), two per CU
+// ------------------------------------------------------------------------------------------------
+// attn_bwd4_kernel exchanges dS through LDS for dQ: two barriers per 32 queries, and between them four serial
+// load -> MFMA -> exp -> MFMA chains per wave (the key tiles sit behind execmask branches): 18 % MFMA duty in its loop
+// (phase ablation: S-phase 90 us, dQ phase 48 us, of 259).  Here the work is cut so that no wave ever needs another wave's
+// data inside a loop, at the price of computing S and dP twice (7 products instead of 5):
+//   pass A (dQ):    K, V in LDS.  A wave owns 16 QUERIES: S^T = K Q^T and dP^T = V dO^T (keys on accumulator rows, as in
+//                   the forward kernel, Q / dO / O fragments straight from global memory one tile ahead), P^T from the saved
+//                   lse, delta = rowsum(dO * O) from the fragments in registers, dS^T is at once the B operand of
+//                   dQ^T = K^T dS^T.  Streams over the keys: 12 MFMAs per 32 keys, 16 accumulator registers.
+//   pass B (dK/dV): the SAME LDS bytes re-staged with Q and dO (one barrier pair per workgroup).  A wave owns 32 KEYS (K, V
+//                   fragments in registers, from global memory) and walks the queries: S, dP (keys on lanes), P / dS are the
+//                   B operands of dV^T += dO^T P and dK^T += Q^T dS -- the S-phase of attn_bwd4_kernel without its dS store.
+// LDS: 2 x [32 NP32 rows][64] bf16 + lse + delta + column sums = 62,208 B (N <= 224) / 79,104 B (N <= 288): two workgroups per CU for the
+// 257-token case as well, which the 104 KB eight-wave kernel above could not do.
+__device__ __forceinline__ void stage_rows_dma(const bf16_t* src, long ld, int N, char* dst, int rows, int wave, int nwaves,
+                                               int lane) {
+  const int prow = lane >> 3, pch = lane & 7;
+  for (int pc = wave; pc < rows / 8; pc += nwaves) {
+    const int row = 8 * pc + prow;
+    const long rr = row < N ? row : N - 1;
+    const int ch = pch ^ (((row >> 1) & 3) << 1);
+    glds16(src + rr * ld + ch * 8, dst + pc * 1024);
+  }
+}
+
+template <int NP32>
+__global__ __launch_bounds__(256, 2) void attn_bwd2p_kernel(const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ out,
+                                                            const bf16_t* __restrict__ dout, const float* __restrict__ lse,
+                                                            bf16_t* __restrict__ dqkv, float* __restrict__ colsum, int N, int H,
+                                                            float scale) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  constexpr int NR = NP32 * 32;
+  char* sA = smem;                           // pass A: K    pass B: Q      ([NR][64] bf16, sw128 image, rows >= N clamped)
+  char* sB = smem + NR * 128;                // pass A: V    pass B: dO
+  float* sLse = reinterpret_cast<float*>(sB + NR * 128);   // lse * log2(e); +inf for rows >= N (their p is exactly 0)
+  float* sDelta = sLse + NR;
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 4;
+  const LaneOff L = make_lane_off(lane);
+  const int b = blockIdx.x / H, h = blockIdx.x % H;
+  const long D = (long)H * 64;
+  const bf16_t* base = qkv + (long)b * N * 3 * D + h * 64;
+  const bf16_t* dobase = dout + (long)b * N * D + h * 64;
+  const bf16_t* obase = out + (long)b * N * D + h * 64;
+  bf16_t* dbase = dqkv + (long)b * N * 3 * D + h * 64;
+  const float c2 = scale * LOG2E;
+
+  stage_rows_dma(base + D, 3 * D, N, sA, NR, wave, 4, lane);
+  stage_rows_dma(base + 2 * D, 3 * D, N, sB, NR, wave, 4, lane);
+  for (int row = tid; row < NR; row += 256) {
+    sLse[row] = row < N ? lse[((long)b * H + h) * N + row] * LOG2E : INFINITY;
+    sDelta[row] = 0.f;
+  }
+  // fragments of a 16-row tile from global memory: B operands (n = row lane&15, 8 consecutive d at 32 ks + 8 g)
+  auto frag = [&](const bf16_t* src, long ld, int row, int ks) -> u32x4 {
+    return *reinterpret_cast<const u32x4*>(src + (long)(row < N ? row : N - 1) * ld + 32 * ks + 8 * g);
+  };
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+
+  // ---------------- pass A: dQ ----------------
+  // a task = 32 queries (two 16-query tiles share every K / V / K^T fragment read: 24 MFMAs per 16 LDS reads -- with one
+  // tile per task this pass was bound by LDS bandwidth)
+  f32x4 dqs[4];
+#pragma unroll
+  for (int dt = 0; dt < 4; ++dt) dqs[dt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  for (int task = wave; task < NP32 && !(MV_ATTN_ABLATE & 32); task += 4) {
+    if (32 * task >= N) break;
+    bf16x8 qf[2][2], dof[2][2];
+    float dl[2], l2[2];
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+      const int qrow = 32 * task + 16 * t + (lane & 15);
+      float d = 0.f;
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks) {
+        qf[t][ks] = __builtin_bit_cast(bf16x8, frag(base, 3 * D, qrow, ks));
+        dof[t][ks] = __builtin_bit_cast(bf16x8, frag(dobase, D, qrow, ks));
+        const bf16x8 of = __builtin_bit_cast(bf16x8, frag(obase, D, qrow, ks));
+#pragma unroll
+        for (int e = 0; e < 8; ++e) d += (float)dof[t][ks][e] * (float)of[e];
+      }
+      d += __shfl_xor(d, 16, 64);
+      d += __shfl_xor(d, 32, 64);
+      if (g == 0) sDelta[qrow] = d;                      // pass B reads it after the barrier between the passes
+      dl[t] = d;
+      l2[t] = sLse[qrow];
+    }
+    f32x4 dq[2][4];
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+      for (int dt = 0; dt < 4; ++dt) dq[t][dt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    // the row fragments of key pair u + 1 are read while pair u computes (two register sets); K^T of pair u is read at the
+    // top of its own iteration (first needed after the S / dP products and the exponentials).  The scheduling barrier
+    // keeps the compiler from hoisting every pair's reads to the top, which spilled.
+    bf16x8 kr[2][2][2], vr[2][2][2], ktr[4];
+#define ATTN_A_READ(buf_, u_)                                                              \
+  {                                                                                        \
+    _Pragma("unroll") for (int kk = 0; kk < 2; ++kk) _Pragma("unroll") for (int ks = 0; ks < 2; ++ks) { \
+      kr[buf_][kk][ks] = row_frag128(sA, (2 * (u_) + kk) * 16, L.rf[ks]);                  \
+      vr[buf_][kk][ks] = row_frag128(sB, (2 * (u_) + kk) * 16, L.rf[ks]);                  \
+    }                                                                                      \
+  }
+    ATTN_A_READ(0, 0)
+#pragma unroll
+    for (int u = 0; u < NP32; ++u) {
+#pragma unroll
+      for (int dt = 0; dt < 4; ++dt) ktr[dt] = tr_frag128(sA, 32 * u, L.tr[dt]);
+      if (u + 1 < NP32) ATTN_A_READ((u + 1) & 1, u + 1)
+#pragma unroll
+      for (int t = 0; t < 2; ++t) {
+        f32x4 ds[2];
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) {
+          f32x4 st = {0.f, 0.f, 0.f, 0.f}, dp = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+          for (int ks = 0; ks < 2; ++ks) {
+            st = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kr[u & 1][kk][ks], qf[t][ks], st, 0, 0, 0);
+            dp = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vr[u & 1][kk][ks], dof[t][ks], dp, 0, 0, 0);
+          }
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const int key = (2 * u + kk) * 16 + 4 * g + r;
+            const float p = key < N ? __builtin_amdgcn_exp2f(st[r] * c2 - l2[t]) : 0.f;
+            ds[kk][r] = p * (dp[r] - dl[t]) * scale;
+          }
+        }
+        const bf16x8 dsf = pack8(ds[0], ds[1]);
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt)
+          dq[t][dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ktr[dt], dsf, dq[t][dt], 0, 0, 0);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+#undef ATTN_A_READ
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+      const int qrow = 32 * task + 16 * t + (lane & 15);
+      if (qrow < N) {
+        bf16_t* drow = dbase + (long)qrow * 3 * D + 4 * g;
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt) *reinterpret_cast<bf16x4*>(drow + dt * 16) = pack4(dq[t][dt]);
+      }
+#pragma unroll
+      for (int dt = 0; dt < 4; ++dt) dqs[dt] += dq[t][dt];   // padded queries: lse = +inf -> p = 0 -> exact zeros
+    }
+  }
+
+  // column sums of this wave's dQ tiles -> LDS now (16 registers that pass B needs)
+  float* sCs = sDelta + NR;                    // [4 waves][192]: dq | dk | dv column sums of this (image, head)
+  if (colsum) {
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const float vq = rowsum16(dqs[dt][r]);
+        if ((lane & 15) == 0) sCs[wave * 192 + dt * 16 + 4 * g + r] = vq;
+      }
+  }
+  // ---------------- the same LDS bytes now hold Q and dO ----------------
+  __syncthreads();
+  stage_rows_dma(base, 3 * D, N, sA, NR, wave, 4, lane);
+  stage_rows_dma(dobase, D, N, sB, NR, wave, 4, lane);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+
+  // ---------------- pass B: dK, dV ----------------
+  if (colsum && (lane & 15) == 0) {
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        sCs[wave * 192 + 64 + dt * 16 + 4 * g + r] = 0.f;
+        sCs[wave * 192 + 128 + dt * 16 + 4 * g + r] = 0.f;
+      }
+  }
+  const int nkt_valid = (N + 15) >> 4;
+  for (int task = wave; task < NP32 && !(MV_ATTN_ABLATE & 64); task += 4) {
+    if (32 * task >= N) break;
+    bf16x8 kf[2][2], vf[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int krow = (2 * task + i) * 16 + (lane & 15);
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks) {
+        kf[i][ks] = __builtin_bit_cast(bf16x8, frag(base + D, 3 * D, krow, ks));
+        vf[i][ks] = __builtin_bit_cast(bf16x8, frag(base + 2 * D, 3 * D, krow, ks));
+      }
+    }
+    f32x4 adk[2][4], adv[2][4];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int dt = 0; dt < 4; ++dt) {
+        adk[i][dt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        adv[i][dt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+      }
+    // query groups beyond N are computed too (their rows are clamped copies and lse = +inf: p = 0 exactly): NP32 is chosen so
+    // that at the production lengths (197, 257) every group is real
+#pragma unroll 1
+    for (int u = 0; u < NP32; ++u) {
+      bf16x8 dotr[4], qtr[4], qrf[2][2], dorf[2][2];
+#pragma unroll
+      for (int dt = 0; dt < 4; ++dt) {
+        dotr[dt] = tr_frag128(sB, 32 * u, L.tr[dt]);
+        qtr[dt] = tr_frag128(sA, 32 * u, L.tr[dt]);
+      }
+#pragma unroll
+      for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+          qrf[t][ks] = row_frag128(sA, 32 * u + 16 * t, L.rf[ks]);
+          dorf[t][ks] = row_frag128(sB, 32 * u + 16 * t, L.rf[ks]);
+        }
+      f32x4 l2v[2], dlv[2];
+#pragma unroll
+      for (int t = 0; t < 2; ++t) {
+        l2v[t] = *reinterpret_cast<const f32x4*>(sLse + 32 * u + 16 * t + 4 * g);
+        dlv[t] = *reinterpret_cast<const f32x4*>(sDelta + 32 * u + 16 * t + 4 * g);
+      }
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        const int key = (2 * task + i) * 16 + (lane & 15);
+        f32x4 pp[2], ds[2];
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+          f32x4 sv = {0.f, 0.f, 0.f, 0.f}, dp = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+          for (int ks = 0; ks < 2; ++ks) {
+            sv = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qrf[t][ks], kf[i][ks], sv, 0, 0, 0);
+            dp = __builtin_amdgcn_mfma_f32_16x16x32_bf16(dorf[t][ks], vf[i][ks], dp, 0, 0, 0);
+          }
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            float p = __builtin_amdgcn_exp2f(sv[r] * c2 - l2v[t][r]);
+            p = key < N ? p : 0.f;
+            pp[t][r] = p;
+            ds[t][r] = p * (dp[r] - dlv[t][r]) * scale;
+          }
+        }
+        const bf16x8 pf = pack8(pp[0], pp[1]);
+        const bf16x8 dsf = pack8(ds[0], ds[1]);
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt) {
+          adv[i][dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(dotr[dt], pf, adv[i][dt], 0, 0, 0);
+          adk[i][dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qtr[dt], dsf, adk[i][dt], 0, 0, 0);
+        }
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int kt = 2 * task + i;
+      const int key = kt * 16 + (lane & 15);
+      if (kt < nkt_valid && key < N) {
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt) {
+          *reinterpret_cast<bf16x4*>(dbase + (long)key * 3 * D + D + dt * 16 + 4 * g) = pack4(adk[i][dt]);
+          *reinterpret_cast<bf16x4*>(dbase + (long)key * 3 * D + 2 * D + dt * 16 + 4 * g) = pack4(adv[i][dt]);
+        }
+      }
+    }
+    if (colsum) {                                        // padded keys: p = 0 -> exact zeros
+#pragma unroll
+      for (int dt = 0; dt < 4; ++dt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const float vk = rowsum16(adk[0][dt][r] + adk[1][dt][r]), vv = rowsum16(adv[0][dt][r] + adv[1][dt][r]);
+          if ((lane & 15) == 0) {
+            sCs[wave * 192 + 64 + dt * 16 + 4 * g + r] += vk;
+            sCs[wave * 192 + 128 + dt * 16 + 4 * g + r] += vv;
+          }
+        }
+    }
+  }
+
+  if (colsum) {                                          // to_qkv bias-gradient partials of this (image, head)
+    __syncthreads();
+    attn_colsum_store<4>(sCs, colsum + (long)b * 3 * D + h * 64, D, tid);
+  }
+}
+
 template <typename K>
 int set_smem(K kernel, int bytes) {
   return hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, bytes) ==
@@ -635,6 +934,15 @@ constexpr int fwd_smem(int nkt) { return nkt * 16 * 128 * 2; }
 constexpr int bwd_smem(int nkt) { return nkt * 16 * 128 * 2 + 2 * 8192 + 2 * nkt * 16 * 64 + 2 * nkt * 16 * 4; }
 
 }  // namespace
+
+namespace {
+std::atomic<int> g_bwd_variant{0};
+}
+extern "C" int mv_attention_bwd_force(int variant) {
+  if (variant != 0 && variant != 2 && variant != 4 && variant != 8) return MV_ERR_UNSUPPORTED;
+  g_bwd_variant.store(variant, std::memory_order_relaxed);
+  return MV_OK;
+}
 
 extern "C" int mv_attention_fwd(const void* qkv, void* out, float* lse, int B, int N, int H, float scale,
                                 mv_stream_t stream) {
@@ -666,8 +974,26 @@ extern "C" int mv_attention_bwd(const void* qkv, const void* out, const void* do
   MV_REQUIRE(mv_aligned16(qkv) && mv_aligned16(out) && mv_aligned16(dout) && mv_aligned16(dqkv), MV_ERR_ALIGN);
   if (B == 0) return MV_OK;
   hipStream_t s = (hipStream_t)stream;
-  static const int force8 = getenv("MV_ATTN_BWD8") ? 1 : 0;      // tests: force the 8-wave kernel
-  if (N <= 208 && !force8) {
+  // measured (tools/bench_attn.py, ViT-B, 12 heads): N = 197, batch 256: bwd4 251 us, two-pass 287 us; N = 257, batch 64:
+  // two-pass 101 us, eight-wave 115 us.  mv_attention_bwd_force overrides (tests run every variant at every length it takes).
+  const int forced = g_bwd_variant.load(std::memory_order_relaxed);
+  const bool force8 = forced == 8;
+  const bool two_pass = forced == 2 || (forced == 0 && N > 208);
+  if (N <= 288 && !force8 && two_pass) {
+    if (N <= 224) {
+      constexpr int smem = 2 * 224 * 128 + 2 * 224 * 4 + 4 * 192 * 4;
+      static const int a = set_smem(attn_bwd2p_kernel<7>, smem);
+      if (a) return MV_ERR_LAUNCH;
+      attn_bwd2p_kernel<7><<<B * H, 256, smem, s>>>((const bf16_t*)qkv, (const bf16_t*)out, (const bf16_t*)dout, lse,
+                                                   (bf16_t*)dqkv, colsum, N, H, scale);
+    } else {
+      constexpr int smem = 2 * 288 * 128 + 2 * 288 * 4 + 4 * 192 * 4;
+      static const int a = set_smem(attn_bwd2p_kernel<9>, smem);
+      if (a) return MV_ERR_LAUNCH;
+      attn_bwd2p_kernel<9><<<B * H, 256, smem, s>>>((const bf16_t*)qkv, (const bf16_t*)out, (const bf16_t*)dout, lse,
+                                                   (bf16_t*)dqkv, colsum, N, H, scale);
+    }
+  } else if (N <= 208 && !force8) {
     constexpr int smem4 = 224 * 128 + 208 * 128 + 8192 + 224 * 64 + 2 * 224 * 4;   // 79,616 B: two workgroups per CU
     static const int a = set_smem(attn_bwd4_kernel, smem4);
     if (a) return MV_ERR_LAUNCH;

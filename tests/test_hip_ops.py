@@ -478,6 +478,18 @@ def test_attention_fused_fwd_bwd(ops, B, N, H):
     assert relerr(part.cpu().double(), ref_in.grad.sum(1)) < 3e-2
     dq2 = ops.attention_bwd(qkv.cuda(), out, dout.cuda(), lse, B, N, H, scale)           # colsum is optional
     assert torch.equal(dq2, dqkv)
+    # every backward kernel that takes this length (auto picked one of them above)
+    from myrtle_vision.hip.lib import lib
+    for variant in [v for v, nmax in ((4, 208), (2, 288), (8, 320)) if N <= nmax]:
+        lib().mv_attention_bwd_force(variant)
+        try:
+            part2 = torch.full((B, 3 * H * 64), float("nan"), device="cuda")
+            got2 = ops.attention_bwd(qkv.cuda(), out, dout.cuda(), lse, B, N, H, scale, colsum=part2).float().cpu().view(B, N, 3, H, 64)
+        finally:
+            lib().mv_attention_bwd_force(0)
+        for i, name in enumerate("qkv"):
+            assert relerr(got2[:, :, i], ref[:, :, i]) < 3e-2, (variant, name)
+        assert relerr(part2.cpu().double(), ref_in.grad.sum(1)) < 3e-2, variant
 
 
 @pytest.mark.parametrize("B,N,H,dh", [(2, 197, 3, 64), (1, 40, 2, 32)])

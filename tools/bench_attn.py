@@ -16,6 +16,9 @@ def timeit(fn, iters=10):
     for _ in range(iters): fn()
     e.record(); torch.cuda.synchronize()
     return s.elapsed_time(e) / iters * 1e3
+if os.environ.get("ATTN_BWD"):                      # 2 two-pass | 4 dS-through-LDS | 8 eight-wave (mv_attention_bwd_force)
+    from myrtle_vision.hip.lib import lib
+    lib().mv_attention_bwd_force(int(os.environ["ATTN_BWD"]))
 out, lse = ops.attention_fwd(qkv, B, N, H, 0.125)
 tf = timeit(lambda: ops.attention_fwd(qkv, B, N, H, 0.125))
 tb = timeit(lambda: ops.attention_bwd(qkv, out, dout, lse, B, N, H, 0.125))
