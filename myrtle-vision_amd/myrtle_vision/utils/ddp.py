@@ -22,7 +22,7 @@ import torch.distributed as dist
 
 
 class GradAllReducer:
-    def __init__(self, arena, process_group=None, bucket_bytes: int = 48 << 20):
+    def __init__(self, arena, process_group=None, bucket_bytes: int = 48 << 20, tail_bytes: int = 12 << 20):
         self.arena = arena
         self.group = process_group
         self.world = dist.get_world_size(process_group) if dist.is_initialized() else 1
@@ -32,7 +32,11 @@ class GradAllReducer:
         # LayerNorm parameter of EVERY layer, < 1 MB) is complete only when the first layer's gradients are, i.e. at the very
         # end of backward -- sharing a bucket with it held the last layers' 57 MiB of weight gradients back until then
         # (tools/ddp_overlap_timeline.py: 23 % of the gradient bytes were enqueued after backward; now < 7 %).
-        cap = max(bucket_bytes // 4, 1)
+        # The LAST buckets to complete (the first layers' weights: the low end of the decay region, which starts the arena)
+        # taper to ``tail_bytes``:
+        # whatever is enqueued in the final instants of backward is the exposed part of the exchange, and with uniform
+        # 48 MiB buckets that was 47 MiB at 0.3 ms before the end (timeline tool); tapered it is one or two parameters.
+        cap_full, cap_tail = max(bucket_bytes // 4, 1), max(min(tail_bytes, bucket_bytes) // 4, 1)
         n_decay_params = sum(1 for o in arena.offsets if o < arena.n_decay)
         self.ranges: List[tuple] = []
         hi = arena.total
@@ -41,6 +45,7 @@ class GradAllReducer:
             j = lo_idx
             lo = hi
             floor = n_decay_params if lo_idx > n_decay_params else 0          # first parameter index this bucket may reach
+            cap = cap_tail if lo_idx <= n_decay_params and hi <= 2 * cap_full else cap_full   # decay region = [0, n_decay)
             while j > floor and (hi - arena.offsets[j - 1]) <= cap or j == lo_idx:
                 j -= 1
                 lo = arena.offsets[j]

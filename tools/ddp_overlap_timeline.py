@@ -6,7 +6,7 @@ An event is recorded on the compute stream at every bucket launch (the collectiv
 stream, then runs on RCCL's own stream beside the rest of backward) and at the end of backward; the table gives, per bucket,
 the GPU time of backward already executed and still to come when its all-reduce could start.
 
-    python tools/ddp_overlap_timeline.py            # ViT-B/16, batch 256, 64 MiB buckets
+    python tools/ddp_overlap_timeline.py            # ViT-B/16, batch 256, the product's bucket size (BUCKET_MIB overrides)
 """
 import os
 import sys
@@ -33,7 +33,8 @@ vit = ViT(decoder="classification", image_size=224, patch_size=16, num_classes=1
           precision="bf16", q_format="FP32").to(dev)
 arena = ParamArena(vit.named_parameters(), skip=vit.unused_parameter_names())
 opt = AdamW(arena, lr=6.25e-5, weight_decay=0.05)
-red = GradAllReducer(arena, bucket_bytes=int(os.environ.get("BUCKET_MIB", 64)) << 20)
+red = (GradAllReducer(arena, bucket_bytes=int(os.environ["BUCKET_MIB"]) << 20) if os.environ.get("BUCKET_MIB")
+       else GradAllReducer(arena))                    # the product default (48 MiB)
 red.enabled = True
 marks = []
 orig = red._launch
@@ -61,7 +62,7 @@ for it in range(4):
     opt.step()
 torch.cuda.synchronize()
 total = t0.elapsed_time(t1)
-print(f"backward: {total:.2f} ms of GPU time; {len(red.ranges)} buckets of <= {os.environ.get('BUCKET_MIB', 64)} MiB "
+print(f"backward: {total:.2f} ms of GPU time; {len(red.ranges)} buckets of <= {os.environ.get('BUCKET_MIB', 48)} MiB "
       f"({arena.total * 4 / 2 ** 20:.0f} MiB of fp32 gradients)")
 print("bucket  MiB   enqueued after (ms)   backward still to run (ms)   share of backward left")
 for b, e in marks:
