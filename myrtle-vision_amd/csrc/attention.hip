@@ -572,13 +572,26 @@ __global__ __launch_bounds__(256, 2) void attn_bwd4_kernel(const bf16_t* __restr
       const int trk0 = (wave & 1) ? L.tr[2] : L.tr[0], trk1 = (wave & 1) ? L.tr[3] : L.tr[1];
       const int dsoff = (4 * g + ((lane >> 2) & 3)) * 64 + ((t ^ (g & 1)) << 5) + 8 * (lane & 3);
       f32x4 dq0 = {0.f, 0.f, 0.f, 0.f}, dq1 = {0.f, 0.f, 0.f, 0.f};
+      // All seven 32-key groups, unconditionally (groups beyond N hold zero dS^T rows -- zero-filled at the start, never
+      // written -- against clamped finite K rows), two register sets: the six transposed reads of group v + 1 are in flight
+      // while group v's two MFMAs run.  (As a rolled loop with a break each group was read -> wait -> MFMA: 16 % MFMA duty.)
+      bf16x8 dsv[2], kv0[2], kv1[2];
+#define ATTN_DQ_READ(buf_, v_)                                                  \
+  {                                                                             \
+    const char* dsp_ = sDS + 2048 * (v_) + dsoff;                               \
+    dsv[buf_] = cat8(tr_read(dsp_), tr_read(dsp_ + 1024));                      \
+    kv0[buf_] = tr_frag128(sK, 32 * (v_), trk0);                                \
+    kv1[buf_] = tr_frag128(sK, 32 * (v_), trk1);                                \
+  }
+      ATTN_DQ_READ(0, 0)
+#pragma unroll
       for (int v = 0; v < NQP; ++v) {
-        if (32 * v >= N) break;
-        const char* dsp = sDS + 2048 * v + dsoff;
-        const bf16x8 dsf = cat8(tr_read(dsp), tr_read(dsp + 1024));
-        dq0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(tr_frag128(sK, 32 * v, trk0), dsf, dq0, 0, 0, 0);
-        dq1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(tr_frag128(sK, 32 * v, trk1), dsf, dq1, 0, 0, 0);
+        if (v + 1 < NQP) ATTN_DQ_READ((v + 1) & 1, v + 1)
+        dq0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kv0[v & 1], dsv[v & 1], dq0, 0, 0, 0);
+        dq1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kv1[v & 1], dsv[v & 1], dq1, 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
       }
+#undef ATTN_DQ_READ
       const int q = 32 * u + 16 * t + (lane & 15);
       if (q < N) {
         bf16_t* dst = dbase + (long)q * 3 * D + (2 * (wave & 1)) * 16 + 4 * g;

@@ -9,6 +9,7 @@ Precision: ``"bf16"`` = bf16 activations and weights on MFMA with fp32 accumulat
 """
 import ctypes
 import os
+import threading
 import weakref
 
 import torch
@@ -306,32 +307,32 @@ def split3(x, rows, cols, ldx, role, stack=False):
 # two role-0 side-by-side splits are kept (with a reference to their source tensor) and reused when the same tensor and
 # geometry come again.  Nothing is remembered outside a scope, and a scope must not write into a tensor it has already
 # split (the kernels write through raw pointers: no version counter would notice).
-_split_memo = None
+_split_tls = threading.local()        # backward runs on autograd's per-device worker threads: one memo per thread
 
 
 class split_scope:
     def __enter__(self):
-        global _split_memo
-        self.prev, _split_memo = _split_memo, []
+        self.prev = getattr(_split_tls, "memo", None)
+        _split_tls.memo = []
         return self
 
     def __exit__(self, *exc):
-        global _split_memo
-        _split_memo = self.prev
+        _split_tls.memo = self.prev
         return False
 
 
 def split_act(x, rows, cols, ldx):
     """Role-0 side-by-side split [rows, 6 * cols] of an activation / gradient, memoised inside a ``split_scope``."""
-    if _split_memo is None:
+    memo = getattr(_split_tls, "memo", None)
+    if memo is None:
         return split3(x, rows, cols, ldx, 0)
-    for ent in _split_memo:
+    for ent in memo:
         if ent[1] == (rows, cols, ldx, x.data_ptr()):        # ent[0] keeps that storage alive: the address cannot be reused
             return ent[2]
     out = split3(x, rows, cols, ldx, 0)
-    _split_memo.append((x, (rows, cols, ldx, x.data_ptr()), out))
-    if len(_split_memo) > 2:
-        _split_memo.pop(0)
+    memo.append((x, (rows, cols, ldx, x.data_ptr()), out))
+    if len(memo) > 2:
+        memo.pop(0)
     return out
 
 
