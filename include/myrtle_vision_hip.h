@@ -249,6 +249,13 @@ int mv_quant_affine_i8(const void* x, int x_dtype, void* codes, long rows, int c
 int mv_gemm_nt_i8(const void* A, int lda, const void* B, int ldb, void* C, int ldc, int c_dtype, int M, int N, int K,
                   float alpha, const float* bias, const int* icorr, int epilogue, const void* aux, int ld_aux,
                   float q_scale, int q_zero_point, mv_stream_t stream);
+/* The same fp32 core for TRAINING in precision="fp32" (vit.py:92-96 forward and its autograd backward), still without the
+ * [B, H, N, N] tensors: the forward also leaves lse[b, h, n] = log sum_j exp(scale q_n . k_j) (fp32 [B, H, N]); the backward
+ * recomputes the probabilities from it and returns dqkv (fp32, qkv's layout) from qkv, out (the forward's result), dout.
+ * N <= 272, dim_head 64. */
+int mv_attention_fwd_f32_lse(const float* qkv, float* out, float* lse, int B, int N, int H, float scale, mv_stream_t stream);
+int mv_attention_bwd_f32(const float* qkv, const float* out, const float* dout, const float* lse, float* dqkv, int B, int N,
+                         int H, float scale, mv_stream_t stream);
 /* Producers with the NEXT layer's quint8 quantiser fused in (converted PyTorchINT8 model; bit-identical to producer +
  * mv_quant_affine_i8): LayerNorm (vit.py:37,41) and the exact-fp32 attention core (vit.py:92-97, quant_out) writing int8
  * codes q - 128 [rows, dim] / [B, N, H*64] directly.  With MV_EPI_GELU_Q8 above they remove every fp32 activation tensor

@@ -29,7 +29,8 @@ constexpr int AF_DH = 64;
 // Q8 = true: the result goes straight into to_out's quint8 quantiser and leaves as int8 codes q - 128 ([B, N, H*64] int8)
 template <int NT, bool Q8 = false>
 __global__ __launch_bounds__(512) void attn_fwd_f32_kernel(const float* __restrict__ qkv, float* __restrict__ out, int N,
-                                                           int H, float scale, float q_inv = 0.f, float q_zp = 0.f) {
+                                                           int H, float scale, float q_inv = 0.f, float q_zp = 0.f,
+                                                           float* __restrict__ lse = nullptr) {
   constexpr int NK = NT * 16;
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float* const Ks = smem;                    // [NK][64]
@@ -118,6 +119,7 @@ __global__ __launch_bounds__(512) void attn_fwd_f32_kernel(const float* __restri
     const float inv = 1.0f / s;
 #pragma unroll
     for (int T = 0; T < NT; ++T) acc[T] *= inv;
+    if (lse && g == 0 && q < N) lse[((long)b * H + h) * N + q] = mx + logf(s);     // log sum_j exp(scale q.k_j): for backward
 
     // ---- O^T = V^T P^T: o[dt][r] = out(query q, feature 16 dt + 4 g + r)
     f32x4 o[4];
@@ -158,13 +160,233 @@ __global__ __launch_bounds__(512) void attn_fwd_f32_kernel(const float* __restri
   }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// Backward of the same core in fp32 (training in precision="fp32"): dq, dk, dv from q, k, v, out, d(out) and the saved
+// log-sum-exp -- no [B, H, N, N] tensor in either direction (the materialised path wrote and re-read 1.4 GB of scores,
+// probabilities and their gradients per layer at batch 64, with 197 x 197 x 64 products at 27-47 TFLOP/s).
+// One workgroup (8 waves) per (image, head), two passes over the SAME two LDS regions, no barrier inside a pass:
+//   pass A (dQ):    R0 = K, R1 = V (row-major, the forward kernel's K image).  A wave owns 16 queries: S^T = K Q^T and
+//                   dP^T = V dO^T (a lane holds one query and four keys per key tile), P^T = exp(scale S^T - lse),
+//                   delta = rowsum(dO * out) from the query's own fragments, dS^T = P^T (dP^T - delta) scale is at once the
+//                   A operand of dQ[q][d] += dS[q][key] K[key][d] (B operand: 4-byte reads of K rows).
+//   pass B (dK/dV): R0 = Q, R1 = dO.  A wave owns 16 keys (K, V fragments in registers): S = Q K^T and dP = dO V^T (a lane
+//                   holds one key and four queries per query tile), P and dS are the A operands of dV[key][d] += P[q][key]
+//                   dO[q][d] and dK[key][d] += dS[q][key] Q[q][d].
+// S and dP are computed in both passes (7 products instead of 5): the f32 matrix pipe is the bound either way, and nothing
+// crosses between waves but delta (written in pass A, read after the one barrier pair between the passes).
+// Same k-assignment rule as the forward kernel: lane group g supplies k = 16 c + 4 g + kk in step (c, kk) on both operands.
+// ---------------------------------------------------------------------------------------------------------------------
+template <int NT>
+__global__ __launch_bounds__(512) void attn_bwd_f32_kernel(const float* __restrict__ qkv, const float* __restrict__ out,
+                                                           const float* __restrict__ dout, const float* __restrict__ lse,
+                                                           float* __restrict__ dqkv, int N, int H, float scale) {
+  constexpr int NK = NT * 16;
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float* const R0 = smem;                    // [NK][64]: K, then Q
+  float* const R1 = smem + NK * AF_DH;       // [NK][64]: V, then dO
+  float* const sLse = R1 + NK * AF_DH;       // [NK]; +inf for rows >= N (their probabilities are exactly 0)
+  float* const sDelta = sLse + NK;           // [NK]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int q16 = lane & 15, g = lane >> 4;
+  const int b = blockIdx.x / H, h = blockIdx.x % H;
+  const long row = 3L * H * AF_DH, orow = (long)H * AF_DH;
+  const float* const qb = qkv + (long)b * N * row + (long)h * AF_DH;
+  const float* const kb = qb + orow;
+  const float* const vb = kb + orow;
+  const float* const ob = out + (long)b * N * orow + (long)h * AF_DH;
+  const float* const dob = dout + (long)b * N * orow + (long)h * AF_DH;
+  float* const dqb = dqkv + (long)b * N * row + (long)h * AF_DH;
+
+  // rows of one [N][64] operand -> LDS (swizzled 16-byte slots, rows >= N zero)
+  auto stage = [&](float* dst, const float* src, long ld) {
+    for (int i = tid; i < NK * 16; i += 512) {
+      const int r = i >> 4, j = i & 15;
+      f32x4 v = {0.f, 0.f, 0.f, 0.f};
+      if (r < N) v = *reinterpret_cast<const f32x4*>(src + r * ld + 4 * j);
+      *reinterpret_cast<f32x4*>(dst + r * AF_DH + ((j ^ (r & 15)) << 2)) = v;
+    }
+  };
+  // A-operand fragments of the 16 rows of tile T: lane (row q16, group g) gets floats 16 c + 4 g .. + 3
+  auto load_rows = [&](f32x4 (&dst)[4], const float* R, int T) {
+    const int r = T * 16 + q16;
+#pragma unroll
+    for (int c = 0; c < 4; ++c) dst[c] = *reinterpret_cast<const f32x4*>(R + r * AF_DH + (((4 * c + g) ^ (r & 15)) << 2));
+  };
+  // B operand of the products that contract over ROWS: element (row 16 T + 4 g + r, column 16 dt + q16)
+  auto elem = [&](const float* R, int T, int r, int dt) -> float {
+    const int rr = T * 16 + 4 * g + r, d = 16 * dt + q16;
+    return R[rr * AF_DH + ((((d >> 2) ^ (rr & 15)) << 2) | (d & 3))];
+  };
+  // B-operand fragments of one global row (clamped; masked through lse / key < N)
+  auto load_global = [&](f32x4 (&dst)[4], const float* base, long ld, int r) {
+    const float* p = base + (long)(r < N ? r : N - 1) * ld + 4 * g;
+#pragma unroll
+    for (int c = 0; c < 4; ++c) dst[c] = *reinterpret_cast<const f32x4*>(p + 16 * c);
+  };
+
+  stage(R0, kb, row);
+  stage(R1, vb, row);
+  for (int i = tid; i < NK; i += 512) {
+    sLse[i] = i < N ? lse[((long)b * H + h) * N + i] : INFINITY;
+    sDelta[i] = 0.f;
+  }
+  __syncthreads();
+
+  // ---------------- pass A: dQ ----------------
+  for (int qt = wave; qt * 16 < N; qt += 8) {
+    const int q = qt * 16 + q16;
+    f32x4 qf[4], dof[4], of[4];
+    load_global(qf, qb, row, q);
+    load_global(dof, dob, orow, q);
+    load_global(of, ob, orow, q);
+    float dl = 0.f;
+#pragma unroll
+    for (int c = 0; c < 4; ++c)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) dl += dof[c][e] * of[c][e];
+    dl += __shfl_xor(dl, 16, 64);
+    dl += __shfl_xor(dl, 32, 64);
+    if (g == 0) sDelta[q] = dl;                  // q < NK always; pass B reads it after the barrier
+    const float l = sLse[q];
+    f32x4 dq[4];
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt) dq[dt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    f32x4 kf[4], vf[4], kn[4], vn[4];
+    load_rows(kf, R0, 0);
+    load_rows(vf, R1, 0);
+#pragma unroll 1
+    for (int T = 0; T < NT; ++T) {
+      if (T + 1 < NT) {
+        load_rows(kn, R0, T + 1);
+        load_rows(vn, R1, T + 1);
+      }
+      f32x4 st = {0.f, 0.f, 0.f, 0.f}, dp = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int c = 0; c < 4; ++c)
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) {
+          st = __builtin_amdgcn_mfma_f32_16x16x4f32(kf[c][kk], qf[c][kk], st, 0, 0, 0);
+          dp = __builtin_amdgcn_mfma_f32_16x16x4f32(vf[c][kk], dof[c][kk], dp, 0, 0, 0);
+        }
+      f32x4 ds;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int key = T * 16 + 4 * g + r;
+        const float p = key < N ? expf(st[r] * scale - l) : 0.f;
+        ds[r] = p * (dp[r] - dl) * scale;
+      }
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt) dq[dt] = __builtin_amdgcn_mfma_f32_16x16x4f32(ds[r], elem(R0, T, r, dt), dq[dt], 0, 0, 0);
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        kf[c] = kn[c];
+        vf[c] = vn[c];
+      }
+    }
+    // dq[dt][r] = dQ(query 16 qt + 4 g + r, feature 16 dt + q16)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int qq = qt * 16 + 4 * g + r;
+      if (qq < N) {
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt) dqb[(long)qq * row + 16 * dt + q16] = dq[dt][r];
+      }
+    }
+  }
+
+  // ---------------- the same LDS bytes now hold Q and dO ----------------
+  __syncthreads();
+  stage(R0, qb, row);
+  stage(R1, dob, orow);
+  __syncthreads();
+
+  // ---------------- pass B: dK, dV ----------------
+  for (int kt = wave; kt * 16 < N; kt += 8) {
+    const int key = kt * 16 + q16;
+    f32x4 kf[4], vf[4];
+    load_global(kf, kb, row, key);
+    load_global(vf, vb, row, key);
+    f32x4 dk[4], dv[4];
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt) {
+      dk[dt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+      dv[dt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    }
+    f32x4 qa[4], da[4], qn[4], dn[4];
+    load_rows(qa, R0, 0);
+    load_rows(da, R1, 0);
+#pragma unroll 1
+    for (int T = 0; T < NT; ++T) {
+      if (T + 1 < NT) {
+        load_rows(qn, R0, T + 1);
+        load_rows(dn, R1, T + 1);
+      }
+      const f32x4 l4 = *reinterpret_cast<const f32x4*>(sLse + T * 16 + 4 * g);
+      const f32x4 d4 = *reinterpret_cast<const f32x4*>(sDelta + T * 16 + 4 * g);
+      f32x4 sv = {0.f, 0.f, 0.f, 0.f}, dp = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int c = 0; c < 4; ++c)
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) {
+          sv = __builtin_amdgcn_mfma_f32_16x16x4f32(qa[c][kk], kf[c][kk], sv, 0, 0, 0);
+          dp = __builtin_amdgcn_mfma_f32_16x16x4f32(da[c][kk], vf[c][kk], dp, 0, 0, 0);
+        }
+      f32x4 p, ds;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const float e = key < N ? expf(sv[r] * scale - l4[r]) : 0.f;      // lse = +inf for padded queries: exp(-inf) = 0
+        p[r] = e;
+        ds[r] = e * (dp[r] - d4[r]) * scale;
+      }
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt) {
+          dv[dt] = __builtin_amdgcn_mfma_f32_16x16x4f32(p[r], elem(R1, T, r, dt), dv[dt], 0, 0, 0);
+          dk[dt] = __builtin_amdgcn_mfma_f32_16x16x4f32(ds[r], elem(R0, T, r, dt), dk[dt], 0, 0, 0);
+        }
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        qa[c] = qn[c];
+        da[c] = dn[c];
+      }
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int kk = kt * 16 + 4 * g + r;
+      if (kk < N) {
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt) {
+          dqb[(long)kk * row + orow + 16 * dt + q16] = dk[dt][r];
+          dqb[(long)kk * row + 2 * orow + 16 * dt + q16] = dv[dt][r];
+        }
+      }
+    }
+  }
+}
+
+template <int NT>
+int launch_attn_bwd_f32(const float* qkv, const float* out, const float* dout, const float* lse, float* dqkv, int B, int N,
+                        int H, float scale, hipStream_t s) {
+  constexpr size_t lds = ((size_t)2 * NT * 16 * AF_DH + 2 * NT * 16) * sizeof(float);
+  static const int attr = hipFuncSetAttribute(reinterpret_cast<const void*>(attn_bwd_f32_kernel<NT>),
+                                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) == hipSuccess ? 0 : -1;
+  if (attr) return MV_ERR_LAUNCH;
+  attn_bwd_f32_kernel<NT><<<B * H, 512, lds, s>>>(qkv, out, dout, lse, dqkv, N, H, scale);
+  MV_CHECK_LAUNCH();
+  return MV_OK;
+}
+
 template <int NT, bool Q8>
-int launch_attn_f32(const float* qkv, void* out, int B, int N, int H, float scale, float q_inv, float q_zp, hipStream_t s) {
+int launch_attn_f32(const float* qkv, void* out, int B, int N, int H, float scale, float q_inv, float q_zp, hipStream_t s,
+                    float* lse = nullptr) {
   constexpr size_t lds = (size_t)2 * NT * 16 * AF_DH * sizeof(float);
   static const int attr = hipFuncSetAttribute(reinterpret_cast<const void*>(attn_fwd_f32_kernel<NT, Q8>),
                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) == hipSuccess ? 0 : -1;
   if (attr) return MV_ERR_LAUNCH;
-  attn_fwd_f32_kernel<NT, Q8><<<B * H, 512, lds, s>>>(qkv, (float*)out, N, H, scale, q_inv, q_zp);
+  attn_fwd_f32_kernel<NT, Q8><<<B * H, 512, lds, s>>>(qkv, (float*)out, N, H, scale, q_inv, q_zp, lse);
   MV_CHECK_LAUNCH();
   return MV_OK;
 }
@@ -191,4 +413,26 @@ extern "C" int mv_attention_fwd_f32_q8(const float* qkv, void* codes, int B, int
   const float inv = 1.0f / q_scale, fz = (float)q_zero_point;
   return N <= 208 ? launch_attn_f32<13, true>(qkv, codes, B, N, H, scale, inv, fz, s)
                   : launch_attn_f32<17, true>(qkv, codes, B, N, H, scale, inv, fz, s);
+}
+
+extern "C" int mv_attention_fwd_f32_lse(const float* qkv, float* out, float* lse, int B, int N, int H, float scale,
+                                        mv_stream_t stream) {
+  MV_REQUIRE(B >= 0 && N > 0 && H > 0 && (long)B * H < (1L << 31), MV_ERR_SHAPE);
+  MV_REQUIRE(N <= 272, MV_ERR_UNSUPPORTED);
+  MV_REQUIRE(mv_aligned16(qkv) && mv_aligned16(out) && lse, MV_ERR_ALIGN);
+  if (B == 0) return MV_OK;
+  hipStream_t s = (hipStream_t)stream;
+  return N <= 208 ? launch_attn_f32<13, false>(qkv, out, B, N, H, scale, 0.f, 0.f, s, lse)
+                  : launch_attn_f32<17, false>(qkv, out, B, N, H, scale, 0.f, 0.f, s, lse);
+}
+
+extern "C" int mv_attention_bwd_f32(const float* qkv, const float* out, const float* dout, const float* lse, float* dqkv,
+                                    int B, int N, int H, float scale, mv_stream_t stream) {
+  MV_REQUIRE(B >= 0 && N > 0 && H > 0 && (long)B * H < (1L << 31), MV_ERR_SHAPE);
+  MV_REQUIRE(N <= 272, MV_ERR_UNSUPPORTED);
+  MV_REQUIRE(mv_aligned16(qkv) && mv_aligned16(out) && mv_aligned16(dout) && mv_aligned16(dqkv) && lse, MV_ERR_ALIGN);
+  if (B == 0) return MV_OK;
+  hipStream_t s = (hipStream_t)stream;
+  return N <= 208 ? launch_attn_bwd_f32<13>(qkv, out, dout, lse, dqkv, B, N, H, scale, s)
+                  : launch_attn_bwd_f32<17>(qkv, out, dout, lse, dqkv, B, N, H, scale, s);
 }

@@ -335,6 +335,27 @@ class _AttentionPV(Function):
         return dP, dqkv, None
 
 
+class _AttentionFusedF32(Function):
+    """The fp32 attention core with gradients, fused both ways (no [B, H, N, N] tensor): saves qkv, out and the
+    log-sum-exp; the backward kernel recomputes the probabilities."""
+
+    @staticmethod
+    def forward(ctx, qkv, heads, scale):
+        B, N, _ = qkv.shape
+        qkv = _c(qkv)
+        out, lse = ops.attention_fwd_f32_lse(qkv, B, N, heads, scale)
+        ctx.save_for_backward(qkv, out, lse)
+        ctx.cfg = (heads, scale)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        qkv, out, lse = ctx.saved_tensors
+        heads, scale = ctx.cfg
+        B, N, _ = qkv.shape
+        return ops.attention_bwd_f32_fused(qkv, out, _c(dout.float()), lse, B, N, heads, scale), None, None
+
+
 def attention_core(qkv, heads, scale, probs_hook=None):
     """Attention.forward lines vit.py:87-96 on a to_qkv output [B, N, 3*heads*dh].
 
@@ -349,6 +370,8 @@ def attention_core(qkv, heads, scale, probs_hook=None):
             and not (torch.is_grad_enabled() and qkv.requires_grad)):
         # no gradient wanted (converted int8 model, fp32 evaluation): exact fp32 arithmetic without the probabilities
         return ops.attention_fwd_f32(_c(qkv), B, N, heads, scale)
+    if probs_hook is None and ops.attention_f32_fused_supported(qkv.dtype, N, dh):
+        return _AttentionFusedF32.apply(qkv, heads, scale)          # fp32 with gradients: fused forward + backward
     src_dtype = qkv.dtype
     q32 = cast(qkv, torch.float32)
     probs = _AttentionProbs.apply(q32, heads, scale)
@@ -481,15 +504,22 @@ class _AttnBlock(Function):
             y6 = ops.split_ex(y, M, D)
             qkv = torch.empty(B, T, inner3, dtype=adt, device=x.device)
             ops.nt_x6(y6, wqkv, "fwd", M, qkv.view(M, inner3), bias=bqkv)
-            if ops.attention_f32_fused_supported(adt, T, dh) and not any(ctx.needs_input_grad):
-                o, probs = ops.attention_fwd_f32(qkv, B, T, heads, scale), x.new_empty(0)      # evaluation: no probabilities kept
+            o = None
+            if ops.attention_f32_fused_supported(adt, T, dh):
+                if any(ctx.needs_input_grad):
+                    o, probs = ops.attention_fwd_f32_lse(qkv, B, T, heads, scale)   # "probs" slot: the log-sum-exp [B, H, T]
+                else:
+                    o, probs = ops.attention_fwd_f32(qkv, B, T, heads, scale), x.new_empty(0)   # evaluation
+                ctx.fused32 = True
             else:
                 probs = ops.attention_probs_fp32(qkv, B, T, heads, dh, scale)
                 o = ops.attention_pv_fp32(probs, qkv, B, T, heads, dh)
+                ctx.fused32 = False
             o6 = ops.split_ex(o.view(M, inner), M, inner)
             out = torch.empty_like(x)
             ops.nt_x6(o6, wo, "fwd", M, out.view(M, D), bias=bo, residual=x.view(M, D))
-            ctx.save_for_backward(x, g, mean, rstd, y6, qkv, o6, probs, wqkv, wo)
+            # the fused backward needs the attention output itself (delta = rowsum(dO * O)), not only its split
+            ctx.save_for_backward(x, g, mean, rstd, y6, qkv, o6, probs, wqkv, wo, *((o,) if ctx.fused32 else ()))
             ctx.cfg = (heads, scale, False)
             ctx.small = (b, bqkv, bo)
             _chain_set(out, bo)
@@ -503,7 +533,11 @@ class _AttnBlock(Function):
         elif ops.attention_f32_fused_supported(adt, T, dh) and not any(ctx.needs_input_grad):
             # fp32 evaluation: nothing will run backward, so the probabilities need not exist
             o, lse, probs = ops.attention_fwd_f32(qkv, B, T, heads, scale), None, None
-        else:                                   # materialised fp32 probabilities (fp32 mode, or shapes the fused kernel lacks)
+        elif ops.attention_f32_fused_supported(adt, T, dh):
+            # fp32 training: fused forward + backward kernels, the log-sum-exp rides in the probabilities' slot
+            o, probs = ops.attention_fwd_f32_lse(qkv, B, T, heads, scale)
+            lse, ctx.fused32 = None, True
+        else:                                   # materialised fp32 probabilities (shapes the fused kernels lack)
             q32 = ops.cast(qkv, torch.float32)
             probs = ops.attention_probs_fp32(q32, B, T, heads, dh, scale)
             o = ops.cast(ops.attention_pv_fp32(probs, q32, B, T, heads, dh), adt)
@@ -521,7 +555,7 @@ class _AttnBlock(Function):
     @staticmethod
     @_scoped
     def backward(ctx, dout):
-        x, g, mean, rstd, y, qkv, o, lse_or_probs, wqkv, wo = ctx.saved_tensors
+        x, g, mean, rstd, y, qkv, o, lse_or_probs, wqkv, wo = ctx.saved_tensors[:10]
         heads, scale, fused = ctx.cfg
         B, T, D = x.shape
         M = B * T
@@ -536,7 +570,10 @@ class _AttnBlock(Function):
             dwo = ops.tn_x6(d6, o6, M, wo)
             do = torch.empty(B, T, inner, dtype=torch.float32, device=x.device)
             ops.nt_x6(d6, wo, "dx", M, do.view(M, inner))
-            dqkv = ops.attention_bwd_fp32(probs, qkv, do, B, T, heads, inner // heads, scale)
+            if ctx.fused32:
+                dqkv = ops.attention_bwd_f32_fused(qkv, ctx.saved_tensors[10], do, probs, B, T, heads, scale)
+            else:
+                dqkv = ops.attention_bwd_fp32(probs, qkv, do, B, T, heads, inner // heads, scale)
             dbqkv = ops.grad_out(bqkv, (inner3,), x.device)
             dq6 = ops.split_ex(dqkv.view(M, inner3), M, inner3, colsum_out=dbqkv)
             dwqkv = ops.tn_x6(dq6, y6, M, wqkv)
@@ -560,6 +597,8 @@ class _AttnBlock(Function):
             part = torch.empty(B, inner3, dtype=torch.float32, device=x.device)
             dqkv = ops.attention_bwd(qkv, o, do, lse_or_probs, B, T, heads, scale, colsum=part)
             dbqkv = ops.colsum(part, B, inner3, inner3, ops.grad_out(bqkv, (inner3,), x.device))
+        elif getattr(ctx, "fused32", False):
+            dqkv = ops.attention_bwd_f32_fused(qkv, o, do, lse_or_probs, B, T, heads, scale)
         else:
             dqkv = ops.cast(ops.attention_bwd_fp32(lse_or_probs, ops.cast(qkv, torch.float32), ops.cast(do, torch.float32),
                                                    B, T, heads, inner // heads, scale), adt)

@@ -599,6 +599,24 @@ def attention_fwd_f32(qkv, B, N, H, scale):
     return out
 
 
+def attention_fwd_f32_lse(qkv, B, N, H, scale):
+    """fp32 attention core for training: -> (out fp32 [B, N, H*64], lse fp32 [B, H, N]); no probabilities are kept."""
+    require_cuda(qkv)
+    out = torch.empty(B, N, H * 64, dtype=torch.float32, device=qkv.device)
+    lse = torch.empty(B, H, N, dtype=torch.float32, device=qkv.device)
+    check(lib().mv_attention_fwd_f32_lse(_p(qkv), _p(out), _p(lse), B, N, H, scale, _s()), "attention_fwd_f32_lse",
+          B=B, N=N, H=H)
+    return out, lse
+
+
+def attention_bwd_f32_fused(qkv, out, dout, lse, B, N, H, scale):
+    """-> dqkv fp32 (qkv's layout) from the saved output and log-sum-exp."""
+    dqkv = torch.empty_like(qkv)
+    check(lib().mv_attention_bwd_f32(_p(qkv), _p(out), _p(dout), _p(lse), _p(dqkv), B, N, H, scale, _s()),
+          "attention_bwd_f32", B=B, N=N, H=H)
+    return dqkv
+
+
 def attention_probs_fp32(qkv, B, N, H, dh, scale):
     """Materialised path (fp32): probs[B, H, N, N] = softmax(q k^T * scale).  qkv fp32 [B, N, 3, H, dh]."""
     D = H * dh

@@ -530,18 +530,48 @@ def test_attention_fused_fp32_forward(ops, B, N, H):
     assert relerr(out2, want2) < 5e-5 and torch.equal(out2, ops.attention_fwd_f32(qkv2.cuda(), B, N, H, scale))
 
 
+@pytest.mark.parametrize("B,N,H", [(2, 197, 3), (1, 257, 2), (3, 50, 1), (1, 17, 12), (2, 208, 2), (1, 272, 1)])
+def test_attention_fused_fp32_backward(ops, B, N, H):
+    """mv_attention_fwd_f32_lse + mv_attention_bwd_f32 (fp32 training without the [B, H, N, N] tensors) against fp64
+    autograd and against the materialised fp32 backward they replace."""
+    scale = 64 ** -0.5
+    qkv = torch.randn(B, N, 3 * H * 64, generator=g(1)) * 1.5
+    dout = torch.randn(B, N, H * 64, generator=g(2))
+    ref_in = qkv.double().requires_grad_(True)
+    want, _ = attn_ref(ref_in, H, scale)
+    want.backward(dout.double())
+    out, lse = ops.attention_fwd_f32_lse(qkv.cuda(), B, N, H, scale)
+    assert relerr(out, want) < 2e-6 and torch.equal(out, ops.attention_fwd_f32(qkv.cuda(), B, N, H, scale))
+    q, k, _ = qkv.double().view(B, N, 3, H, 64).permute(2, 0, 3, 1, 4)
+    assert float((lse.cpu().double() - torch.logsumexp((q @ k.transpose(-2, -1)) * scale, dim=-1)).abs().max()) < 2e-5
+    dqkv = ops.attention_bwd_f32_fused(qkv.cuda(), out, dout.cuda(), lse, B, N, H, scale)
+    got, ref = dqkv.cpu().view(B, N, 3, H, 64), ref_in.grad.view(B, N, 3, H, 64)
+    for i, name in enumerate("qkv"):
+        assert relerr(got[:, :, i], ref[:, :, i]) < 5e-6, name
+    probs = ops.attention_probs_fp32(qkv.cuda(), B, N, H, 64, scale)
+    mat = ops.attention_bwd_fp32(probs, qkv.cuda(), dout.cuda(), B, N, H, 64, scale)
+    assert relerr(dqkv, mat.double().cpu()) < 5e-6
+    assert torch.equal(dqkv, ops.attention_bwd_f32_fused(qkv.cuda(), out, dout.cuda(), lse, B, N, H, scale))   # deterministic
+
+
 def test_attention_core_dispatch_fp32(ops):
-    """attention_core: fp32 input without gradient -> the fused fp32 kernel; with gradient -> the materialised path (its
-    backward needs the probabilities); a hook on attn_output always materialises."""
+    """attention_core: fp32 input without gradient -> the fused fp32 forward kernel; with gradient -> the fused forward +
+    backward pair (no probabilities kept); a hook on attn_output always materialises."""
     from myrtle_vision.hip import functional as F
     qkv = torch.randn(2, 197, 3 * 2 * 64, generator=g(1)).cuda()
     with torch.no_grad():
         a = F.attention_core(qkv, 2, 0.125, None)
-    b = F.attention_core(qkv.clone().requires_grad_(True), 2, 0.125, None)
+    qg = qkv.clone().requires_grad_(True)
+    b = F.attention_core(qg, 2, 0.125, None)
     seen = []
-    c = F.attention_core(qkv, 2, 0.125, lambda p: (seen.append(p.shape), p)[1])
+    qh = qkv.clone().requires_grad_(True)
+    c = F.attention_core(qh, 2, 0.125, lambda p: (seen.append(p.shape), p)[1])
     assert b.requires_grad and not a.requires_grad and seen == [(2, 2, 197, 197)]
-    assert relerr(a, b.detach().double().cpu()) < 2e-6 and torch.equal(b.detach(), c)
+    assert torch.equal(a, b.detach()) and relerr(b, c.detach().double().cpu()) < 2e-6
+    dout = torch.randn(2, 197, 128, generator=g(2)).cuda()
+    b.backward(dout)
+    c.backward(dout)
+    assert relerr(qg.grad, qh.grad.double().cpu()) < 5e-6          # fused backward == materialised backward
 
 
 # ---------------------------------------------------------------- elementwise / layout
