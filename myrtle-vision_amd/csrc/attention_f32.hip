@@ -24,44 +24,82 @@
 namespace {
 
 constexpr int AF_DH = 64;
+constexpr float AF_LOG2E = 1.4426950408889634f, AF_LN2 = 0.6931471805599453f;
+#ifndef MV_AF_ABLATE
+#define MV_AF_ABLATE 0   // diagnostic builds only: 1 no S products, 2 no softmax, 4 no PV products, 8 no staging, 16 no output
+#endif
 
 // NT = key/query tiles of 16 (13: N <= 208, i.e. 197 tokens; 17: N <= 272, i.e. 257 tokens)
 // Q8 = true: the result goes straight into to_out's quint8 quantiser and leaves as int8 codes q - 128 ([B, N, H*64] int8)
 template <int NT, bool Q8 = false>
 __global__ __launch_bounds__(512) void attn_fwd_f32_kernel(const float* __restrict__ qkv, float* __restrict__ out, int N,
                                                            int H, float scale, float q_inv = 0.f, float q_zp = 0.f,
-                                                           float* __restrict__ lse = nullptr) {
+                                                           float* __restrict__ lse = nullptr, int n_items = 0) {
   constexpr int NK = NT * 16;
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float* const Ks = smem;                    // [NK][64]
   float* const Vt = smem + NK * AF_DH;       // [64][NK]
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int b = blockIdx.x / H, h = blockIdx.x % H;
   const long row = 3L * H * AF_DH;           // floats between consecutive tokens
-  const float* const qb = qkv + (long)b * N * row + (long)h * AF_DH;
-  const float* const kb = qb + (long)H * AF_DH;
-  const float* const vb = kb + (long)H * AF_DH;
 
-  // ---- stage K (row-major, swizzled slots) and V^T; keys >= N are zero rows / columns
-  for (int i = tid; i < NK * 16; i += 512) {
-    const int key = i >> 4, j = i & 15;
-    f32x4 v = {0.f, 0.f, 0.f, 0.f};
-    if (key < N) v = *reinterpret_cast<const f32x4*>(kb + key * row + 4 * j);
-    *reinterpret_cast<f32x4*>(Ks + key * AF_DH + ((j ^ (key & 15)) << 2)) = v;
-  }
-  for (int i = tid; i < NK * 16; i += 512) {
-    const int key = i % NK, j = i / NK;      // lanes walk the keys: the transposed writes below are conflict-free
-    f32x4 v = {0.f, 0.f, 0.f, 0.f};
-    if (key < N) v = *reinterpret_cast<const f32x4*>(vb + key * row + 4 * j);
+  // ---- staging of K (row-major, swizzled slots) and V^T of one (image, head); keys >= N are zero rows / columns.
+  // The kernel is PERSISTENT (grid = #CUs, one workgroup per CU by LDS): a workgroup walks items blockIdx.x, + gridDim.x, ...
+  // and the 16-byte global loads of the NEXT item's K and V (7 + 7 per thread at 197 tokens) are issued before the current
+  // item's products and land under them; only the LDS writes (between two barriers) stay exposed.  With one item per
+  // workgroup the staging loads were 108 of 511 us at batch 256 (phase ablation, tools/ablate_attn_f32.sh): nothing else
+  // runs on a CU whose only workgroup waits for memory.  NT = 17 (257 tokens) has no registers to spare: its next item's
+  // loads are issued after the current item's products.
+  constexpr int NIT = (NK * 16 + 511) / 512;
+  constexpr bool PREFETCH = NT <= 13;
+  f32x4 kst[NIT], vst[NIT];
+  auto issue_loads = [&](int item) {
+    const int ib = item / H, ih = item % H;
+    const float* const kb = qkv + (long)ib * N * row + (long)ih * AF_DH + (long)H * AF_DH;
+    const float* const vb = kb + (long)H * AF_DH;
 #pragma unroll
-    for (int e = 0; e < 4; ++e) {
-      const int d = 4 * j + e;
-      Vt[d * NK + ((((key >> 2) ^ ((d >> 2) & 3))) << 2) + (key & 3)] = v[e];
+    for (int it = 0; it < NIT; ++it) {
+      const int i = tid + 512 * it;
+      const int kkey = i >> 4, kj = i & 15;
+      const int vkey = i % NK, vj = i / NK;
+      kst[it] = (f32x4){0.f, 0.f, 0.f, 0.f};
+      vst[it] = (f32x4){0.f, 0.f, 0.f, 0.f};
+      if (i < NK * 16 && kkey < N && !(MV_AF_ABLATE & 8)) kst[it] = *reinterpret_cast<const f32x4*>(kb + kkey * row + 4 * kj);
+      if (i < NK * 16 && vkey < N && !(MV_AF_ABLATE & 8)) vst[it] = *reinterpret_cast<const f32x4*>(vb + vkey * row + 4 * vj);
     }
-  }
+  };
+  auto write_lds = [&]() {
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {
+      const int i = tid + 512 * it;
+      if (i < NK * 16) {
+        const int key = i >> 4, j = i & 15;
+        *reinterpret_cast<f32x4*>(Ks + key * AF_DH + ((j ^ (key & 15)) << 2)) = kst[it];
+      }
+    }
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {
+      const int i = tid + 512 * it;
+      if (i < NK * 16) {
+        const int key = i % NK, j = i / NK;    // lanes walk the keys: the transposed writes below are conflict-free
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const int d = 4 * j + e;
+          Vt[d * NK + ((((key >> 2) ^ ((d >> 2) & 3))) << 2) + (key & 3)] = vst[it][e];
+        }
+      }
+    }
+  };
+  issue_loads(blockIdx.x);
+  write_lds();
   __syncthreads();
 
   const int q16 = lane & 15, g = lane >> 4;
+  const float sl2 = scale * AF_LOG2E;
+  for (int item = blockIdx.x; item < n_items; item += gridDim.x) {
+  const int b = item / H, h = item % H;
+  const float* const qb = qkv + (long)b * N * row + (long)h * AF_DH;
+  const bool has_next = item + (int)gridDim.x < n_items;      // workgroup-uniform
+  if (PREFETCH && has_next) issue_loads(item + gridDim.x);
   for (int qt = wave; qt * 16 < N; qt += 8) {
     const int q = qt * 16 + q16;
     const float* qrow = qb + (long)(q < N ? q : N - 1) * row + 4 * g;       // clamped: rows >= N are never stored
@@ -87,7 +125,10 @@ __global__ __launch_bounds__(512) void attn_fwd_f32_kernel(const float* __restri
 #pragma unroll
       for (int c = 0; c < 4; ++c)
 #pragma unroll
-        for (int kk = 0; kk < 4; ++kk) acc[T] = __builtin_amdgcn_mfma_f32_16x16x4f32(kf[c][kk], qf[c][kk], acc[T], 0, 0, 0);
+        for (int kk = 0; kk < 4; ++kk) {
+          if (MV_AF_ABLATE & 1) continue;
+          acc[T] = __builtin_amdgcn_mfma_f32_16x16x4f32(kf[c][kk], qf[c][kk], acc[T], 0, 0, 0);
+        }
 #pragma unroll
       for (int c = 0; c < 4; ++c) kf[c] = kn[c];
       __builtin_amdgcn_sched_barrier(0);
@@ -99,7 +140,7 @@ __global__ __launch_bounds__(512) void attn_fwd_f32_kernel(const float* __restri
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const int key = T * 16 + 4 * g + r;
-        const float x = key < N ? acc[T][r] * scale : -INFINITY;
+        const float x = key < N ? acc[T][r] * sl2 : -INFINITY;        // scores in log2 units: exp2 is one instruction
         acc[T][r] = x;
         mx = fmaxf(mx, x);
       }
@@ -110,7 +151,7 @@ __global__ __launch_bounds__(512) void attn_fwd_f32_kernel(const float* __restri
     for (int T = 0; T < NT; ++T)
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        const float e = expf(acc[T][r] - mx);      // exp(-inf) = 0 for the padded keys
+        const float e = __builtin_amdgcn_exp2f(acc[T][r] - mx);      // exp2(-inf) = 0 for the padded keys
         acc[T][r] = e;
         s += e;
       }
@@ -119,7 +160,7 @@ __global__ __launch_bounds__(512) void attn_fwd_f32_kernel(const float* __restri
     const float inv = 1.0f / s;
 #pragma unroll
     for (int T = 0; T < NT; ++T) acc[T] *= inv;
-    if (lse && g == 0 && q < N) lse[((long)b * H + h) * N + q] = mx + logf(s);     // log sum_j exp(scale q.k_j): for backward
+    if (lse && g == 0 && q < N) lse[((long)b * H + h) * N + q] = (mx + __builtin_amdgcn_logf(s)) * AF_LN2;     // ln sum_j exp(scale q.k_j)
 
     // ---- O^T = V^T P^T: o[dt][r] = out(query q, feature 16 dt + 4 g + r)
     f32x4 o[4];
@@ -140,7 +181,10 @@ __global__ __launch_bounds__(512) void attn_fwd_f32_kernel(const float* __restri
 #pragma unroll
       for (int r = 0; r < 4; ++r)
 #pragma unroll
-        for (int dt = 0; dt < 4; ++dt) o[dt] = __builtin_amdgcn_mfma_f32_16x16x4f32(vf[dt][r], acc[T][r], o[dt], 0, 0, 0);
+        for (int dt = 0; dt < 4; ++dt) {
+          if (MV_AF_ABLATE & 4) continue;
+          o[dt] = __builtin_amdgcn_mfma_f32_16x16x4f32(vf[dt][r], acc[T][r], o[dt], 0, 0, 0);
+        }
 #pragma unroll
       for (int dt = 0; dt < 4; ++dt) vf[dt] = vn[dt];
       __builtin_amdgcn_sched_barrier(0);
@@ -157,6 +201,13 @@ __global__ __launch_bounds__(512) void attn_fwd_f32_kernel(const float* __restri
         for (int dt = 0; dt < 4; ++dt) *reinterpret_cast<f32x4*>(op + 16 * dt) = o[dt];
       }
     }
+  }
+  if (has_next) {
+    __syncthreads();                          // every wave is done reading this item's K / V^T
+    if (!PREFETCH) issue_loads(item + gridDim.x);
+    write_lds();
+    __syncthreads();
+  }
   }
 }
 
@@ -188,6 +239,7 @@ __global__ __launch_bounds__(512) void attn_bwd_f32_kernel(const float* __restri
   float* const sDelta = sLse + NK;           // [NK]
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int q16 = lane & 15, g = lane >> 4;
+  const float sl2 = scale * AF_LOG2E;
   const int b = blockIdx.x / H, h = blockIdx.x % H;
   const long row = 3L * H * AF_DH, orow = (long)H * AF_DH;
   const float* const qb = qkv + (long)b * N * row + (long)h * AF_DH;
@@ -197,13 +249,28 @@ __global__ __launch_bounds__(512) void attn_bwd_f32_kernel(const float* __restri
   const float* const dob = dout + (long)b * N * orow + (long)h * AF_DH;
   float* const dqb = dqkv + (long)b * N * row + (long)h * AF_DH;
 
-  // rows of one [N][64] operand -> LDS (swizzled 16-byte slots, rows >= N zero)
-  auto stage = [&](float* dst, const float* src, long ld) {
-    for (int i = tid; i < NK * 16; i += 512) {
-      const int r = i >> 4, j = i & 15;
-      f32x4 v = {0.f, 0.f, 0.f, 0.f};
-      if (r < N) v = *reinterpret_cast<const f32x4*>(src + r * ld + 4 * j);
-      *reinterpret_cast<f32x4*>(dst + r * AF_DH + ((j ^ (r & 15)) << 2)) = v;
+  // rows of two [N][64] operands -> R0, R1 (swizzled 16-byte slots, rows >= N zero); every load of the thread is issued
+  // before the first LDS write (see the forward kernel)
+  constexpr int NIT = (NK * 16 + 511) / 512;
+  auto stage2 = [&](const float* src0, long ld0, const float* src1, long ld1) {
+    f32x4 a[NIT], c[NIT];
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {
+      const int i = tid + 512 * it, r = i >> 4, j = i & 15;
+      a[it] = (f32x4){0.f, 0.f, 0.f, 0.f};
+      c[it] = (f32x4){0.f, 0.f, 0.f, 0.f};
+      if (i < NK * 16 && r < N) {
+        a[it] = *reinterpret_cast<const f32x4*>(src0 + r * ld0 + 4 * j);
+        c[it] = *reinterpret_cast<const f32x4*>(src1 + r * ld1 + 4 * j);
+      }
+    }
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {
+      const int i = tid + 512 * it, r = i >> 4, j = i & 15;
+      if (i < NK * 16) {
+        *reinterpret_cast<f32x4*>(R0 + r * AF_DH + ((j ^ (r & 15)) << 2)) = a[it];
+        *reinterpret_cast<f32x4*>(R1 + r * AF_DH + ((j ^ (r & 15)) << 2)) = c[it];
+      }
     }
   };
   // A-operand fragments of the 16 rows of tile T: lane (row q16, group g) gets floats 16 c + 4 g .. + 3
@@ -224,10 +291,9 @@ __global__ __launch_bounds__(512) void attn_bwd_f32_kernel(const float* __restri
     for (int c = 0; c < 4; ++c) dst[c] = *reinterpret_cast<const f32x4*>(p + 16 * c);
   };
 
-  stage(R0, kb, row);
-  stage(R1, vb, row);
+  stage2(kb, row, vb, row);
   for (int i = tid; i < NK; i += 512) {
-    sLse[i] = i < N ? lse[((long)b * H + h) * N + i] : INFINITY;
+    sLse[i] = i < N ? lse[((long)b * H + h) * N + i] * AF_LOG2E : INFINITY;     // log2 units, like the scores below
     sDelta[i] = 0.f;
   }
   __syncthreads();
@@ -272,7 +338,7 @@ __global__ __launch_bounds__(512) void attn_bwd_f32_kernel(const float* __restri
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const int key = T * 16 + 4 * g + r;
-        const float p = key < N ? expf(st[r] * scale - l) : 0.f;
+        const float p = key < N ? __builtin_amdgcn_exp2f(st[r] * sl2 - l) : 0.f;
         ds[r] = p * (dp[r] - dl) * scale;
       }
 #pragma unroll
@@ -298,8 +364,7 @@ __global__ __launch_bounds__(512) void attn_bwd_f32_kernel(const float* __restri
 
   // ---------------- the same LDS bytes now hold Q and dO ----------------
   __syncthreads();
-  stage(R0, qb, row);
-  stage(R1, dob, orow);
+  stage2(qb, row, dob, orow);
   __syncthreads();
 
   // ---------------- pass B: dK, dV ----------------
@@ -336,7 +401,7 @@ __global__ __launch_bounds__(512) void attn_bwd_f32_kernel(const float* __restri
       f32x4 p, ds;
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        const float e = key < N ? expf(sv[r] * scale - l4[r]) : 0.f;      // lse = +inf for padded queries: exp(-inf) = 0
+        const float e = key < N ? __builtin_amdgcn_exp2f(sv[r] * sl2 - l4[r]) : 0.f;   // lse = +inf for padded queries: 0
         p[r] = e;
         ds[r] = e * (dp[r] - d4[r]) * scale;
       }
@@ -386,7 +451,14 @@ int launch_attn_f32(const float* qkv, void* out, int B, int N, int H, float scal
   static const int attr = hipFuncSetAttribute(reinterpret_cast<const void*>(attn_fwd_f32_kernel<NT, Q8>),
                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) == hipSuccess ? 0 : -1;
   if (attr) return MV_ERR_LAUNCH;
-  attn_fwd_f32_kernel<NT, Q8><<<B * H, 512, lds, s>>>(qkv, (float*)out, N, H, scale, q_inv, q_zp, lse);
+  static const int n_cu = [] {
+    int dev = 0, n = 0;
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) n = 0;
+    return n > 0 ? n : 256;
+  }();
+  const int items = B * H;
+  attn_fwd_f32_kernel<NT, Q8><<<items < n_cu ? items : n_cu, 512, lds, s>>>(qkv, (float*)out, N, H, scale, q_inv, q_zp, lse,
+                                                                             items);
   MV_CHECK_LAUNCH();
   return MV_OK;
 }
