@@ -141,8 +141,20 @@ __device__ __forceinline__ void gelu_both_fast(float x, float& gl, float& dg) {
   gl = x * cdf;
   dg = fmaf(x * 0.39894228040143267794f, e, cdf);
 }
-constexpr bool epi_is_gelu(int e) { return e == MV_EPI_GELU || e == MV_EPI_GELU_GRAD; }
-constexpr bool epi_is_dgelu(int e) { return e == MV_EPI_DGELU || e == MV_EPI_MUL; }
+constexpr bool epi_is_gelu(int e) { return e == MV_EPI_GELU || e == MV_EPI_GELU_GRAD || e == MV_EPI_GELU_GRAD8; }
+constexpr bool epi_is_dgelu(int e) { return e == MV_EPI_DGELU || e == MV_EPI_MUL || e == MV_EPI_MUL8; }
+constexpr bool epi_is_gelugrad(int e) { return e == MV_EPI_GELU_GRAD || e == MV_EPI_GELU_GRAD8; }
+// gelu'(x) lies in [-0.1290, 1.1290]: MV_EPI_GELU_GRAD8 leaves it as an 8-bit code on a fixed grid (step 1.26 / 255 =
+// 0.00494, |error| <= 0.0025 -- below the bf16 rounding of the gradient it multiplies for |gelu'| > 0.6, 0.24 % of the rms
+// value overall), MV_EPI_MUL8 reads it back: one byte per hidden element instead of two in fc1's epilogue and in fc2-dX's.
+constexpr float GQ_LO = -0.13f, GQ_STEP = 1.26f / 255.0f, GQ_INV = 255.0f / 1.26f;
+__device__ __forceinline__ unsigned gq_code(float g) {
+  return (unsigned)__builtin_amdgcn_fmed3f(fmaf(g, GQ_INV, 0.5f - GQ_LO * GQ_INV), 0.f, 255.f);
+}
+__device__ __forceinline__ unsigned gq_pack4(const float (&g)[4]) {
+  return gq_code(g[0]) | (gq_code(g[1]) << 8) | (gq_code(g[2]) << 16) | (gq_code(g[3]) << 24);
+}
+__device__ __forceinline__ float gq_decode(unsigned w, int k) { return fmaf((float)((w >> (8 * k)) & 255u), GQ_STEP, GQ_LO); }
 __device__ __forceinline__ float dgelu_fast(float x) {
   float e;
   const float cdf = 0.5f * (1.0f + erf_fast(x * 0.70710678118654752440f, e));
@@ -224,7 +236,33 @@ __device__ __forceinline__ void nt_epilogue(f32x4 (&acc)[4][4], CT* __restrict__
         }
     }
     bf16x4 hx[4][4];                                   // DGELU: the saved pre-activation, kept packed (32 VGPRs, not 64)
-    if constexpr (epi_is_dgelu(EPI)) {
+    unsigned hq[4][4];                                 // MUL8: four 8-bit codes of gelu'
+    if constexpr (EPI == MV_EPI_MUL8) {
+      const unsigned char* a8 = reinterpret_cast<const unsigned char*>(ep.aux);
+      if ((ep.ld_aux & 15) == 0 && (reinterpret_cast<uintptr_t>(a8) & 15) == 0) {
+        // one 16-byte load per 16 rows (lane group g takes the 16 codes of column tile g), then the 4 x 4 transpose over
+        // (word, lane group) of MV_EPI_GELU_GRAD8's store, which is its own inverse: word j = tile j, columns 4g .. 4g+3
+        typedef unsigned u32x2_t __attribute__((ext_vector_type(2)));
+        u32x4 x[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+          x[i] = *reinterpret_cast<const u32x4*>(a8 + (long)(mb + i * 16) * ep.ld_aux + n0 + wn * 64 + 16 * (lane >> 4));
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const u32x2_t s01 = __builtin_amdgcn_permlane16_swap(x[i][0], x[i][1], false, false);
+          const u32x2_t s23 = __builtin_amdgcn_permlane16_swap(x[i][2], x[i][3], false, false);
+          const u32x2_t t02 = __builtin_amdgcn_permlane32_swap(s01[0], s23[0], false, false);
+          const u32x2_t t13 = __builtin_amdgcn_permlane32_swap(s01[1], s23[1], false, false);
+          hq[i][0] = t02[0]; hq[i][1] = t13[0]; hq[i][2] = t02[1]; hq[i][3] = t13[1];
+        }
+      } else {
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+          for (int j = 0; j < 4; ++j)
+            hq[i][j] = *reinterpret_cast<const unsigned*>(a8 + (long)(mb + i * 16) * ep.ld_aux + nb + j * 16);
+      }
+    } else if constexpr (epi_is_dgelu(EPI)) {
 #pragma unroll
       for (int i = 0; i < 4; ++i)
 #pragma unroll
@@ -238,11 +276,12 @@ __device__ __forceinline__ void nt_epilogue(f32x4 (&acc)[4][4], CT* __restrict__
 #pragma unroll
       for (int r = 0; r < 4; ++r) cs[j][r] = 0.f;
     if constexpr (sizeof(CT) == 2 && (EPI == MV_EPI_NONE || epi_is_gelu(EPI) || epi_is_dgelu(EPI))) {
-      if (((ldc & 7) == 0) && ((ep.ld_out2 & 7) == 0 || !epi_is_gelu(EPI))) {
+      if (((ldc & 7) == 0) && ((ep.ld_out2 & (EPI == MV_EPI_GELU_GRAD8 ? 15 : 7)) == 0 || !epi_is_gelu(EPI))) {
         const int g = lane >> 4;
         const int nw = n0 + wn * 64 + 16 * (g & 1) + 8 * (g >> 1);      // + 32 jp: first of this lane's 8 columns
 #pragma unroll
-        for (int i = 0; i < 4; ++i)
+        for (int i = 0; i < 4; ++i) {
+          unsigned gw[4] = {0u, 0u, 0u, 0u};                 // GELU_GRAD8: this row tile's codes, one word per column tile
 #pragma unroll
           for (int jp = 0; jp < 2; ++jp) {
             float v[2][4], hpre[2][4];
@@ -254,7 +293,7 @@ __device__ __forceinline__ void nt_epilogue(f32x4 (&acc)[4][4], CT* __restrict__
               if constexpr (epi_is_gelu(EPI)) {
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                  if constexpr (EPI == MV_EPI_GELU_GRAD) {
+                  if constexpr (epi_is_gelugrad(EPI)) {
                     float gl, dg;
                     gelu_both_fast(v[q][r], gl, dg);
                     hpre[q][r] = dg;                       // out2 <- gelu'(pre-activation)
@@ -267,17 +306,37 @@ __device__ __forceinline__ void nt_epilogue(f32x4 (&acc)[4][4], CT* __restrict__
               } else if constexpr (epi_is_dgelu(EPI)) {
 #pragma unroll
                 for (int r = 0; r < 4; ++r)
-                  v[q][r] *= (EPI == MV_EPI_MUL) ? (float)hx[i][j][r] : dgelu_fast((float)hx[i][j][r]);
+                  v[q][r] *= (EPI == MV_EPI_MUL8) ? gq_decode(hq[i][j], r)
+                             : (EPI == MV_EPI_MUL) ? (float)hx[i][j][r] : dgelu_fast((float)hx[i][j][r]);
                 cs[j][0] += v[q][0]; cs[j][1] += v[q][1]; cs[j][2] += v[q][2]; cs[j][3] += v[q][3];
               }
             }
-            if constexpr (epi_is_gelu(EPI)) {
+            if constexpr (EPI == MV_EPI_GELU_GRAD8) {
+              gw[2 * jp] = gq_pack4(hpre[0]);
+              gw[2 * jp + 1] = gq_pack4(hpre[1]);
+            } else if constexpr (epi_is_gelu(EPI)) {
               if (ep.out2)
                 st16(reinterpret_cast<bf16_t*>(ep.out2) + (long)(mb + i * 16) * ep.ld_out2 + nw + 32 * jp,
                      pair_swap_bf16(hpre[0], hpre[1]));
             }
             st16(C + crow[i] * ldc + nw + 32 * jp, pair_swap_bf16(v[0], v[1]));
           }
+          if constexpr (EPI == MV_EPI_GELU_GRAD8) {
+            // The lane holds one word (4 codes = columns 4g .. 4g+3) of each of the four 16-column tiles.  A 4 x 4 transpose
+            // over (tile, lane group) -- two swap stages -- leaves lane group g with all 16 codes of tile g: ONE 16-byte
+            // store per 16 rows instead of two 8-byte ones (the tail of this epilogue is bound by store issue, not bytes:
+            // with 8-byte stores the byte-wide gelu' bought 0.14 ms per step instead of the 0.8 its bytes promised).
+            if (ep.out2) {
+              typedef unsigned u32x2_t __attribute__((ext_vector_type(2)));
+              const u32x2_t s01 = __builtin_amdgcn_permlane16_swap(gw[0], gw[1], false, false);
+              const u32x2_t s23 = __builtin_amdgcn_permlane16_swap(gw[2], gw[3], false, false);
+              const u32x2_t t02 = __builtin_amdgcn_permlane32_swap(s01[0], s23[0], false, false);
+              const u32x2_t t13 = __builtin_amdgcn_permlane32_swap(s01[1], s23[1], false, false);
+              st16(reinterpret_cast<unsigned char*>(ep.out2) + (long)(mb + i * 16) * ep.ld_out2 + n0 + wn * 64 + 16 * (lane >> 4),
+                   (u32x4){t02[0], t13[0], t02[1], t13[1]});
+            }
+          }
+        }
         if constexpr (epi_is_dgelu(EPI)) {
           if (ep.out2) nt_colsum_flush(cs, reinterpret_cast<float*>(ep.out2), ep.ld_out2, (m0 + wm * 64) >> 6, nb, N, lane);
         }
@@ -295,15 +354,23 @@ __device__ __forceinline__ void nt_epilogue(f32x4 (&acc)[4][4], CT* __restrict__
           float o2[4] = {v[0], v[1], v[2], v[3]};
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
-            if constexpr (EPI == MV_EPI_GELU_GRAD) gelu_both_fast(o2[r], v[r], o2[r]);
+            if constexpr (epi_is_gelugrad(EPI)) gelu_both_fast(o2[r], v[r], o2[r]);
             else v[r] = gelu_fast(v[r]);
           }
-          if (ep.out2) store4(reinterpret_cast<bf16_t*>(ep.out2) + (long)(mb + i * 16) * ep.ld_out2 + n, o2, true, 4);
+          if constexpr (EPI == MV_EPI_GELU_GRAD8) {
+            if (ep.out2)
+              *reinterpret_cast<unsigned*>(reinterpret_cast<unsigned char*>(ep.out2) + (long)(mb + i * 16) * ep.ld_out2 + n) =
+                  gq_pack4(o2);
+          } else {
+            if (ep.out2) store4(reinterpret_cast<bf16_t*>(ep.out2) + (long)(mb + i * 16) * ep.ld_out2 + n, o2, true, 4);
+          }
         } else if constexpr (EPI == MV_EPI_RESIDUAL || EPI == MV_EPI_EMBED) {
           v[0] += ax[i][j].x; v[1] += ax[i][j].y; v[2] += ax[i][j].z; v[3] += ax[i][j].w;
         } else if constexpr (epi_is_dgelu(EPI)) {
 #pragma unroll
-          for (int r = 0; r < 4; ++r) v[r] *= (EPI == MV_EPI_MUL) ? (float)hx[i][j][r] : dgelu_fast((float)hx[i][j][r]);
+          for (int r = 0; r < 4; ++r)
+            v[r] *= (EPI == MV_EPI_MUL8) ? gq_decode(hq[i][j], r)
+                    : (EPI == MV_EPI_MUL) ? (float)hx[i][j][r] : dgelu_fast((float)hx[i][j][r]);
           cs[j][0] += v[0]; cs[j][1] += v[1]; cs[j][2] += v[2]; cs[j][3] += v[3];
         }
         if constexpr (sizeof(CT) == 4)
@@ -350,15 +417,32 @@ __device__ __forceinline__ void nt_epilogue(f32x4 (&acc)[4][4], CT* __restrict__
         float o2[4] = {v[0], v[1], v[2], v[3]};
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-          if constexpr (EPI == MV_EPI_GELU_GRAD) gelu_both_fast(o2[r], v[r], o2[r]);
+          if constexpr (epi_is_gelugrad(EPI)) gelu_both_fast(o2[r], v[r], o2[r]);
           else v[r] = gelu_fast(v[r]);
         }
-        if (ep.out2) store4(reinterpret_cast<bf16_t*>(ep.out2) + (long)m * ep.ld_out2 + n, o2, vec && (ep.ld_out2 & 3) == 0, nvalid);
+        if constexpr (EPI == MV_EPI_GELU_GRAD8) {
+          if (ep.out2) {
+            unsigned char* o8 = reinterpret_cast<unsigned char*>(ep.out2) + (long)m * ep.ld_out2 + n;
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+              if (r < nvalid) o8[r] = (unsigned char)gq_code(o2[r]);
+          }
+        } else {
+          if (ep.out2) store4(reinterpret_cast<bf16_t*>(ep.out2) + (long)m * ep.ld_out2 + n, o2, vec && (ep.ld_out2 & 3) == 0, nvalid);
+        }
       } else if constexpr (EPI == MV_EPI_RESIDUAL) {
         const float* ax = reinterpret_cast<const float*>(ep.aux) + (long)m * ep.ld_aux + n;
 #pragma unroll
         for (int r = 0; r < 4; ++r)
           if (r < nvalid) v[r] += ax[r];
+      } else if constexpr (EPI == MV_EPI_MUL8) {
+        const unsigned char* ax = reinterpret_cast<const unsigned char*>(ep.aux) + (long)m * ep.ld_aux + n;
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+          if (r < nvalid) {
+            v[r] *= fmaf((float)ax[r], GQ_STEP, GQ_LO);
+            cs[j][r] += v[r];
+          }
       } else if constexpr (epi_is_dgelu(EPI)) {
         const bf16_t* ax = reinterpret_cast<const bf16_t*>(ep.aux) + (long)m * ep.ld_aux + n;
 #pragma unroll
@@ -1949,6 +2033,12 @@ extern "C" int mv_gemm_nt_bf16_scaled(const void* A, int lda, const void* B, int
     case MV_EPI_MUL:
       MV_REQUIRE(c_dtype == MV_BF16 && aux, MV_ERR_UNSUPPORTED);
       return launch_nt<MV_EPI_MUL, bf16_t>(A, lda, B, ldb, C, ldc, M, N, K, ep, s);
+    case MV_EPI_GELU_GRAD8:
+      MV_REQUIRE(c_dtype == MV_BF16, MV_ERR_UNSUPPORTED);
+      return launch_nt<MV_EPI_GELU_GRAD8, bf16_t>(A, lda, B, ldb, C, ldc, M, N, K, ep, s);
+    case MV_EPI_MUL8:
+      MV_REQUIRE(c_dtype == MV_BF16 && aux, MV_ERR_UNSUPPORTED);
+      return launch_nt<MV_EPI_MUL8, bf16_t>(A, lda, B, ldb, C, ldc, M, N, K, ep, s);
     case MV_EPI_EMBED:
       MV_REQUIRE(c_dtype == MV_F32 && aux && aux_i > 0, MV_ERR_UNSUPPORTED);
       return launch_nt<MV_EPI_EMBED, float>(A, lda, B, ldb, C, ldc, M, N, K, ep, s);

@@ -15,10 +15,11 @@ import weakref
 import torch
 
 from . import lib as _l
-from .lib import (EPI_DGELU, EPI_EMBED, EPI_GELU, EPI_GELU_GRAD, EPI_MUL, EPI_NONE, EPI_RESIDUAL, MV_BF16, MV_F32, check,
+from .lib import (EPI_DGELU, EPI_EMBED, EPI_GELU, EPI_GELU_GRAD, EPI_GELU_GRAD8, EPI_MUL, EPI_MUL8, EPI_NONE, EPI_RESIDUAL, MV_BF16,
+                  MV_F32, check,
                   lib)
 
-__all__ = ["EPI_NONE", "EPI_GELU", "EPI_RESIDUAL", "EPI_DGELU", "EPI_EMBED", "EPI_GELU_GRAD", "EPI_MUL"]
+__all__ = ["EPI_NONE", "EPI_GELU", "EPI_RESIDUAL", "EPI_DGELU", "EPI_EMBED", "EPI_GELU_GRAD", "EPI_MUL", "EPI_GELU_GRAD8", "EPI_MUL8"]
 
 _DT = {torch.float32: MV_F32, torch.bfloat16: MV_BF16}
 

@@ -135,6 +135,24 @@ def test_gemm_nt_every_variant(ops, variant, M, N, K):
             ops.linear_dx(dy.cuda(), M, N, wp, dx, K, epi=ops.EPI_MUL, aux=gg.cuda(), ld_aux=K, colsum_partial=part)
             assert relerr(dx.float(), want) < 2.0 ** -8
             assert relerr(part.sum(0), want.sum(0)) < 3e-3
+        # the 8-bit forms: gelu' as a code on the fixed grid [-0.13, 1.13] (step 1.26 / 255), and its consumer
+        g8 = torch.full((M, ldn), 77, device="cuda", dtype=torch.uint8)
+        act8 = torch.zeros(M, ldn, device="cuda", dtype=torch.bfloat16)
+        ops.linear_fwd(a.cuda(), M, K, wp, b.cuda(), act8, ldn, epi=ops.EPI_GELU_GRAD8, out2=g8, ld_out2=ldn)
+        assert torch.equal(act8[:, :N], act[:, :N])
+        dec = g8[:, :N].double().cpu() * (1.26 / 255) - 0.13
+        assert float((dec - dgelu64(pre)).abs().max()) <= 0.5 * 1.26 / 255 + 2e-6
+        if ldn > N:
+            assert bool((g8[:, N:] == 77).all())                          # padding columns untouched
+        if N % 8 == 0:
+            dy = bf(torch.randn(M, N, generator=g(5)))
+            codes = torch.randint(0, 256, (M, K), generator=g(9), dtype=torch.uint8)
+            want = (dy.double() @ w.double()) * (codes.double() * (1.26 / 255) - 0.13)
+            dx = torch.empty(M, K, device="cuda", dtype=torch.bfloat16)
+            part = torch.zeros((M + 63) // 64, K, device="cuda")
+            ops.linear_dx(dy.cuda(), M, N, wp, dx, K, epi=ops.EPI_MUL8, aux=codes.cuda(), ld_aux=K, colsum_partial=part)
+            assert relerr(dx.float(), want) < 2.0 ** -8
+            assert relerr(part.sum(0), want.sum(0)) < 3e-3
         # a second launch is bit-identical (no race between DMA and fragment reads shows up as a flaky tile)
         out2 = torch.empty(M, N, device="cuda")
         for _ in range(3):

@@ -3,6 +3,7 @@
 blocks of STEPS steps for ROUNDS rounds (cdna guide rule 24); prints mean, std and min of ms/step per variant.
 
     NT_VARIANTS=0,2569 ROUNDS=10 STEPS=10 python tools/ab_step.py
+    GELU_BITS=8,16 ROUNDS=8 python tools/ab_step.py        # instead: width of the gelu' the MLP block keeps (functional.GELU_GRAD_BITS)
 """
 import os
 import statistics
@@ -18,7 +19,19 @@ from myrtle_vision.models.vit import ViT  # noqa: E402
 from myrtle_vision.utils.optim import AdamW, ParamArena  # noqa: E402
 from myrtle_vision.utils.utils import seed_everything  # noqa: E402
 
-VARIANTS = [int(v) for v in os.environ.get("NT_VARIANTS", "0,2569").split(",")]
+import myrtle_vision.hip.functional as _F  # noqa: E402
+
+GELU_AB = "GELU_BITS" in os.environ
+VARIANTS = [int(v) for v in os.environ.get("GELU_BITS" if GELU_AB else "NT_VARIANTS", "0,2569").split(",")]
+
+
+def select(v):
+    if GELU_AB:
+        _F.GELU_GRAD_BITS = v
+    else:
+        lib().mv_gemm_force_variant(v, 0)
+
+
 ROUNDS, STEPS, BATCH = int(os.environ.get("ROUNDS", 10)), int(os.environ.get("STEPS", 10)), int(os.environ.get("BATCH", 256))
 dev = torch.device("cuda", 0)
 seed_everything(1234)
@@ -44,7 +57,7 @@ for _ in range(5):
 times = {v: [] for v in VARIANTS}
 for r in range(ROUNDS):
     for v in VARIANTS:
-        lib().mv_gemm_force_variant(v, 0)
+        select(v)
         step()                                    # one untimed step after the switch
         s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         torch.cuda.synchronize()
@@ -54,7 +67,8 @@ for r in range(ROUNDS):
         e.record()
         torch.cuda.synchronize()
         times[v].append(s.elapsed_time(e) / STEPS)
-lib().mv_gemm_force_variant(0, 0)
+if not GELU_AB:
+    lib().mv_gemm_force_variant(0, 0)
 for v in VARIANTS:
     t = times[v]
     print(f"variant {v:6d}: mean {statistics.mean(t):7.3f} ms/step  std {statistics.pstdev(t):6.3f}  min {min(t):7.3f}  "
