@@ -342,6 +342,30 @@ def test_gradient_allreduce_world2_gloo(tmp_path):
     assert torch.equal(f0, f1)                                       # identical parameters on all ranks after K steps
 
 
+def test_gradient_bucket_layout_vit_b():
+    """GradAllReducer's buckets at ViT-B size: they tile the arena exactly, none straddles the decay / no-decay boundary (the
+    no-decay region completes only at the very end of backward), full-size buckets stay under the cap, and the buckets that
+    complete LAST in backward (the first layers' weights = the start of the arena) taper to the tail size."""
+    from myrtle_vision.utils.ddp import GradAllReducer
+    from myrtle_vision.utils.optim import ParamArena
+    nn = torch.nn
+    blocks = [nn.ModuleDict(dict(n1=nn.LayerNorm(768), qkv=nn.Linear(768, 2304), proj=nn.Linear(768, 768), n2=nn.LayerNorm(768),
+                                 fc1=nn.Linear(768, 3072), fc2=nn.Linear(3072, 768))) for _ in range(12)]
+    model = nn.ModuleDict(dict(pe=nn.Linear(768, 768), blocks=nn.ModuleList(blocks), head=nn.Linear(768, 1000)))
+    arena = ParamArena(model.named_parameters())
+    red = GradAllReducer(arena, bucket_bytes=48 << 20, tail_bytes=12 << 20)
+    ranges = sorted((lo, hi) for lo, hi, _, _ in red.ranges)
+    assert ranges[0][0] == 0 and ranges[-1][1] == arena.total
+    assert all(a[1] == b[0] for a, b in zip(ranges, ranges[1:]))                       # exact tiling
+    assert all(hi <= arena.n_decay or lo >= arena.n_decay for lo, hi in ranges)        # no straddling
+    sizes = [(hi - lo) * 4 for lo, hi in ranges]
+    assert max(sizes) <= 48 << 20
+    assert sizes[0] <= 12 << 20 and sizes[1] <= 12 << 20                               # the arena's first (= last finished) buckets
+    assert sum(1 for s_ in sizes if s_ > 40 << 20) >= 5                                # the bulk still travels in large buckets
+    assert set(red.bucket_of) == set(range(len(arena.params)))
+    red.remove()
+
+
 @pytest.mark.parametrize("q_format", ["FP16_32", "TF32", "FP16_16", "PyTorchINT8"])
 def test_quantised_formats_force_fp32_on_every_leaf(q_format):
     """Fake-quantised values are fp32 by definition (reference utils/quantize.py:84): a model built with the default
