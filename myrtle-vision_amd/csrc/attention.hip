@@ -45,6 +45,20 @@ __device__ __forceinline__ bf16x4 pack4(f32x4 a) {
   bf16x4 r = {(bf16_t)a[0], (bf16_t)a[1], (bf16_t)a[2], (bf16_t)a[3]};
   return r;
 }
+// Outputs leave as 16-byte stores: a lane holds 4 consecutive features (8 bytes) of each 16-feature tile; for an adjacent
+// tile pair v_permlane16_swap (lanes l <-> l ^ 16, same row) leaves lane group g with 8 consecutive features of tile
+// (g & 1), starting at feature 8 (g >> 1) -- a row's four lanes then cover 64 contiguous bytes per instruction instead of
+// two 32-byte pieces in two instructions (the NT epilogue's trick; partial-sector accesses are what hurt, DESIGN finding 23).
+// Must be executed by every lane of the wave.
+__device__ __forceinline__ u32x4 pair16(f32x4 a, f32x4 b) {
+  typedef unsigned u32x2_t __attribute__((ext_vector_type(2)));
+  const u32x2_t pa = __builtin_bit_cast(u32x2_t, pack4(a)), pb = __builtin_bit_cast(u32x2_t, pack4(b));
+  const u32x2_t r0 = __builtin_amdgcn_permlane16_swap(pa[0], pb[0], false, false);
+  const u32x2_t r1 = __builtin_amdgcn_permlane16_swap(pa[1], pb[1], false, false);
+  return (u32x4){r0[0], r1[0], r0[1], r1[1]};
+}
+// feature offset of that vector inside the tile pair starting at tile j0: 16 (j0 + (g & 1)) + 8 (g >> 1)
+__device__ __forceinline__ int pair16_off(int j0, int g) { return 16 * (j0 + (g & 1)) + 8 * (g >> 1); }
 // Per-lane LDS offsets of the fragment reads.  Every tile base used below is a multiple of 16 rows, so the swizzle
 // term of sw128 -- a function of (row>>1)&3 -- depends on the LANE only, and every fragment address is
 // "tile + row_base*128 + lane constant (+ 2048 for the second half of a transposed fragment)".  Computing sw128() per
@@ -170,15 +184,17 @@ __global__ __launch_bounds__(256, (NKT <= 18 ? 2 : 1)) void attn_fwd_kernel(cons
       for (int dt = 0; dt < 4; ++dt)
         o[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(tr_frag128(sV, 32 * u, L.tr[dt]), pf, o[dt], 0, 0, 0);
     }
-    if (qrow < N) {
+    {
       const float inv = 1.0f / sum;
-      bf16_t* orow = out + ((long)b * N + qrow) * D + h * 64 + 4 * g;
 #pragma unroll
-      for (int dt = 0; dt < 4; ++dt) {
-        const f32x4 v = {o[dt][0] * inv, o[dt][1] * inv, o[dt][2] * inv, o[dt][3] * inv};
-        *reinterpret_cast<bf16x4*>(orow + dt * 16) = pack4(v);
+      for (int dt = 0; dt < 4; ++dt) o[dt] *= inv;
+      const u32x4 w0 = pair16(o[0], o[1]), w1 = pair16(o[2], o[3]);
+      if (qrow < N) {
+        bf16_t* orow = out + ((long)b * N + qrow) * D + h * 64;
+        *reinterpret_cast<u32x4*>(orow + pair16_off(0, g)) = w0;
+        *reinterpret_cast<u32x4*>(orow + pair16_off(2, g)) = w1;
+        if (g == 0) lse[((long)b * H + h) * N + qrow] = (mx + __builtin_amdgcn_logf(sum)) * LN2;
       }
-      if (g == 0) lse[((long)b * H + h) * N + qrow] = (mx + __builtin_amdgcn_logf(sum)) * LN2;
     }
   }
 }
@@ -593,11 +609,8 @@ __global__ __launch_bounds__(256, 2) void attn_bwd4_kernel(const bf16_t* __restr
       }
 #undef ATTN_DQ_READ
       const int q = 32 * u + 16 * t + (lane & 15);
-      if (q < N) {
-        bf16_t* dst = dbase + (long)q * 3 * D + (2 * (wave & 1)) * 16 + 4 * g;
-        *reinterpret_cast<bf16x4*>(dst) = pack4(dq0);
-        *reinterpret_cast<bf16x4*>(dst + 16) = pack4(dq1);
-      }
+      const u32x4 dqw = pair16(dq0, dq1);
+      if (q < N) *reinterpret_cast<u32x4*>(dbase + (long)q * 3 * D + pair16_off(2 * (wave & 1), g)) = dqw;
       dqs0 += dq0;
       dqs1 += dq1;
     }
@@ -608,11 +621,14 @@ __global__ __launch_bounds__(256, 2) void attn_bwd4_kernel(const bf16_t* __restr
   for (int i = 0; i < KPW; ++i) {
     const int kt = wave + 4 * i;
     const int key = kt * 16 + (lane & 15);
-    if (kt < nkt_valid && kt < NKT && key < N) {
+    if (kt < nkt_valid && kt < NKT) {                     // wave-uniform: the lane exchange below runs on whole waves
 #pragma unroll
-      for (int dt = 0; dt < 4; ++dt) {
-        *reinterpret_cast<bf16x4*>(dbase + (long)key * 3 * D + D + dt * 16 + 4 * g) = pack4(adk[i][dt]);
-        *reinterpret_cast<bf16x4*>(dbase + (long)key * 3 * D + 2 * D + dt * 16 + 4 * g) = pack4(adv[i][dt]);
+      for (int dp = 0; dp < 4; dp += 2) {
+        const u32x4 wk = pair16(adk[i][dp], adk[i][dp + 1]), wv = pair16(adv[i][dp], adv[i][dp + 1]);
+        if (key < N) {
+          *reinterpret_cast<u32x4*>(dbase + (long)key * 3 * D + D + pair16_off(dp, g)) = wk;
+          *reinterpret_cast<u32x4*>(dbase + (long)key * 3 * D + 2 * D + pair16_off(dp, g)) = wv;
+        }
       }
     }
   }
@@ -792,10 +808,11 @@ __global__ __launch_bounds__(256, 2) void attn_bwd2p_kernel(const bf16_t* __rest
 #pragma unroll
     for (int t = 0; t < 2; ++t) {
       const int qrow = 32 * task + 16 * t + (lane & 15);
+      const u32x4 w0 = pair16(dq[t][0], dq[t][1]), w1 = pair16(dq[t][2], dq[t][3]);
       if (qrow < N) {
-        bf16_t* drow = dbase + (long)qrow * 3 * D + 4 * g;
-#pragma unroll
-        for (int dt = 0; dt < 4; ++dt) *reinterpret_cast<bf16x4*>(drow + dt * 16) = pack4(dq[t][dt]);
+        bf16_t* drow = dbase + (long)qrow * 3 * D;
+        *reinterpret_cast<u32x4*>(drow + pair16_off(0, g)) = w0;
+        *reinterpret_cast<u32x4*>(drow + pair16_off(2, g)) = w1;
       }
 #pragma unroll
       for (int dt = 0; dt < 4; ++dt) dqs[dt] += dq[t][dt];   // padded queries: lse = +inf -> p = 0 -> exact zeros
@@ -907,11 +924,12 @@ __global__ __launch_bounds__(256, 2) void attn_bwd2p_kernel(const bf16_t* __rest
     for (int i = 0; i < 2; ++i) {
       const int kt = 2 * task + i;
       const int key = kt * 16 + (lane & 15);
-      if (kt < nkt_valid && key < N) {
 #pragma unroll
-        for (int dt = 0; dt < 4; ++dt) {
-          *reinterpret_cast<bf16x4*>(dbase + (long)key * 3 * D + D + dt * 16 + 4 * g) = pack4(adk[i][dt]);
-          *reinterpret_cast<bf16x4*>(dbase + (long)key * 3 * D + 2 * D + dt * 16 + 4 * g) = pack4(adv[i][dt]);
+      for (int dp = 0; dp < 4; dp += 2) {
+        const u32x4 wk = pair16(adk[i][dp], adk[i][dp + 1]), wv = pair16(adv[i][dp], adv[i][dp + 1]);
+        if (kt < nkt_valid && key < N) {
+          *reinterpret_cast<u32x4*>(dbase + (long)key * 3 * D + D + pair16_off(dp, g)) = wk;
+          *reinterpret_cast<u32x4*>(dbase + (long)key * 3 * D + 2 * D + pair16_off(dp, g)) = wv;
         }
       }
     }
