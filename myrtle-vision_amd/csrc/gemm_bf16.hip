@@ -214,15 +214,31 @@ __device__ __forceinline__ void nt_epilogue(f32x4 (&acc)[4][4], CT* __restrict__
       // Linear -> GELU -> the next Linear's quint8 quantiser, on the accumulators: v is the fp32 Linear output exactly as the
       // MV_EPI_NONE epilogue would store it, affine_i8_pack4<1> is the standalone quantiser's own function (erf GELU, rint,
       // clamp): same int8 codes, and the [M, N] fp32 hidden tensor (2.5 GB at batch 1024) never exists
+      const bool wide = (ldc & 15) == 0 && (reinterpret_cast<uintptr_t>(C) & 15) == 0;     // wave-uniform
 #pragma unroll
-      for (int i = 0; i < 4; ++i)
+      for (int i = 0; i < 4; ++i) {
+        unsigned w[4];
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
           const float v0 = fmaf(acc[i][j][0], ep.alpha, bv[j].x), v1 = fmaf(acc[i][j][1], ep.alpha, bv[j].y);
           const float v2 = fmaf(acc[i][j][2], ep.alpha, bv[j].z), v3 = fmaf(acc[i][j][3], ep.alpha, bv[j].w);
-          *reinterpret_cast<unsigned*>(reinterpret_cast<char*>(C) + (long)(mb + i * 16) * ldc + nb + j * 16) =
-              affine_i8_pack4<1>(v0, v1, v2, v3, ep.q_inv, ep.q_zp);
+          w[j] = affine_i8_pack4<1>(v0, v1, v2, v3, ep.q_inv, ep.q_zp);
         }
+        char* crow8 = reinterpret_cast<char*>(C) + (long)(mb + i * 16) * ldc;
+        if (wide) {
+          // 4 x 4 transpose over (column tile, lane group), as in MV_EPI_GELU_GRAD8: lane group g ends with the 16 codes of
+          // tile g -- one 16-byte store per 16 rows (64 contiguous bytes per row) instead of four 4-byte ones
+          typedef unsigned u32x2_t __attribute__((ext_vector_type(2)));
+          const u32x2_t s01 = __builtin_amdgcn_permlane16_swap(w[0], w[1], false, false);
+          const u32x2_t s23 = __builtin_amdgcn_permlane16_swap(w[2], w[3], false, false);
+          const u32x2_t t02 = __builtin_amdgcn_permlane32_swap(s01[0], s23[0], false, false);
+          const u32x2_t t13 = __builtin_amdgcn_permlane32_swap(s01[1], s23[1], false, false);
+          st16(crow8 + n0 + wn * 64 + 16 * (lane >> 4), (u32x4){t02[0], t13[0], t02[1], t13[1]});
+        } else {
+#pragma unroll
+          for (int j = 0; j < 4; ++j) *reinterpret_cast<unsigned*>(crow8 + nb + j * 16) = w[j];
+        }
+      }
       return;
     }
     float4 ax[4][4];
