@@ -110,12 +110,13 @@ class _Linear(Function):
             padded = torch.zeros(M, ld_dy, dtype=dy2.dtype, device=dy2.device)
             padded[:, :N] = dy2
             dy2 = padded
+        # dW first: in fp32 mode its split of dY also leaves the bias gradient, and the dX product below reuses that split
+        dw, db = ops.linear_dw(dy2, x2, M, N, K, ld_dy=ld_dy, want_bias=ctx.has_bias, weight=weight, bias=ctx.bias)
         dx = None
         if ctx.needs_input_grad[0]:
             dx = torch.empty(M, K, dtype=x2.dtype, device=x2.device)
             ops.linear_dx(dy2, M, N, weight, dx, K, ld_dy=ld_dy)
             dx = dx.view(ctx.in_shape)
-        dw, db = ops.linear_dw(dy2, x2, M, N, K, ld_dy=ld_dy, want_bias=ctx.has_bias, weight=weight, bias=ctx.bias)
         return dx, dw, db, None
 
 
@@ -153,12 +154,12 @@ class _LinearQatF16(Function):
         M, K = x2.shape
         N = wq.shape[0]
         dy2 = _c(dy.float()).view(M, N)
+        dw, db = ops.linear_dw(dy2, x2, M, N, K, want_bias=bias is not None, weight=weight, bias=bias)   # dW first: see _Linear
         dx = None
         if ctx.needs_input_grad[0]:
             dx = torch.empty(M, K, dtype=torch.float32, device=dy.device)
             ops.linear_dx(dy2, M, N, wq, dx, K)
             dx = dx.view(ctx.in_shape)
-        dw, db = ops.linear_dw(dy2, x2, M, N, K, want_bias=bias is not None, weight=weight, bias=bias)
         return dx, dw, db
 
 

@@ -322,15 +322,21 @@ class split_scope:
         return False
 
 
-def split_act(x, rows, cols, ldx):
-    """Role-0 side-by-side split [rows, 6 * cols] of an activation / gradient, memoised inside a ``split_scope``."""
+def split_act(x, rows, cols, ldx, colsum_out=None):
+    """Role-0 side-by-side split [rows, 6 * cols] of an activation / gradient, memoised inside a ``split_scope``.
+    ``colsum_out`` (fp32 [cols]): also leave the column sums of x there (the bias gradient when x is a dY) -- from the split
+    pass itself when the split is made here, by a separate pass when it comes from the memo."""
     memo = getattr(_split_tls, "memo", None)
+    make = (lambda: split3(x, rows, cols, ldx, 0)) if colsum_out is None else \
+           (lambda: split_ex(x, rows, cols, ldx=ldx, colsum_out=colsum_out))
     if memo is None:
-        return split3(x, rows, cols, ldx, 0)
+        return make()
     for ent in memo:
         if ent[1] == (rows, cols, ldx, x.data_ptr()):        # ent[0] keeps that storage alive: the address cannot be reused
+            if colsum_out is not None:
+                colsum(x, rows, cols, ldx, colsum_out)
             return ent[2]
-    out = split3(x, rows, cols, ldx, 0)
+    out = make()
     memo.append((x, (rows, cols, ldx, x.data_ptr()), out))
     if len(memo) > 2:
         memo.pop(0)
@@ -518,15 +524,13 @@ def linear_dw(dy, x, M, N, K, *, ld_dy=None, ldx=None, want_bias=True, weight=No
         if t0 is not None:
             _timer.end("gemm_tn_bf16(+reduce+colsum)", t0, 2.0 * M * N * K, shape=f"dw N{N} K{K} bias{int(want_bias)}")
     elif _x6_tn_ok(M, N, K) and dy.dtype == torch.float32 and x.dtype == torch.float32:
-        a6, b6 = split_act(dy, M, N, ld_dy), split_act(x, M, K, ldx)
+        a6, b6 = split_act(dy, M, N, ld_dy, colsum_out=db if want_bias else None), split_act(x, M, K, ldx)
         ws = workspace(lib().mv_gemm_tn_workspace_bytes(N, K, 6 * M), x.device)
         t0 = _timer.begin() if _timer is not None else None
         check(lib().mv_gemm_tn_bf16_x6(_p(a6), _p(b6), _p(dw), K, N, K, M, _p(ws), ws.numel(), _s()),
               "gemm_tn_bf16_x6", M=N, N=K, rows=M)
         if t0 is not None:
             _timer.end("gemm_tn_bf16x6", t0, 2.0 * M * N * K, shape=f"dw N{N} K{K}")
-        if want_bias:
-            colsum(dy, M, N, ld_dy, db)
     else:
         S = f32_dw_splits(M, N, K)
         if S == 1:

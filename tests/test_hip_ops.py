@@ -436,7 +436,10 @@ def test_gemm_f32_bf16x6_is_fp32_accurate(ops, M, N, K):
     with ops.split_scope():
         o = torch.empty(M, K, device="cuda"); ops.linear_dx(dy, M, N, w, o, K)
         dw, db = ops.linear_dw(dy, x, M, N, K)
-    assert torch.equal(o, x6[4]) and torch.equal(dw, x6[6]) and torch.equal(db, x6[7])
+    assert torch.equal(o, x6[4]) and torch.equal(dw, x6[6])
+    # (the bias gradient comes from the split pass when the split is made by the dW call, from the colsum kernel when the
+    # split is found in the scope's memo: two summation orders of the same column sums)
+    assert relerr(db, x6[7].double()) < 2e-6 and relerr(db, dy.double().sum(0)) < 2e-6
     # weights are re-split when the parameter changes in place
     w.mul_(2.0)
     o = torch.empty(M, N, device="cuda"); ops.linear_fwd(x, M, K, w, b, o, N)
