@@ -290,6 +290,19 @@ def set_f32_gemm(mode: str) -> str:
     return prev
 
 
+def pad32(n: int) -> int:
+    return (n + 31) & ~31
+
+
+def _split_buffer(rows, cols, device):
+    """[rows, 6 * cols] bf16 whose STORAGE runs on to the next multiple of 32 rows, zero-filled: the dW product walks its
+    contraction (the rows) in stages of 32, and zero rows add nothing -- any token count takes the bf16x6 path."""
+    full = torch.empty(pad32(rows), 6 * cols, dtype=torch.bfloat16, device=device)
+    if full.shape[0] != rows:
+        full[rows:].zero_()
+    return full[:rows]
+
+
 def split3(x, rows, cols, ldx, role, stack=False):
     """fp32 [rows, cols] (row stride ldx) -> its six bf16 segments: [rows, 6 * cols] side by side, or stacked
     [6 * rows, cols] (``stack``).  role 0 = left operand of the product, 1 = right operand."""
@@ -298,7 +311,7 @@ def split3(x, rows, cols, ldx, role, stack=False):
         out = torch.empty(6 * rows, cols, dtype=torch.bfloat16, device=x.device)
         ldo, seg = cols, rows * cols
     else:
-        out = torch.empty(rows, 6 * cols, dtype=torch.bfloat16, device=x.device)
+        out = _split_buffer(rows, cols, x.device)
         ldo, seg = 6 * cols, cols
     check(lib().mv_split3_bf16(_p(x), ldx, _p(out), ldo, seg, rows, cols, role, _s()), "split3_bf16", rows=rows, cols=cols)
     return out
@@ -377,20 +390,20 @@ def _x6_nt_ok(M, N, Kc):
 
 def _x6_tn_ok(M, N, K):
     """dW[N, K] = dY[M, N]^T X[M, K] through the segmented TN ring kernel with a 6 * M contraction."""
-    return _f32_gemm_mode == "bf16x6" and M % 32 == 0 and M >= 512 and N % 8 == 0 and K % 8 == 0
+    return _f32_gemm_mode == "bf16x6" and M >= 128 and N % 8 == 0 and K % 8 == 0
 
 
 def x6_block_ok(M, *dims):
     """Whether every Linear product of a transformer block with M token rows and these feature widths takes the bf16x6
     path (forward, dX and dW): the block functions then keep the SPLITS of their activations instead of the activations."""
-    return _f32_gemm_mode == "bf16x6" and M % 32 == 0 and M >= 512 and all(d % 64 == 0 for d in dims)
+    return _f32_gemm_mode == "bf16x6" and M >= 128 and all(d % 64 == 0 for d in dims)
 
 
 def split_ex(x, rows, cols, *, ldx=None, op=0, h=None, ldh=None, colsum_out=None):
     """Role-0 side-by-side split [rows, 6 * cols] of v = x (op 0), gelu(x) (op 1) or x * gelu'(h) (op 2); ``colsum_out``
     (fp32 [cols]) receives the column sums of v."""
     require_cuda(x)
-    out = torch.empty(rows, 6 * cols, dtype=torch.bfloat16, device=x.device)
+    out = _split_buffer(rows, cols, x.device)
     ws = workspace(lib().mv_split3_ex_workspace_bytes(rows, cols), x.device) if colsum_out is not None else None
     check(lib().mv_split3_bf16_ex(_p(x), cols if ldx is None else ldx, _p(h), cols if ldh is None else ldh, op, _p(out), rows,
                                   cols, _p(colsum_out), _p(ws), ws.numel() if ws is not None else 0, _s()),
@@ -412,10 +425,11 @@ def tn_x6(dy6, x6, M, weight):
     """dW[N, K] = dY^T X from the two splits, into the weight's gradient slot."""
     N, K = weight.shape
     dw = grad_out(weight, (N, K), dy6.device)
-    ws = workspace(lib().mv_gemm_tn_workspace_bytes(N, K, 6 * M), dy6.device)
+    Mp = pad32(M)                                  # the splits' storage is zero-padded to whole stages (_split_buffer)
+    ws = workspace(lib().mv_gemm_tn_workspace_bytes(N, K, 6 * Mp), dy6.device)
     t0 = _timer.begin() if _timer is not None else None
-    check(lib().mv_gemm_tn_bf16_x6(_p(dy6), _p(x6), _p(dw), K, N, K, M, _p(ws), ws.numel(), _s()),
-          "gemm_tn_bf16_x6", M=N, N=K, rows=M)
+    check(lib().mv_gemm_tn_bf16_x6(_p(dy6), _p(x6), _p(dw), K, N, K, Mp, _p(ws), ws.numel(), _s()),
+          "gemm_tn_bf16_x6", M=N, N=K, rows=Mp)
     if t0 is not None:
         _timer.end("gemm_tn_bf16x6", t0, 2.0 * M * N * K, shape=f"dw N{N} K{K}")
     return dw
@@ -525,10 +539,11 @@ def linear_dw(dy, x, M, N, K, *, ld_dy=None, ldx=None, want_bias=True, weight=No
             _timer.end("gemm_tn_bf16(+reduce+colsum)", t0, 2.0 * M * N * K, shape=f"dw N{N} K{K} bias{int(want_bias)}")
     elif _x6_tn_ok(M, N, K) and dy.dtype == torch.float32 and x.dtype == torch.float32:
         a6, b6 = split_act(dy, M, N, ld_dy, colsum_out=db if want_bias else None), split_act(x, M, K, ldx)
-        ws = workspace(lib().mv_gemm_tn_workspace_bytes(N, K, 6 * M), x.device)
+        Mp = pad32(M)
+        ws = workspace(lib().mv_gemm_tn_workspace_bytes(N, K, 6 * Mp), x.device)
         t0 = _timer.begin() if _timer is not None else None
-        check(lib().mv_gemm_tn_bf16_x6(_p(a6), _p(b6), _p(dw), K, N, K, M, _p(ws), ws.numel(), _s()),
-              "gemm_tn_bf16_x6", M=N, N=K, rows=M)
+        check(lib().mv_gemm_tn_bf16_x6(_p(a6), _p(b6), _p(dw), K, N, K, Mp, _p(ws), ws.numel(), _s()),
+              "gemm_tn_bf16_x6", M=N, N=K, rows=Mp)
         if t0 is not None:
             _timer.end("gemm_tn_bf16x6", t0, 2.0 * M * N * K, shape=f"dw N{N} K{K}")
     else:
