@@ -2219,7 +2219,9 @@ extern "C" int mv_gemm_force_variant(int nt_variant, int tn_variant) {
 extern "C" size_t mv_gemm_tn_workspace_bytes(int M, int N, int Kc) {
   // the larger of the two plans: independent of which variant is (or is forced to be) launched later
   int splits = tn_plan(M, N, Kc).splits;
-  if (Kc > 0 && Kc % BKR == 0 && tn_plan256(M, N, Kc).splits > splits) splits = tn_plan256(M, N, Kc).splits;
+  const int kr = Kc & ~(BKR - 1);               // the ring kernel also takes the whole stages of a ragged contraction
+  if (kr > 0 && tn_plan256(M, N, kr).splits > splits) splits = tn_plan256(M, N, kr).splits;
+  if (kr > 0 && kr != Kc && tn_plan(M, N, kr).splits > splits) splits = tn_plan(M, N, kr).splits;
   const size_t slabs = (size_t)splits * (size_t)M * (size_t)N * sizeof(float);
   const size_t cs = (size_t)colsum_parts(Kc) * (size_t)M * sizeof(float);
   return slabs + cs + 256;
@@ -2260,6 +2262,25 @@ extern "C" int mv_gemm_tn_bf16(const void* A, int lda, const void* B, int ldb, f
   static const int attr = set_smem(gemm_tn_kernel) | set_smem(gemm_tn_glds_kernel);
   if (attr != 0) return MV_ERR_LAUNCH;
   hipStream_t s = (hipStream_t)stream;
+  // A contraction that is not a whole number of the ring kernel's 32-row stages (197 tokens x a batch that is not a multiple
+  // of 32) used to fall to the 128-tile register-staged kernel for ALL of it: the step took as long at batch 48 as at 64.
+  // Now the ring kernel takes the whole stages and the general kernel adds the last < 32 rows (accumulate).
+  if (Kc % BKR != 0 && tn_use_ring(M, N, Kc & ~(BKR - 1))) {
+    const int main_rows = Kc & ~(BKR - 1);
+    int rc = mv_gemm_tn_bf16(A, lda, B, ldb, C, ldc, M, N, main_rows, accumulate, nullptr, workspace, workspace_bytes, stream);
+    if (rc != MV_OK) return rc;
+    rc = mv_gemm_tn_bf16(reinterpret_cast<const bf16_t*>(A) + (long)main_rows * lda, lda,
+                         reinterpret_cast<const bf16_t*>(B) + (long)main_rows * ldb, ldb, C, ldc, M, N, Kc - main_rows, 1, nullptr,
+                         workspace, workspace_bytes, stream);
+    if (rc != MV_OK) return rc;
+    if (colsum) {
+      const TnPlan plc = tn_plan256(M, N, main_rows);
+      float* cs_ws = workspace + (size_t)plc.splits * (size_t)M * (size_t)N;
+      return mv_colsum(A, MV_BF16, lda, colsum, accumulate, Kc, M, cs_ws, (size_t)colsum_parts(Kc) * (size_t)M * sizeof(float),
+                       stream);
+    }
+    return MV_OK;
+  }
   const bool ring = tn_use_ring(M, N, Kc);
   // (An 8-phase port of this kernel -- the gemm_nt_8phase_kernel schedule with [64 kc][128 col] slots -- measured 10-15 %
   // SLOWER than the ring in the same process, 851 vs 968 and 909 vs 1031 TFLOP/s: the ring's DMA rows are whole

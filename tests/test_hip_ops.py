@@ -276,7 +276,8 @@ def test_gemm_nt_embed_epilogue(ops):
 
 
 TN_SHAPES = [(1576, 192, 576), (1600, 192, 576), (4096, 200, 136), (1576, 768, 192), (5000, 768, 768), (256, 48, 768), (100, 136, 200), (63, 8, 8),
-             (20000, 3072, 768)]
+             (20000, 3072, 768), (9456, 768, 2304), (19700, 3072, 768), (4097, 768, 768)]   # the last three: ragged contractions
+                                                                                       # (197 x 48 / x 100 rows): ring + tail
 
 
 @pytest.mark.parametrize("Kc,M,N", TN_SHAPES)
