@@ -11,7 +11,7 @@ is called on its own).  The fused functions ``attn_block`` / ``mlp_block`` imple
                  attention backward, LN backward with the residual gradient folded in.
 
 The residual stream and all gradients w.r.t. parameters are fp32; activations are bf16 (``prec='bf16'``) or fp32
-(``prec='fp32'``: exact-parity mode).  Backward runs on autograd's worker thread: everything here is stateless
+(``prec='fp32'``: parity mode, fp32-accurate arithmetic).  Backward runs on autograd's worker thread: everything here is stateless
 apart from caches keyed by tensor identity.
 """
 import functools

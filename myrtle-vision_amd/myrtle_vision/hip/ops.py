@@ -5,7 +5,8 @@ Every wrapper takes CUDA (ROCm) tensors owned by PyTorch, passes raw device poin
 streams.  CPU tensors are rejected: there is no CPU compute path in this package.
 
 Precision: ``"bf16"`` = bf16 activations and weights on MFMA with fp32 accumulation and an fp32 residual stream
-(the benchmark configuration); ``"fp32"`` = every contraction in fp32 FMA chains (exact-parity mode).
+(the benchmark configuration); ``"fp32"`` = every contraction to fp32 accuracy (parity mode: bf16x6 Linear products, f32-MFMA
+attention; MV_F32_GEMM=mfma puts every product on the bit-exact fmaf-chain kernels).
 """
 import ctypes
 import os
@@ -466,7 +467,8 @@ def _nt_x6(a6, b6, out, ldc, M, N, Kc, bias, epi, aux=None, ld_aux=0, aux_i=0, t
 # ------------------------------------------------------------------------------------------------------------
 def linear_fwd(x, M, K, weight, bias, out, ldc, *, lda=None, epi=EPI_NONE, aux=None, ld_aux=0, aux_i=0, out2=None,
                ld_out2=0):
-    """out[M, N] (+epilogue) = x[M, K] @ weight[N, K]^T + bias.  Dispatches on x.dtype (bf16 -> MFMA, fp32 -> FMA)."""
+    """out[M, N] (+epilogue) = x[M, K] @ weight[N, K]^T + bias.  Dispatches on x.dtype: bf16 -> the bf16 MFMA kernels;
+    fp32 -> bf16x6 (fp32-accurate, on the bf16 MFMA) where the shape rules allow, else mv_gemm_f32 (f32 MFMA, fmaf-chain bits)."""
     N = weight.shape[0]
     lda = K if lda is None else lda
     if x.dtype == torch.bfloat16:

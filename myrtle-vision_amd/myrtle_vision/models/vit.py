@@ -7,7 +7,7 @@ arithmetic runs in the HIP kernels of ``csrc/`` through ``myrtle_vision.hip.func
 
 One extension: ``ViT(..., precision="bf16" | "fp32")`` (default: env ``MYRTLE_VISION_PRECISION`` or ``"bf16"``).
 ``bf16`` is the benchmark configuration (MFMA, fp32 accumulate, fp32 residual stream); ``fp32`` is the
-exact-parity mode.  Any fake-quantised ``q_format`` runs in ``fp32`` (its values are fp32 by definition,
+parity mode (fp32-accurate arithmetic: the one held to 1e-3 / bit-exact argmax against the reference).  Any fake-quantised ``q_format`` runs in ``fp32`` (its values are fp32 by definition,
 utils/quantize.py:84).
 
 There is no CPU compute path: ``forward`` on CPU tensors raises.
