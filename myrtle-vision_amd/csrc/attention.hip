@@ -21,7 +21,8 @@
 #include <atomic>
 
 #ifndef MV_ATTN_ABLATE
-#define MV_ATTN_ABLATE 0   // diagnostic builds only (tools/ablate_attn.sh): bit k removes one phase of attn_bwd4_kernel
+#define MV_ATTN_ABLATE 0   // diagnostic builds only (tools/ablate_attn.sh): bits 1-16 remove phases of attn_bwd4_kernel, 32 / 64 the passes
+                           // of attn_bwd2p_kernel, 128-2048 phases of attn_fwd_kernel (S products, exp, PV products, K/V staging, stores)
 #endif
 
 namespace {
@@ -122,7 +123,7 @@ __global__ __launch_bounds__(256, (NKT <= 18 ? 2 : 1)) void attn_fwd_kernel(cons
   const int b = blockIdx.x / H, h = blockIdx.x % H;
   const long D = (long)H * 64;
   const bf16_t* base = qkv + (long)b * N * 3 * D + h * 64;
-  stage_kv_dma(base, D, N, sK, NP, sV, NP, wave, 4, lane);
+  if (!(MV_ATTN_ABLATE & 1024)) stage_kv_dma(base, D, N, sK, NP, sV, NP, wave, 4, lane);
   const int nqt = (N + 15) >> 4;
   // Q fragments straight from global memory, one 16-query tile ahead: the next tile's loads are in flight while this
   // one computes (rows >= N clamped: those outputs are not stored)
@@ -149,8 +150,10 @@ __global__ __launch_bounds__(256, (NKT <= 18 ? 2 : 1)) void attn_fwd_kernel(cons
     for (int kt = 0; kt < NKT; ++kt) {
       f32x4 acc = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-      for (int ks = 0; ks < 2; ++ks)
+      for (int ks = 0; ks < 2; ++ks) {
+        if (MV_ATTN_ABLATE & 128) continue;
         acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(row_frag128(sK, kt * 16, L.rf[ks]), qf[ks], acc, 0, 0, 0);
+      }
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const int key = kt * 16 + 4 * g + r;
@@ -167,7 +170,7 @@ __global__ __launch_bounds__(256, (NKT <= 18 ? 2 : 1)) void attn_fwd_kernel(cons
     for (int kt = 0; kt < NKT; ++kt)
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        const float p = __builtin_amdgcn_exp2f(st[kt][r] - mx);
+        const float p = (MV_ATTN_ABLATE & 256) ? st[kt][r] : __builtin_amdgcn_exp2f(st[kt][r] - mx);
         st[kt][r] = p;
         sum += p;
       }
@@ -181,15 +184,17 @@ __global__ __launch_bounds__(256, (NKT <= 18 ? 2 : 1)) void attn_fwd_kernel(cons
     for (int u = 0; u < NKT / 2; ++u) {
       const bf16x8 pf = pack8(st[2 * u], st[2 * u + 1]);
 #pragma unroll
-      for (int dt = 0; dt < 4; ++dt)
+      for (int dt = 0; dt < 4; ++dt) {
+        if (MV_ATTN_ABLATE & 512) continue;
         o[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(tr_frag128(sV, 32 * u, L.tr[dt]), pf, o[dt], 0, 0, 0);
+      }
     }
     {
       const float inv = 1.0f / sum;
 #pragma unroll
       for (int dt = 0; dt < 4; ++dt) o[dt] *= inv;
       const u32x4 w0 = pair16(o[0], o[1]), w1 = pair16(o[2], o[3]);
-      if (qrow < N) {
+      if (qrow < N && (!(MV_ATTN_ABLATE & 2048) || sum == 1234.5f)) {
         bf16_t* orow = out + ((long)b * N + qrow) * D + h * 64;
         *reinterpret_cast<u32x4*>(orow + pair16_off(0, g)) = w0;
         *reinterpret_cast<u32x4*>(orow + pair16_off(2, g)) = w1;
