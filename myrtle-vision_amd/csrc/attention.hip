@@ -146,22 +146,31 @@ __global__ __launch_bounds__(256, (NKT <= 18 ? 2 : 1)) void attn_fwd_kernel(cons
     }
     f32x4 st[NKT];
     float mx = -INFINITY;
+    // key tiles in PAIRS with their two-step accumulation chains interleaved (a0 b0 a1 b1): issued tile by tile, every
+    // second MFMA waited for the one before it (this phase took 41 us against 20 for the equally large P.V products,
+    // whose four accumulators are independent)
 #pragma unroll
-    for (int kt = 0; kt < NKT; ++kt) {
-      f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-      for (int ks = 0; ks < 2; ++ks) {
-        if (MV_ATTN_ABLATE & 128) continue;
-        acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(row_frag128(sK, kt * 16, L.rf[ks]), qf[ks], acc, 0, 0, 0);
+    for (int kp = 0; kp < NKT; kp += 2) {
+      f32x4 acc[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+      if (!(MV_ATTN_ABLATE & 128)) {
+        const bf16x8 ka0 = row_frag128(sK, kp * 16, L.rf[0]), kb0 = row_frag128(sK, (kp + 1) * 16, L.rf[0]);
+        const bf16x8 ka1 = row_frag128(sK, kp * 16, L.rf[1]), kb1 = row_frag128(sK, (kp + 1) * 16, L.rf[1]);
+        acc[0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ka0, qf[0], acc[0], 0, 0, 0);
+        acc[1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kb0, qf[0], acc[1], 0, 0, 0);
+        acc[0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ka1, qf[1], acc[0], 0, 0, 0);
+        acc[1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kb1, qf[1], acc[1], 0, 0, 0);
       }
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int key = kt * 16 + 4 * g + r;
-        const float v = key < N ? acc[r] * scale_log2e : -INFINITY;
-        acc[r] = v;
-        mx = fmaxf(mx, v);
+      for (int t = 0; t < 2; ++t) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int key = (kp + t) * 16 + 4 * g + r;
+          const float v = key < N ? acc[t][r] * scale_log2e : -INFINITY;
+          acc[t][r] = v;
+          mx = fmaxf(mx, v);
+        }
+        st[kp + t] = acc[t];
       }
-      st[kt] = acc;
     }
     mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
     mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
