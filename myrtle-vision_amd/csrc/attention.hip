@@ -33,6 +33,13 @@ constexpr float LN2 = 0.6931471805599453f;
 __device__ __forceinline__ int sw128(int row, int ch) { return row * 128 + ((ch ^ (((row >> 1) & 3) << 1)) << 4); }
 // dS^T image: [key][32 queries] bf16 = 64-byte rows; the two 32-byte halves swap on rows 4..7 (mod 8)
 __device__ __forceinline__ int swds(int key, int half) { return key * 64 + ((half ^ ((key >> 2) & 1)) << 5); }
+// attn_bwd4_kernel's image of the same tile: the 8-byte atom (query tile t, query group gq = 4 queries) of row `key` sits at
+// slot (4 t + gq) ^ X((key >> 2) & 3), X = {0, 4, 2, 6} (the 2-bit index bit-reversed, times 2).  Writers touch {16 keys} x
+// {gq = lane >> 4} per instruction, the transposed readers {rows 4 g + q} x {gq = lane & 3}: with this XOR both half-waves of
+// both patterns hit 32 distinct bank pairs.  swds() above leaves the WRITES 2-way conflicted -- SQ_LDS_BANK_CONFLICT showed
+// half of that kernel's LDS-active cycles were conflict cycles, all from these stores (phase ablation under the counter).
+__device__ __forceinline__ int dsx(int key_quad) { return ((key_quad & 1) << 2) | ((key_quad >> 1) << 1); }
+__device__ __forceinline__ int swds4(int key, int t, int gq) { return key * 64 + (((4 * t + gq) ^ dsx((key >> 2) & 3)) << 3); }
 
 __device__ __forceinline__ bf16x8 cat8(bf16x4 a, bf16x4 b) { return __builtin_shufflevector(a, b, 0, 1, 2, 3, 4, 5, 6, 7); }
 __device__ __forceinline__ bf16x4 tr_read(const char* p) {
@@ -448,7 +455,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd4_kernel(const bf16_t* __restr
   char* sK = smem;                           // [224][64] bf16 (rows >= N zero; rows 208..223 exist for the key-pair reads)
   char* sV = sK + NPK * 128;                 // [208][64]
   char* sPair = sV + NPV * 128;              // Q[32][64], dO[32][64]
-  char* sDS = sPair + 8192;                  // [224 keys][32 queries] bf16 (dS^T), swds
+  char* sDS = sPair + 8192;                  // [224 keys][32 queries] bf16 (dS^T), swds4
   float* sLse = reinterpret_cast<float*>(sDS + NPK * 64);
   float* sDelta = sLse + NPK;
 
@@ -587,7 +594,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd4_kernel(const bf16_t* __restr
           adk[i][dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qtr[dt], dsf, adk[i][dt], 0, 0, 0);
         }
 #pragma unroll
-        for (int t = 0; t < 2; ++t) *reinterpret_cast<bf16x4*>(sDS + swds(key, t) + 8 * g) = pack4(ds[t]);
+        for (int t = 0; t < 2; ++t) *reinterpret_cast<bf16x4*>(sDS + swds4(key, t, g)) = pack4(ds[t]);
       }
     }
     __syncthreads();                                   // S-phase done everywhere: dS^T complete, Q/dO pair no longer read
@@ -600,7 +607,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd4_kernel(const bf16_t* __restr
     if (32 * u < N && !(MV_ATTN_ABLATE & 1)) {
       const int t = wave >> 1;
       const int trk0 = (wave & 1) ? L.tr[2] : L.tr[0], trk1 = (wave & 1) ? L.tr[3] : L.tr[1];
-      const int dsoff = (4 * g + ((lane >> 2) & 3)) * 64 + ((t ^ (g & 1)) << 5) + 8 * (lane & 3);
+      const int dsoff = swds4(4 * g + ((lane >> 2) & 3), t, lane & 3);   // rows 32 v + 4 g + q: the same key quad (g) for every v
       f32x4 dq0 = {0.f, 0.f, 0.f, 0.f}, dq1 = {0.f, 0.f, 0.f, 0.f};
       // All seven 32-key groups, unconditionally (groups beyond N hold zero dS^T rows -- zero-filled at the start, never
       // written -- against clamped finite K rows), two register sets: the six transposed reads of group v + 1 are in flight
