@@ -34,12 +34,15 @@ __device__ __forceinline__ int sw128(int row, int ch) { return row * 128 + ((ch 
 // dS^T image: [key][32 queries] bf16 = 64-byte rows; the two 32-byte halves swap on rows 4..7 (mod 8)
 __device__ __forceinline__ int swds(int key, int half) { return key * 64 + ((half ^ ((key >> 2) & 1)) << 5); }
 // attn_bwd4_kernel's image of the same tile: the 8-byte atom (query tile t, query group gq = 4 queries) of row `key` sits at
-// slot (4 t + gq) ^ X((key >> 2) & 3), X = {0, 4, 2, 6} (the 2-bit index bit-reversed, times 2).  Writers touch {16 keys} x
-// {gq = lane >> 4} per instruction, the transposed readers {rows 4 g + q} x {gq = lane & 3}: with this XOR both half-waves of
-// both patterns hit 32 distinct bank pairs.  swds() above leaves the WRITES 2-way conflicted -- SQ_LDS_BANK_CONFLICT showed
-// half of that kernel's LDS-active cycles were conflict cycles, all from these stores (phase ablation under the counter).
-__device__ __forceinline__ int dsx(int key_quad) { return ((key_quad & 1) << 2) | ((key_quad >> 1) << 1); }
-__device__ __forceinline__ int swds4(int key, int t, int gq) { return key * 64 + (((4 * t + gq) ^ dsx((key >> 2) & 3)) << 3); }
+// slot (4 t + gq) ^ Y((key >> 1) & 7), Y(k2 k1 k0) = (k1 k2 k0).  Banking rules (MI355X_MICROARCH.md, LDS table): ds_write_b64
+// goes in 4 groups of 16 contiguous lanes over 32 banks, ds_read_b64_tr_b16 in 2 x 32 lanes over 64.  A store touches
+// {16 keys} x {gq = lane >> 4}: within 16 lanes the 8 keys of one parity share a 128-byte window and need 8 different slots
+// (Y is a bijection of the key pair index); a transposed read touches {rows 4 g + q} x {gq = lane & 3}: rows r and r + 4 share a
+// 256-byte window and need opposite slot halves (bit 2 of Y follows bit 1 of its argument).  swds() above is conflict-free
+// for the reads but 4-way conflicted for the stores (16 cycles instead of 4): SQ_LDS_BANK_CONFLICT = half of that kernel's
+// LDS-active cycles, all from those stores by phase ablation under the counter; this image: both at their ideal.
+__device__ __forceinline__ int dsy(int k) { return (((k >> 1) & 1) << 2) | (((k >> 2) & 1) << 1) | (k & 1); }
+__device__ __forceinline__ int swds4(int key, int t, int gq) { return key * 64 + (((4 * t + gq) ^ dsy((key >> 1) & 7)) << 3); }
 
 __device__ __forceinline__ bf16x8 cat8(bf16x4 a, bf16x4 b) { return __builtin_shufflevector(a, b, 0, 1, 2, 3, 4, 5, 6, 7); }
 __device__ __forceinline__ bf16x4 tr_read(const char* p) {
@@ -607,7 +610,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd4_kernel(const bf16_t* __restr
     if (32 * u < N && !(MV_ATTN_ABLATE & 1)) {
       const int t = wave >> 1;
       const int trk0 = (wave & 1) ? L.tr[2] : L.tr[0], trk1 = (wave & 1) ? L.tr[3] : L.tr[1];
-      const int dsoff = swds4(4 * g + ((lane >> 2) & 3), t, lane & 3);   // rows 32 v + 4 g + q: the same key quad (g) for every v
+      const int dsoff = swds4(4 * g + ((lane >> 2) & 3), t, lane & 3);   // rows 32 v + 4 g + q: (row >> 1) & 7 is the same for every v
       f32x4 dq0 = {0.f, 0.f, 0.f, 0.f}, dq1 = {0.f, 0.f, 0.f, 0.f};
       // All seven 32-key groups, unconditionally (groups beyond N hold zero dS^T rows -- zero-filled at the start, never
       // written -- against clamped finite K rows), two register sets: the six transposed reads of group v + 1 are in flight
