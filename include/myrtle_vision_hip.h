@@ -55,8 +55,8 @@ enum {
                           quantiser (q_scale, q_zero_point): FeedForward's Linear -> GELU -> next Linear's QuantStub
                           (vit.py:48-51) without the fp32 hidden activations ever reaching memory */
   MV_EPI_GELU_GRAD8 = 8, /* as MV_EPI_GELU_GRAD with out2 as ONE BYTE per element (uint8 [M, ld_out2]): gelu' lies in
-                            [-0.129, 1.129]; code = round((gelu' + 0.13) * 255 / 1.26), |error| <= 0.0025 */
-  MV_EPI_MUL8 = 9,       /* as MV_EPI_MUL with aux = those codes (uint8 [M, ld_aux]): C = acc * (code * 1.26 / 255 - 0.13) */
+                            [-0.129, 1.129]; code = round(gelu' * 200) + 26: 0 and 1 are codes 26 and 226 exactly, |error| <= 0.0025 */
+  MV_EPI_MUL8 = 9,       /* as MV_EPI_MUL with aux = those codes (uint8 [M, ld_aux]): C = acc * ((code - 26) * 0.005) */
   MV_EPI_EMBED = 4     /* patch-embedding: row m of the GEMM is patch (m % aux_i) of image (m / aux_i);
                           C row = img*(aux_i+1) + 1 + patch;  C = acc + bias + aux[1 + patch]  (aux: fp32 [aux_i+1, N]) */
 };

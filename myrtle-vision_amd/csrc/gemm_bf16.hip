@@ -144,17 +144,21 @@ __device__ __forceinline__ void gelu_both_fast(float x, float& gl, float& dg) {
 constexpr bool epi_is_gelu(int e) { return e == MV_EPI_GELU || e == MV_EPI_GELU_GRAD || e == MV_EPI_GELU_GRAD8; }
 constexpr bool epi_is_dgelu(int e) { return e == MV_EPI_DGELU || e == MV_EPI_MUL || e == MV_EPI_MUL8; }
 constexpr bool epi_is_gelugrad(int e) { return e == MV_EPI_GELU_GRAD || e == MV_EPI_GELU_GRAD8; }
-// gelu'(x) lies in [-0.1290, 1.1290]: MV_EPI_GELU_GRAD8 leaves it as an 8-bit code on a fixed grid (step 1.26 / 255 =
-// 0.00494, |error| <= 0.0025 -- below the bf16 rounding of the gradient it multiplies for |gelu'| > 0.6, 0.24 % of the rms
-// value overall), MV_EPI_MUL8 reads it back: one byte per hidden element instead of two in fc1's epilogue and in fc2-dX's.
-constexpr float GQ_LO = -0.13f, GQ_STEP = 1.26f / 255.0f, GQ_INV = 255.0f / 1.26f;
+// gelu'(x) lies in [-0.1290, 1.1290]: MV_EPI_GELU_GRAD8 leaves it as an 8-bit code on a fixed grid, MV_EPI_MUL8 reads it
+// back: one byte per hidden element instead of two in fc1's epilogue and in fc2-dX's.  The grid is step 0.005 from -0.13:
+// code 26 IS 0 and code 226 IS 1 (a saturated unit's gradient passes unchanged and a dead unit leaks nothing -- a grid
+// without those two points gives the two most common values of gelu' a systematic, not zero-mean, error), code 255 = 1.145
+// covers the maximum 1.129; |error| <= 0.0025 elsewhere.  Decoding is (code - 26) * 0.005f, NOT fma(code, step, lo): the
+// subtraction is exact and 200 * 0.005f rounds to exactly 1.0f.
+constexpr float GQ_STEP = 0.005f, GQ_INV = 200.0f, GQ_ZERO = 26.0f;
 __device__ __forceinline__ unsigned gq_code(float g) {
-  return (unsigned)__builtin_amdgcn_fmed3f(fmaf(g, GQ_INV, 0.5f - GQ_LO * GQ_INV), 0.f, 255.f);
+  return (unsigned)__builtin_amdgcn_fmed3f(fmaf(g, GQ_INV, GQ_ZERO + 0.5f), 0.f, 255.f);
 }
 __device__ __forceinline__ unsigned gq_pack4(const float (&g)[4]) {
   return gq_code(g[0]) | (gq_code(g[1]) << 8) | (gq_code(g[2]) << 16) | (gq_code(g[3]) << 24);
 }
-__device__ __forceinline__ float gq_decode(unsigned w, int k) { return fmaf((float)((w >> (8 * k)) & 255u), GQ_STEP, GQ_LO); }
+__device__ __forceinline__ float gq_value(float code) { return (code - GQ_ZERO) * GQ_STEP; }
+__device__ __forceinline__ float gq_decode(unsigned w, int k) { return gq_value((float)((w >> (8 * k)) & 255u)); }
 __device__ __forceinline__ float dgelu_fast(float x) {
   float e;
   const float cdf = 0.5f * (1.0f + erf_fast(x * 0.70710678118654752440f, e));
@@ -456,7 +460,7 @@ __device__ __forceinline__ void nt_epilogue(f32x4 (&acc)[4][4], CT* __restrict__
 #pragma unroll
         for (int r = 0; r < 4; ++r)
           if (r < nvalid) {
-            v[r] *= fmaf((float)ax[r], GQ_STEP, GQ_LO);
+            v[r] *= gq_value((float)ax[r]);
             cs[j][r] += v[r];
           }
       } else if constexpr (epi_is_dgelu(EPI)) {

@@ -97,7 +97,8 @@ Quant = Optional[Callable[[str, torch.Tensor], torch.Tensor]]
 
 
 def vit_forward(params: Dict[str, torch.Tensor], img: torch.Tensor, cfg: ViTConfig,
-                quant: Quant = None, taps: Optional[dict] = None, quant_outputs: bool = False) -> torch.Tensor:
+                quant: Quant = None, taps: Optional[dict] = None, quant_outputs: bool = False,
+                probs_site: bool = False) -> torch.Tensor:
     """``ViT.forward`` (``vit.py:267-320``) for the classification and segmentation
     decoders.  ``quant(site, tensor)`` is the fake-quant hook (identity when None);
     sites follow ``ModelQuantizer._prepare_qat_fp16_32/_tf32``
@@ -108,7 +109,9 @@ def vit_forward(params: Dict[str, torch.Tensor], img: torch.Tensor, cfg: ViTConf
     ("act:gelu": nn.GELU gets a QuantStub in front but, not being in torch's
     observed-module list, no output observer) and every FloatFunctional result
     ("ff:<name>": cls_token_cat, pos_embedding_cat, pos_embedding_add, res_add).
-    ``taps`` (optional dict) receives intermediate activations.
+    ``taps`` (optional dict) receives intermediate activations.  ``probs_site`` adds one site the reference does not
+    have, "attn:probs" on the softmax output: the rounding-error budget of the bf16 kernels (tests/test_error_budget.py)
+    needs it, no fixture uses it.
     """
     q = quant if quant is not None else (lambda site, t: t)
     qo = q if quant_outputs else (lambda site, t: t)
@@ -142,6 +145,8 @@ def vit_forward(params: Dict[str, torch.Tensor], img: torch.Tensor, cfg: ViTConf
         qh, kh, vh = qkv[0], qkv[1], qkv[2]
         attn = (qh @ kh.transpose(-2, -1)) * scale                   # :92
         attn = attn.softmax(dim=-1)                                  # :93
+        if probs_site:
+            attn = q("attn:probs", attn)
         if taps is not None:
             taps[f"attn{i}"] = attn
         o = (attn @ vh).transpose(1, 2).reshape(b, n, c)             # :96

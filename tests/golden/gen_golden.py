@@ -97,6 +97,9 @@ CASES = {
     "micro_seg_256": (dict(decoder="segmentation", image_size=256, num_classes=17, **MICRO), 1, None, False),
     "base_seg": (dict(decoder="segmentation", image_size=224, num_classes=17, **BASE), 2, None, False),
     "micro_seg_fp16_32": (dict(decoder="segmentation", image_size=224, num_classes=17, **MICRO), 2, "FP16_32", False),
+    # round 3: logits-only fixtures over enough images for a top-1 agreement RATE (eval-mode forward, no backward)
+    "base_cls_b32": (dict(decoder="classification", image_size=224, num_classes=1000, **BASE), 32, None, "logits_only"),
+    "tiny_cls_b64": (dict(decoder="classification", image_size=224, num_classes=45, **TINY), 64, None, "logits_only"),
 }
 
 
@@ -130,6 +133,12 @@ def run_case(name, kwargs, batch, q_format, convert):
         labels = det_labels(name, (batch,), kwargs["num_classes"])
     else:
         labels = det_labels(name, (batch, kwargs["image_size"], kwargs["image_size"]), kwargs["num_classes"])
+
+    if convert == "logits_only":
+        vit.eval()
+        with torch.no_grad():
+            out["logits"] = vit(img).numpy()
+        return out, meta
 
     if convert:
         vit.train()

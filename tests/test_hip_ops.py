@@ -93,6 +93,31 @@ def test_gemm_nt_bias_f32_out(ops, M, N, K):
     assert relerr(out16.float(), want) < 2.0 ** -8        # + one bf16 rounding
 
 
+@pytest.mark.parametrize("M,N,K", [(512, 512, 256), (130, 72, 64)])
+def test_gelu_grad8_grid_holds_zero_and_one_exactly(ops, M, N, K):
+    """the two most common values of gelu' must be grid points.  A saturated unit (pre-activation >> 0,
+    gelu' = 1) gets code 226 and passes the gradient UNCHANGED; a dead unit (pre-activation << 0, gelu' = 0) gets code 26
+    and leaks NOTHING: the consumer's output equals the plain product bit for bit, respectively is exactly zero."""
+    a = bf(torch.randn(M, K, generator=g(1)))
+    w = torch.zeros(N, K)
+    b = torch.where(torch.arange(N) % 2 == 0, 30.0, -30.0)              # even columns saturated, odd columns dead
+    g8 = torch.zeros(M, N, device="cuda", dtype=torch.uint8)
+    act = torch.zeros(M, N, device="cuda", dtype=torch.bfloat16)
+    ops.linear_fwd(a.cuda(), M, K, w.cuda(), b.cuda(), act, N, epi=ops.EPI_GELU_GRAD8, out2=g8, ld_out2=N)
+    assert bool((g8[:, 0::2] == 226).all()) and bool((g8[:, 1::2] == 26).all())
+    # consumer: dx = (dy W2) * decode(codes); the codes tensor has the shape of dx, [M, K]
+    dy, w2 = bf(torch.randn(M, N, generator=g(5))), bf(torch.randn(N, K, generator=g(6)) * N ** -0.5)
+    codes = torch.where(torch.arange(K) % 2 == 0, 226, 26).to(torch.uint8).expand(M, K).contiguous()
+    dx = torch.empty(M, K, device="cuda", dtype=torch.bfloat16)
+    plain = torch.empty(M, K, device="cuda", dtype=torch.bfloat16)
+    part = torch.zeros((M + 63) // 64, K, device="cuda")
+    ops.linear_dx(dy.cuda(), M, N, w2.float().cuda(), dx, K, epi=ops.EPI_MUL8, aux=codes.cuda(), ld_aux=K, colsum_partial=part)
+    ops.linear_dx(dy.cuda(), M, N, w2.float().cuda(), plain, K)
+    assert torch.equal(dx[:, 0::2], plain[:, 0::2])                      # x 1.0 exactly
+    assert bool((dx[:, 1::2] == 0).all())                                # x 0.0 exactly
+    assert bool((part[:, 1::2] == 0).all())
+
+
 # Every NT / TN kernel variant on shapes large enough to reach it (>= 2 tiles of 256, ragged M and N edges, K long
 # enough for the 8-phase pipeline), all epilogues.  The automatic dispatch only picks the 256^2 kernels for >= 256
 # tiles, which no unit-test shape has; mv_gemm_force_variant switches variants inside this one process.
@@ -135,19 +160,19 @@ def test_gemm_nt_every_variant(ops, variant, M, N, K):
             ops.linear_dx(dy.cuda(), M, N, wp, dx, K, epi=ops.EPI_MUL, aux=gg.cuda(), ld_aux=K, colsum_partial=part)
             assert relerr(dx.float(), want) < 2.0 ** -8
             assert relerr(part.sum(0), want.sum(0)) < 3e-3
-        # the 8-bit forms: gelu' as a code on the fixed grid [-0.13, 1.13] (step 1.26 / 255), and its consumer
+        # the 8-bit forms: gelu' as a code on the fixed grid (code - 26) * 0.005 (0 and 1 are grid points), and its consumer
         g8 = torch.full((M, ldn), 77, device="cuda", dtype=torch.uint8)
         act8 = torch.zeros(M, ldn, device="cuda", dtype=torch.bfloat16)
         ops.linear_fwd(a.cuda(), M, K, wp, b.cuda(), act8, ldn, epi=ops.EPI_GELU_GRAD8, out2=g8, ld_out2=ldn)
         assert torch.equal(act8[:, :N], act[:, :N])
-        dec = g8[:, :N].double().cpu() * (1.26 / 255) - 0.13
-        assert float((dec - dgelu64(pre)).abs().max()) <= 0.5 * 1.26 / 255 + 2e-6
+        dec = (g8[:, :N].double().cpu() - 26) * 0.005
+        assert float((dec - dgelu64(pre)).abs().max()) <= 0.5 * 0.005 + 2e-6
         if ldn > N:
             assert bool((g8[:, N:] == 77).all())                          # padding columns untouched
         if N % 8 == 0:
             dy = bf(torch.randn(M, N, generator=g(5)))
             codes = torch.randint(0, 256, (M, K), generator=g(9), dtype=torch.uint8)
-            want = (dy.double() @ w.double()) * (codes.double() * (1.26 / 255) - 0.13)
+            want = (dy.double() @ w.double()) * ((codes.double() - 26) * 0.005)
             dx = torch.empty(M, K, device="cuda", dtype=torch.bfloat16)
             part = torch.zeros((M + 63) // 64, K, device="cuda")
             ops.linear_dx(dy.cuda(), M, N, wp, dx, K, epi=ops.EPI_MUL8, aux=codes.cuda(), ld_aux=K, colsum_partial=part)

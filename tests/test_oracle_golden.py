@@ -62,6 +62,19 @@ def test_oracle_matches_reference_fp32(name):
             np.testing.assert_allclose(g.numpy(), w, atol=2e-4 * max(np.abs(w).max(), 1e-12), err_msg=k)
 
 
+@pytest.mark.parametrize("name", ["base_cls_b32", "tiny_cls_b64"])
+def test_oracle_matches_reference_logits_only(name):
+    """Round-3 top-1 fixtures (eval forward of the reference over 32 / 64 images): oracle logits and EVERY argmax."""
+    arrays, meta, cfg, params, img, labels = _setup(name)
+    torch.set_num_threads(8)
+    with torch.no_grad():
+        logits = vit_forward(params, img, cfg)
+    want = arrays["logits"]
+    assert want.shape[0] == meta["batch"] >= 32
+    np.testing.assert_allclose(logits.numpy(), want, atol=2e-5 * np.abs(want).max())
+    assert (logits.argmax(1).numpy() == want.argmax(1)).all()
+
+
 def test_oracle_taps_match_reference():
     arrays, meta, cfg, params, img, labels = _setup("micro_cls")
     taps = {}
