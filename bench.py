@@ -63,9 +63,10 @@ def pmc_traffic(kernel_family):
     inside this process, so this is the last measured value for the same command, or None if none has been committed."""
     got = _latest_profile("pmc_traffic.json")
     try:
-        return round(got[0]["kernels"][kernel_family]["hbm_bytes_per_launch"])
+        d, name = got
+        return round(d["kernels"][kernel_family]["hbm_bytes_per_launch"]), {"source": f"profiles/{name}", "commit": d.get("commit")}
     except (TypeError, KeyError, ValueError):
-        return None
+        return None, None
 
 
 def pmc_mfma_util():
@@ -76,7 +77,8 @@ def pmc_mfma_util():
         d, name = got
         return {"gemm_nt": round(d["kernels"]["gemm_nt"]["mfma_util"], 4), "gemm_tn": round(d["kernels"]["gemm_tn"]["mfma_util"], 4),
                 "attention": round(d["kernels"]["attention"]["mfma_util"], 4),
-                "attention_mlp_block": round(d["block"]["mfma_util"], 4), "source": f"profiles/{name}"}
+                "attention_mlp_block": round(d["block"]["mfma_util"], 4), "source": f"profiles/{name}",
+                "commit": d.get("commit")}
     except (TypeError, KeyError, ValueError):
         return None
 
@@ -109,7 +111,7 @@ def cpu_baseline(seconds_budget=25.0):
     med = times[len(times) // 2]
     return {"value": round(8.0 / med, 3), "unit": "images/sec", "cores": torch.get_num_threads(), "kind": "port",
             "sample": f"ViT-B/16 224^2 fp32 fwd+bwd, batch 8, median of {len(times)} after 1 warm-up "
-                      f"(oracle/vit_oracle.py on {os.cpu_count()} host cpus)"}
+                      f"(oracle/vit_oracle.py; {torch.get_num_threads()}-thread affinity share of a {os.cpu_count()}-cpu host)"}
 
 
 def self_launch(n_gpus):
@@ -215,11 +217,13 @@ def main():
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
         else:
             dist.init_process_group(backend, rank=rank, world_size=world)
+        if not force_dist and dist.get_world_size() != args.gpus:      # every rank checks: one process per GPU, all of them here
+            raise SystemExit(f"rank {rank}: process group has {dist.get_world_size()} ranks, --gpus says {args.gpus}")
 
     from myrtle_vision.hip import ops
     from myrtle_vision.hip.functional import cross_entropy
     from myrtle_vision.models.vit import ViT
-    from myrtle_vision.utils.ddp import GradAllReducer, broadcast_parameters
+    from myrtle_vision.utils.ddp import GradAllReducer, broadcast_parameters, exchange_dtype_from_env
     from myrtle_vision.utils.optim import AdamW, ParamArena
     from myrtle_vision.utils.utils import seed_everything
 
@@ -233,7 +237,7 @@ def main():
     vit = ViT(precision=args.precision, q_format=q_format, **cfg).to(dev)
     arena = ParamArena(vit.named_parameters(), skip=vit.unused_parameter_names())
     opt = AdamW(arena, lr=6.25e-5, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.05)      # vit_base.json
-    reducer = GradAllReducer(arena)
+    reducer = GradAllReducer(arena, exchange_dtype=exchange_dtype_from_env(), measure=True)    # MV_DDP_EXCHANGE=bf16: opt-in
     if force_dist:
         reducer.enabled = True                                  # launch the bucketed all-reduces although world == 1
         dist.broadcast(arena.flat_param, src=0)
@@ -289,10 +293,15 @@ def main():
     elapsed = time.perf_counter() - t0
     ops.set_kernel_timer(None)
     final_loss = float(loss.detach())
+    exposed_ms = reducer.exposed_ms()                           # per rank; the slowest rank's is reported
     if world > 1:
         t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t)
+        if exposed_ms is not None:
+            t = torch.tensor([exposed_ms], device=dev, dtype=torch.float64)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            exposed_ms = float(t)
 
     if rank == 0:
         img_s = args.batch * world * args.steps / elapsed
@@ -312,15 +321,31 @@ def main():
                        "per_gpu_batch": args.batch, "global_batch": args.batch * world,
                        "parallelism": f"dp{world}", "final_loss": round(final_loss, 4)},
         }
+        if world > 1 or force_dist:
+            # what the exchange looked like, so a scaling run explains itself: the collective library and
+            # its version, what one step puts on the links, and how long the GPU waited for the exchange after backward's
+            # last kernel (events on the compute stream around GradAllReducer.finish(), mean over the timed steps, max over ranks)
+            try:
+                rccl = ".".join(str(v) for v in torch.cuda.nccl.version())
+            except Exception:
+                rccl = None
+            out["dist"] = {"backend": dist.get_backend(), "world": dist.get_world_size(), "rccl_version": rccl,
+                           **reducer.describe(),
+                           "allreduce_exposed_ms": None if exposed_ms is None else round(exposed_ms, 3),
+                           "rehearsal_one_rank": bool(force_dist),
+                           "env": {k: os.environ[k] for k in ("NCCL_MAX_NCHANNELS", "NCCL_MIN_NCHANNELS", "NCCL_ALGO", "NCCL_PROTO",
+                                                               "MV_DDP_EXCHANGE") if k in os.environ}}
         if args.workload == "cls":
             out["step_mfma_frac"] = round(img_s / world * TRAIN_GFLOP_PER_IMG * 1e9 / (BF16_DENSE_PEAK_TFLOPS * 1e12), 4)
         if timer is not None:
             summ = timer.summary()
             k = summ.get("gemm_nt_bf16")
+            traffic, traffic_src = pmc_traffic("gemm_nt")
             if k:
                 out["roofline"] = {"bound": "mfma", "kernel": "gemm_nt_8phase_kernel family (mv_gemm_nt_bf16)",
                                    "achieved": round(k["tflops"], 1), "peak": BF16_DENSE_PEAK_TFLOPS, "unit": "TFLOP/s",
-                                   "frac": round(k["tflops"] / BF16_DENSE_PEAK_TFLOPS, 4), "traffic": pmc_traffic("gemm_nt"),
+                                   "frac": round(k["tflops"] / BF16_DENSE_PEAK_TFLOPS, 4), "traffic": traffic,
+                                   "traffic_source": traffic_src,
                                    "launches": k["launches"], "timed_steps": f"every {args.timer_every}th of {args.steps}",
                                    "avg_launch_us": round(k["avg_us"], 1),
                                    "gflop_per_launch": round(k["flops_per_launch"] / 1e9, 2),

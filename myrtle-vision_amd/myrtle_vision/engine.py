@@ -25,7 +25,7 @@ from torch.utils.data import DataLoader, Sampler
 
 from myrtle_vision.hip.functional import CrossEntropyLoss
 from myrtle_vision.hip import ops
-from myrtle_vision.utils.ddp import GradAllReducer, broadcast_parameters
+from myrtle_vision.utils.ddp import GradAllReducer, broadcast_parameters, exchange_dtype_from_env
 from myrtle_vision.utils.miou import MIoU
 from myrtle_vision.utils.models import (get_models, get_optimizer_args, prepare_model_and_load_ckpt,
                                         rename_timm_state_dict, save_checkpoint)
@@ -153,6 +153,34 @@ class BatchFeed:
             cur = nxt
 
 
+class _Scalars:
+    """The reference's segmentation loop logs validation accuracy / loss / mIoU to TensorBoard
+    (segmentation/train.py:17,33,69-71: ``SummaryWriter("runs/")``).  ``torch.utils.tensorboard`` needs the
+    ``tensorboard`` package; where it is missing the same three scalars go to ``runs/scalars.jsonl`` instead (one JSON
+    object per call), so the log exists either way and nothing fails at import time."""
+
+    def __init__(self, logdir="runs/"):
+        self.writer, self.path = None, None
+        try:
+            from torch.utils.tensorboard import SummaryWriter
+            self.writer = SummaryWriter(logdir)
+        except Exception:                                       # ImportError, or tensorboard present but unusable
+            os.makedirs(logdir, exist_ok=True)
+            self.path = os.path.join(logdir, "scalars.jsonl")
+
+    def add_scalar(self, tag, value, step):
+        if self.writer is not None:
+            self.writer.add_scalar(tag, value, step)
+        else:
+            import json
+            with open(self.path, "a") as f:
+                f.write(json.dumps({"tag": tag, "value": float(value), "step": int(step)}) + "\n")
+
+    def close(self):
+        if self.writer is not None:
+            self.writer.close()
+
+
 def _fused_seg_tail(task, criterion):
     """The segmentation loops may replace ``criterion(vit(x), y)`` + ``argmax`` by ``vit.segmentation_loss`` only when
     the criterion is the plain mean cross entropy the reference uses (segmentation/train.py:188)."""
@@ -231,12 +259,17 @@ def train_worker(rank, num_gpus, config, task="classification"):
     iteration = prepare_model_and_load_ckpt(train_config=train_config, model=vit, optimizer=optimizer,
                                             lr_scheduler=lr_scheduler)
     optimizer.arena.bump_versions()
-    reducer = GradAllReducer(optimizer.arena)
+    reducer = GradAllReducer(optimizer.arena, exchange_dtype=exchange_dtype_from_env())   # MV_DDP_EXCHANGE=bf16: half-width, opt-in
     broadcast_parameters(optimizer.arena)
     optimizer.grad_scale = reducer.grad_scale
     # classification/train.py:265-270 (clip_grad_norm_ after backward): here the norm is taken once per optimizer step over
     # the flat (all-reduced, accumulated) gradient arena and the coefficient is applied inside the AdamW kernel
     optimizer.max_grad_norm = optimizer_args.clip_grad
+    if optimizer_args.clip_grad is not None and n_batch_accum > 1 and rank == 0:
+        print(f"WARNING: clip_grad={optimizer_args.clip_grad} with n_batch_accum={n_batch_accum}: the reference clips the "
+              "running accumulated gradient after EVERY micro-batch backward (classification/train.py:265-270); this loop "
+              "clips once per optimizer step, after accumulation and all-reduce.  The two differ whenever a clip engages.")
+    scalars = _Scalars(train_config.get("tensorboard_dir", "runs/")) if (task == "segmentation" and rank == 0) else None
 
     vit.train()
     epoch_offset = max(0, int(batch_size * world * iteration / max(len(trainset), 1)))
@@ -254,6 +287,10 @@ def train_worker(rank, num_gpus, config, task="classification"):
                                 filepath=f"{out_dir}/vit_{iteration:06}")
             if iteration % train_config["iters_per_val"] == 0 and n_accum == 0 and rank == 0:
                 last_val = validation(val_loader, device, criterion, vit, task, num_classes)
+                if scalars is not None:                          # segmentation/train.py:69-71
+                    scalars.add_scalar("accuracy", last_val[1], iteration)
+                    scalars.add_scalar("loss", last_val[0], iteration)
+                    scalars.add_scalar("miou", last_val[2], iteration)
             if n_accum == 0:
                 optimizer.zero_grad()
             reducer.enabled = reducer.world > 1 and (n_accum == n_batch_accum - 1)
@@ -280,6 +317,8 @@ def train_worker(rank, num_gpus, config, task="classification"):
             extra = f" - val_miou: {last_val[2]:.4f}" if last_val[2] is not None else ""
             print(f"Epoch : {epoch + 1} - loss : {epoch_loss:.4f} - acc: {epoch_acc:.4f} - "
                   f"val_loss : {last_val[0]:.4f} - val_acc: {last_val[1]:.4f}{extra}\n")
+    if scalars is not None:
+        scalars.close()
     if num_gpus > 1:
         cleanup_distributed()
     return iteration

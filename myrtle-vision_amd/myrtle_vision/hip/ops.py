@@ -732,6 +732,15 @@ def cast(src, out_dtype):
     return out
 
 
+def cast_into(src, dst):
+    """dst <- src with a dtype conversion, into caller-owned storage (the DDP exchange's bf16 staging copies)."""
+    require_cuda(src, dst)
+    if src.numel() != dst.numel() or not (src.is_contiguous() and dst.is_contiguous()):
+        raise ValueError("cast_into: contiguous tensors of equal size")
+    check(lib().mv_cast(_p(src), _DT[src.dtype], _p(dst), _DT[dst.dtype], src.numel(), _s()), "cast", n=src.numel())
+    return dst
+
+
 def gelu_fwd(x):
     y = torch.empty_like(x)
     check(lib().mv_gelu_fwd(_p(x), _p(y), _DT[x.dtype], x.numel(), _s()), "gelu_fwd", n=x.numel())

@@ -14,6 +14,15 @@ backward ends is reduced in ``finish()``, so a missing gradient can never deadlo
 xGMI is point-to-point (7 links x ~153 GB/s per GPU), a ring all-reduce is per-link bound, so buckets are large
 (default 48 MiB): 86 M fp32 gradients = 8 collectives per step rather than torch-DDP's 14 x 25 MiB, and the bucket that can
 only complete at the end of backward (the first layers') stays below 7 % of the gradient bytes.
+
+``exchange_dtype=torch.bfloat16`` (opt-in; ``MV_DDP_EXCHANGE=bf16`` in the training loops and bench.py) halves the bytes on
+the links: a bucket is rounded to bf16 into a staging buffer when it completes, summed in bf16 by the collective, and
+widened back into the fp32 arena in ``finish()``.  The fp32 default is bit-for-bit DDP's mean; the bf16 form adds one
+rounding of each rank's gradient and the collective's bf16 partial sums (<= ~1e-2 relative per element at 8 ranks: the size
+of the bf16 backward's own error, tests/test_host_cpu.py::test_gradient_allreduce_bf16_exchange_world2_gloo).
+
+``measure=True`` brackets ``finish()`` with events on the compute stream: the time between the end of backward and the
+last collective's completion as the GPU sees it -- the EXPOSED part of the exchange (``exposed_ms()``); bench.py reports it.
 """
 from typing import List
 
@@ -22,8 +31,16 @@ import torch.distributed as dist
 
 
 class GradAllReducer:
-    def __init__(self, arena, process_group=None, bucket_bytes: int = 48 << 20, tail_bytes: int = 12 << 20):
+    def __init__(self, arena, process_group=None, bucket_bytes: int = 48 << 20, tail_bytes: int = 12 << 20,
+                 exchange_dtype=torch.float32, measure: bool = False):
+        if exchange_dtype not in (torch.float32, torch.bfloat16):
+            raise ValueError(f"exchange_dtype {exchange_dtype}: float32 or bfloat16")
         self.arena = arena
+        self.exchange_dtype = exchange_dtype
+        self.stage = (torch.empty(arena.total, dtype=torch.bfloat16, device=arena.flat_grad.device)
+                      if exchange_dtype == torch.bfloat16 else None)
+        self.measure = measure and arena.flat_grad.is_cuda
+        self._spans = []                                       # (event at finish() entry, event after the last wait)
         self.group = process_group
         self.world = dist.get_world_size(process_group) if dist.is_initialized() else 1
         # bucket boundaries fall on parameter boundaries; buckets are filled from the END of the arena, because
@@ -81,12 +98,19 @@ class GradAllReducer:
     def _launch(self, b):
         lo, hi, _, _ = self.ranges[b]
         self.launched[b] = True
-        self.handles.append(dist.all_reduce(self.arena.flat_grad[lo:hi], op=dist.ReduceOp.SUM, group=self.group,
-                                            async_op=True))
+        buf = self.arena.flat_grad[lo:hi]
+        if self.stage is not None:
+            _convert(buf, self.stage[lo:hi])                   # on the compute stream, behind the kernels that wrote the bucket
+            buf = self.stage[lo:hi]
+        self.handles.append(dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=self.group, async_op=True))
 
     def finish(self):
         """Call after backward: reduce whatever has not been reduced, wait for every collective, re-arm."""
         if self.enabled:
+            span = None
+            if self.measure:
+                span = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+                span[0].record()                              # everything backward enqueued is in front of this
             for b in range(len(self.ranges)):
                 if not self.launched[b]:
                     for j in range(self.ranges[b][2], self.ranges[b][3]):
@@ -94,10 +118,34 @@ class GradAllReducer:
                             self.arena.sync_grad(j)          # no gradient this step: the slot must hold zeros
                     self._launch(b)
             for h in self.handles:
-                h.wait()
+                h.wait()                                      # the compute stream waits for the collective's stream
+            if self.stage is not None:
+                for lo, hi, _, _ in self.ranges:
+                    _convert(self.stage[lo:hi], self.arena.flat_grad[lo:hi])
+            if span is not None:
+                span[1].record()
+                self._spans.append(span)
         self.handles = []
         self.pending = list(self.sizes)
         self.launched = [False] * len(self.ranges)
+
+    def exposed_ms(self, reset: bool = True):
+        """Mean GPU time per step between the end of backward and the completion of the exchange (``measure=True``), or
+        None.  Synchronises the device: call it outside the timed region."""
+        if not self._spans:
+            return None
+        torch.cuda.synchronize()
+        ms = sum(a.elapsed_time(b) for a, b in self._spans) / len(self._spans)
+        if reset:
+            self._spans = []
+        return ms
+
+    def describe(self) -> dict:
+        """What one step puts on the links (for the benchmark's ``dist`` record)."""
+        esz = 2 if self.stage is not None else 4
+        sizes = [(hi - lo) * esz for lo, hi, _, _ in self.ranges]
+        return {"buckets": len(self.ranges), "bytes": int(sum(sizes)), "largest_bucket_bytes": int(max(sizes)),
+                "exchange_dtype": "bf16" if self.stage is not None else "fp32"}
 
     @property
     def grad_scale(self) -> float:
@@ -107,6 +155,25 @@ class GradAllReducer:
     def remove(self):
         for h in self._hooks:
             h.remove()
+
+
+def _convert(src, dst):
+    """dst <- src across fp32 / bf16 (the staging copies of the bf16 exchange): the HIP cast kernel on the device, torch on
+    the host (the gloo tests)."""
+    if src.is_cuda:
+        from myrtle_vision.hip import ops
+        ops.cast_into(src, dst)
+    else:
+        dst.copy_(src)
+
+
+def exchange_dtype_from_env():
+    """``MV_DDP_EXCHANGE`` = fp32 (default) | bf16."""
+    import os
+    v = os.environ.get("MV_DDP_EXCHANGE", "fp32").lower()
+    if v not in ("fp32", "bf16"):
+        raise ValueError(f"MV_DDP_EXCHANGE={v!r}: fp32 or bf16")
+    return torch.bfloat16 if v == "bf16" else torch.float32
 
 
 def broadcast_parameters(arena, src: int = 0, process_group=None):

@@ -291,7 +291,7 @@ def test_get_models_reads_reference_config_schema(tmp_path):
 
 
 # ---------------------------------------------------------------- N > 1: gradient exchange over gloo
-def _ddp_worker(rank, world, port, tmpdir):
+def _ddp_worker(rank, world, port, tmpdir, exchange=torch.float32):
     os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     from myrtle_vision.utils.ddp import GradAllReducer, broadcast_parameters
@@ -302,8 +302,9 @@ def _ddp_worker(rank, world, port, tmpdir):
     named = list(model.named_parameters()) + [("unused", unused)]
     arena = ParamArena(named)
     broadcast_parameters(arena, src=0)                              # DDP's constructor broadcast
-    red = GradAllReducer(arena, bucket_bytes=2048)                  # several buckets
+    red = GradAllReducer(arena, bucket_bytes=2048, exchange_dtype=exchange)   # several buckets
     assert len(red.ranges) > 2
+    assert red.describe()["bytes"] == arena.total * (2 if exchange == torch.bfloat16 else 4)
     g = torch.Generator().manual_seed(7)
     X, Y = torch.randn(8, 12, generator=g), torch.randn(8, 3, generator=g)
     xs, ys = X[rank::world], Y[rank::world]                         # DistributedSampler-style shard
@@ -340,6 +341,74 @@ def test_gradient_allreduce_world2_gloo(tmp_path):
     assert torch.allclose(arena.flat_grad, r0["grad"], atol=1e-6, rtol=1e-5)
     f0, f1 = torch.load(tmp_path / "final0.pt"), torch.load(tmp_path / "final1.pt")
     assert torch.equal(f0, f1)                                       # identical parameters on all ranks after K steps
+
+
+def test_gradient_allreduce_bf16_exchange_world2_gloo(tmp_path):
+    """``exchange_dtype=torch.bfloat16`` (half the bytes on the links): every rank still ends with the SAME gradient and the
+    same parameters; the gradient equals the fp32 exchange's to bf16 resolution (one rounding per rank + one bf16 sum)."""
+    port = 31500 + (os.getpid() % 2000)
+    mp.spawn(_ddp_worker, args=(2, port, str(tmp_path), torch.bfloat16), nprocs=2, join=True)
+    r0, r1 = torch.load(tmp_path / "r0.pt"), torch.load(tmp_path / "r1.pt")
+    assert torch.equal(r0["grad"], r1["grad"])
+    f0, f1 = torch.load(tmp_path / "final0.pt"), torch.load(tmp_path / "final1.pt")
+    assert torch.equal(f0, f1)
+    from myrtle_vision.utils.optim import ParamArena
+    torch.manual_seed(100)
+    model = torch.nn.Sequential(torch.nn.Linear(12, 40), torch.nn.Tanh(), torch.nn.Linear(40, 24), torch.nn.Tanh(), torch.nn.Linear(24, 3))
+    arena = ParamArena(list(model.named_parameters()) + [("unused", torch.nn.Parameter(torch.randn(5)))])
+    g = torch.Generator().manual_seed(7)
+    X, Y = torch.randn(8, 12, generator=g), torch.randn(8, 3, generator=g)
+    ((model(X) - Y) ** 2).mean().backward()
+    arena.sync_grads()
+    want, got = arena.flat_grad, r0["grad"]
+    assert float((want - got).norm() / want.norm()) < 2.0 ** -7            # measured 2e-3: bf16 is 2^-9 per rounding
+    assert float((want - got).abs().max() / want.abs().max()) < 2.0 ** -6
+    assert not torch.equal(want, got)                                        # it really went through bf16
+    with pytest.raises(ValueError):
+        from myrtle_vision.utils.ddp import GradAllReducer
+        GradAllReducer(arena, exchange_dtype=torch.float16)
+
+
+def _synthetic_arena(shapes):
+    """[(name, shape)] -> ParamArena; 1-D tensors and '.bias' names land in the no-decay region."""
+    from myrtle_vision.utils.optim import ParamArena
+    return ParamArena([(n, torch.nn.Parameter(torch.zeros(s))) for n, s in shapes])
+
+
+@pytest.mark.parametrize("case", ["no_decay_only", "decay_only", "one_param_over_cap", "tail_taper", "mixed_small"])
+def test_gradient_buckets_tile_any_arena(case):
+    """on ANY arena the bucket ranges are contiguous, cover [0, total) exactly once, every parameter belongs to
+    exactly one bucket whose range contains its slot, no bucket straddles the decay / no-decay boundary, and a bucket exceeds
+    the cap only when it holds a single parameter that is itself larger."""
+    from myrtle_vision.utils.ddp import GradAllReducer
+    shapes = {
+        "no_decay_only": [(f"l{i}.bias", (100,)) for i in range(7)],                       # zero decay parameters
+        "decay_only": [(f"l{i}.weight", (64, 64)) for i in range(9)],                      # zero no-decay parameters
+        "one_param_over_cap": [("a.weight", (8, 8)), ("big.weight", (600, 512)), ("b.weight", (16, 16)), ("b.bias", (16,))],
+        "tail_taper": [(f"l{i}.weight", (256, 256)) for i in range(12)] + [(f"l{i}.bias", (256,)) for i in range(12)],
+        "mixed_small": [("w0.weight", (3, 5)), ("w0.bias", (3,)), ("w1.weight", (7, 3)), ("w1.bias", (7,)), ("scale", (1,))],
+    }[case]
+    arena = _synthetic_arena(shapes)
+    cap, tail = 256 << 10, 64 << 10
+    red = GradAllReducer(arena, bucket_bytes=cap, tail_bytes=tail)
+    ranges = sorted((lo, hi, j0, j1) for lo, hi, j0, j1 in red.ranges)
+    assert ranges[0][0] == 0 and ranges[-1][1] == arena.total
+    assert all(a[1] == b[0] and a[3] == b[2] for a, b in zip(ranges, ranges[1:]))       # contiguous in elements AND in parameters
+    assert ranges[0][2] == 0 and ranges[-1][3] == len(arena.params)
+    assert sorted(red.bucket_of) == list(range(len(arena.params)))                      # every parameter exactly once
+    for j, b in red.bucket_of.items():
+        lo, hi, j0, j1 = red.ranges[b]
+        assert j0 <= j < j1 and lo <= arena.offsets[j] and arena.offsets[j] + arena.params[j].numel() <= hi
+    for lo, hi, j0, j1 in ranges:
+        assert hi <= arena.n_decay or lo >= arena.n_decay or arena.n_decay in (0, arena.total)
+        assert (hi - lo) * 4 <= cap or j1 - j0 == 1
+    if case == "one_param_over_cap":
+        assert any((hi - lo) * 4 > cap and j1 - j0 == 1 for lo, hi, j0, j1 in ranges)
+    if case == "tail_taper":                                                            # the arena's first buckets = the last to complete
+        assert (ranges[0][1] - ranges[0][0]) * 4 <= tail + 256 * 256 * 4
+        assert max((hi - lo) * 4 for lo, hi, _, _ in ranges) > tail
+    assert sum(red.sizes) == len(arena.params) and red.pending == red.sizes
+    red.remove()
 
 
 def test_gradient_bucket_layout_vit_b():

@@ -1,0 +1,107 @@
+"""BASELINE config 5 as a whole model: the converted PyTorchINT8 ViT-B/16 on the int8 matrix cores against the CPU oracle
+``oracle/int8_oracle.py`` (torch's MinMaxObserver + fake_quantize semantics at every Linear; pinned on the CPU in
+tests/test_int8_oracle.py), full depth, and the batch-1024 configuration through a size-independent property.
+
+8-bit quantisers are discontinuous: an fp32-ulp difference in front of one flips a code (1/255 of that tensor's range),
+so a model-level comparison has a floor that per-layer exactness (tests/test_hip_ops.py) does not; the bound below is the
+measured value with about 2x slack, and class indices are compared wherever the oracle's top-2 margin exceeds the
+measured error."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from oracle import int8_oracle  # noqa: E402
+from oracle.detinit import det_images, det_state_dict  # noqa: E402
+from oracle.vit_oracle import ViTConfig  # noqa: E402
+from test_vit_parity import report  # noqa: E402
+
+BASE = dict(decoder="classification", image_size=224, patch_size=16, num_classes=1000, dim=768, depth=12, heads=12, mlp_dim=3072)
+
+
+def _converted(kw, calib):
+    from myrtle_vision.models.vit import ViT
+    cfg = ViTConfig(**kw)
+    params = det_state_dict(cfg.param_shapes())
+    vit = ViT(q_format="FP32", precision="bf16", **kw)
+    vit.load_state_dict(params)
+    vit = vit.cuda()
+    vit.quantizer.prepare_qat("PyTorchINT8")                  # classification/test_quantize.py:100-103
+    with torch.no_grad():
+        for b in calib:                                       # calibrate(): test_quantize.py:26-34
+            vit(b.cuda())
+    return vit, cfg, params
+
+
+@pytest.mark.parametrize("name,kw,tol", [("micro", dict(BASE, dim=192, depth=2, heads=3, mlp_dim=768, num_classes=45), 1.5e-2),
+                                         ("vit_b", BASE, 3e-2)])
+def test_converted_int8_model_matches_oracle(name, kw, tol):
+    calib = [det_images(f"int8-calib{i}", 4, 224) for i in range(3)]
+    img = det_images("int8-eval", 4, 224)
+    vit, cfg, params = _converted(kw, calib)
+    torch.set_num_threads(8)
+    ranges = int8_oracle.calibrate(params, calib, cfg)
+    # (1) the observers saw what the oracle's saw: every Linear input's running min / max
+    from myrtle_vision.utils.quantize import MinMaxObserver, QuantStub
+    seen = {}
+    for mname, m in vit.named_modules():
+        if isinstance(m, QuantStub) and isinstance(m.activation_post_process, MinMaxObserver):
+            seen["act:" + mname[:-2]] = [float(v) for v in m.activation_post_process.state[:2].tolist()]    # "<linear>.0" -> "<linear>"
+    assert set(seen) == {s for s in ranges if s.startswith("act:")}
+    worst = 0.0
+    for site, (lo, hi) in seen.items():
+        span = ranges[site][1] - ranges[site][0]
+        worst = max(worst, abs(lo - ranges[site][0]) / span, abs(hi - ranges[site][1]) / span)
+    report(f"int8/{name} calibration min-max vs oracle (of the span)", worst)
+    assert worst < 1e-4                                        # far below one 8-bit step (3.9e-3 of the span)
+    # (2) convert, then the frozen parameters are torch's calculate_qparams of those ranges
+    vit.convert()
+    vit.eval()
+    qp = int8_oracle.qparams(ranges)
+    from myrtle_vision.utils.quantize import Int8Linear
+    n_lin = 0
+    for mname, m in vit.named_modules():
+        if isinstance(m, Int8Linear):
+            n_lin += 1
+            site = mname[:-2]
+            s, z = m.act_observer.frozen
+            so, zo = qp["act:" + site][:2]
+            assert abs(z - zo) <= 1 and abs(s - float(so)) < 1e-4 * float(so), (site, s, z, so, zo)
+            assert abs(m.weight_scale - float(qp["w:" + site][0])) < 1e-6 * m.weight_scale, site
+    assert n_lin == 4 * cfg.depth + 2
+    # (3) the converted forward pass
+    with torch.no_grad():
+        got = vit(img.cuda()).float().cpu().numpy()
+    want = int8_oracle.int8_forward(params, img, cfg, qp).numpy()
+    scale = np.abs(want).max()
+    err = float(np.abs(got - want).max() / scale)
+    report(f"int8/{name} converted logits vs oracle", err)
+    assert np.isfinite(got).all() and err < tol
+    top2 = np.sort(want, axis=1)[:, -2:]
+    safe = (top2[:, 1] - top2[:, 0]) / scale > 2 * err
+    report(f"int8/{name} images outside the margin", float(safe.sum()))
+    assert (got.argmax(1) == want.argmax(1))[safe].all()
+
+
+def test_converted_int8_batch_1024_contains_its_images():
+    """BASELINE config 5's own size (ViT-B/16, batch 1024, forward only): finite logits, and an image's logits do not
+    depend on the batch around it -- the 8 images evaluated alone give the same logits as inside the 1024 (per-tensor
+    quantiser parameters are frozen, integer products are exact; only kernel variants differ between M = 1 576 and
+    201 728 rows)."""
+    gen = torch.Generator().manual_seed(11)
+    calib = [torch.randn(16, 3, 224, 224, generator=gen) for _ in range(2)]
+    vit, cfg, params = _converted(BASE, calib)
+    vit.convert()
+    vit.eval()
+    big = torch.randn(1024, 3, 224, 224, generator=gen).cuda()
+    with torch.no_grad():
+        all_ = vit(big).float()
+        idx = torch.tensor([0, 1, 255, 256, 511, 777, 1022, 1023], device="cuda")
+        alone = vit(big[idx]).float()
+    assert all_.shape == (1024, 1000) and bool(torch.isfinite(all_).all())
+    d = float((all_[idx] - alone).norm() / alone.norm())
+    report("int8/vit_b batch-1024 vs the same 8 images alone (rel-L2)", d)
+    assert d < 1e-5
+    assert torch.equal(all_[idx].argmax(1), alone.argmax(1))
+    assert len(set(all_.argmax(1).tolist())) > 1               # not a constant function

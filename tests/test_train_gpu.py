@@ -26,7 +26,7 @@ def _config(tmp_path, task, size="tiny"):
     cfg["data_config_path"] = dpath
     t = cfg["train_config"]
     t.update(output_directory=str(tmp_path / "ckpt"), epochs=1, local_batch_size=8, global_batch_size=8, iters_per_checkpoint=2,
-             iters_per_val=2, distributed=False, pretrained_backbone=None)
+             iters_per_val=2, distributed=False, pretrained_backbone=None, tensorboard_dir=str(tmp_path / "runs"))
     cfg["vit_config"]["depth"] = 2                                          # keep the test short
     return cfg
 
@@ -42,6 +42,12 @@ def test_train_loop_writes_reloadable_checkpoints(tmp_path, task, capsys):
     assert "vit_000000" in ckpts and "vit_000002" in ckpts                  # rank-0 checkpoints, reference naming
     ck = torch.load(os.path.join(cfg["train_config"]["output_directory"], "vit_000002"), map_location="cpu", weights_only=False)
     assert set(ck) == {"model", "optimizer", "lr_scheduler", "iteration"} and ck["iteration"] == 2
+    if task == "segmentation":                                              # segmentation/train.py:69-71: accuracy, loss, miou
+        logged = os.listdir(cfg["train_config"]["tensorboard_dir"])
+        assert logged, "validation scalars were not written"
+        if "scalars.jsonl" in logged:
+            rows = [json.loads(l) for l in open(os.path.join(cfg["train_config"]["tensorboard_dir"], "scalars.jsonl"))]
+            assert {r["tag"] for r in rows} == {"accuracy", "loss", "miou"} and {r["step"] for r in rows} >= {0, 2}
     # resume + evaluate from the checkpoint
     cfg2 = copy.deepcopy(cfg)
     cfg2["train_config"]["checkpoint_path"] = os.path.join(cfg["train_config"]["output_directory"], "vit_000002")
@@ -110,64 +116,86 @@ def test_gradients_land_in_their_arena_slots(decoder, precision, size):
         assert torch.allclose(p.grad, 2 * want[n], rtol=1e-6, atol=1e-30), n
 
 
-def _ddp_rank(rank, world, port, tmpdir):
+_DDP_KW = {"classification": dict(decoder="classification", num_classes=10), "segmentation": dict(decoder="segmentation", num_classes=17)}
+
+
+def _ddp_model(task):
+    from myrtle_vision.models.vit import ViT
+    return ViT(precision="bf16", q_format="FP32", image_size=224, patch_size=16, dim=128, depth=2, heads=2, mlp_dim=256,
+               dropout=0.0, emb_dropout=0.0, **_DDP_KW[task]).cuda()
+
+
+def _ddp_data(task):
+    g = torch.Generator().manual_seed(5)
+    X = torch.randn(8, 3, 224, 224, generator=g)
+    Y = torch.randint(0, 10, (8,), generator=g) if task == "classification" else torch.randint(0, 17, (8, 224, 224), generator=g)
+    return X, Y
+
+
+def _ddp_loss(task, vit, x, y):
+    from myrtle_vision.hip.functional import cross_entropy
+    if task == "segmentation":
+        return vit.segmentation_loss(x, y)[0]                               # what the segmentation loop runs (engine.py)
+    return cross_entropy(vit(x), y)
+
+
+def _ddp_rank(rank, world, port, tmpdir, task="classification", exchange="fp32"):
     import torch.distributed as dist
     os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)          # both ranks share GPU 0; the exchange is the point
     torch.cuda.set_device(0)
-    from myrtle_vision.hip.functional import cross_entropy
-    from myrtle_vision.models.vit import ViT
     from myrtle_vision.utils.ddp import GradAllReducer, broadcast_parameters
     from myrtle_vision.utils.optim import AdamW, ParamArena
     from myrtle_vision.utils.utils import seed_everything
     seed_everything(100 + rank)                                             # different initial weights: the broadcast must fix it
-    vit = ViT(precision="bf16", q_format="FP32", decoder="classification", image_size=224, patch_size=16, num_classes=10,
-              dim=128, depth=2, heads=2, mlp_dim=256, dropout=0.0, emb_dropout=0.0).cuda()
+    vit = _ddp_model(task)
     arena = ParamArena(vit.named_parameters(), skip=vit.unused_parameter_names())
     opt = AdamW(arena, lr=1e-3, weight_decay=0.05)
-    red = GradAllReducer(arena, bucket_bytes=256 << 10)                     # several buckets
+    red = GradAllReducer(arena, bucket_bytes=256 << 10,                     # several buckets
+                         exchange_dtype=torch.bfloat16 if exchange == "bf16" else torch.float32, measure=True)
     assert len(red.ranges) > 2
     broadcast_parameters(arena)
     opt.grad_scale = red.grad_scale
-    g = torch.Generator().manual_seed(5)
-    X, Y = torch.randn(8, 3, 224, 224, generator=g), torch.randint(0, 10, (8,), generator=g)
+    X, Y = _ddp_data(task)
     x, y = X[rank::world].cuda(), Y[rank::world].cuda()                     # DistributedSampler-style shard
     for step in range(3):
         opt.zero_grad()
-        cross_entropy(vit(x), y).backward()
+        _ddp_loss(task, vit, x, y).backward()
         red.finish()
         if step == 0:
             torch.save({"grad": (arena.flat_grad * red.grad_scale).cpu(), "param": arena.flat_param.cpu()},
                        os.path.join(tmpdir, f"r{rank}.pt"))
         opt.step()
+    exposed = red.exposed_ms()
+    assert exposed is not None and exposed >= 0.0                           # the span events were recorded and are readable
     torch.save(arena.flat_param.cpu(), os.path.join(tmpdir, f"final{rank}.pt"))
     dist.destroy_process_group()
 
 
-def test_ddp_two_ranks_match_single_process(tmp_path):
-    """SURVEY 8e parity check on the HIP path: all-reduced gradients of a rank-sharded batch == the single-process gradient
-    of the concatenated batch (mean loss), and the ranks hold identical parameters after K optimizer steps."""
+@pytest.mark.parametrize("task,exchange", [("classification", "fp32"), ("segmentation", "fp32"), ("classification", "bf16")])
+def test_ddp_two_ranks_match_single_process(tmp_path, task, exchange):
+    """SURVEY 8e parity check on the HIP path, for BOTH training loops (BASELINE configs 3 and 4): all-reduced gradients of a
+    rank-sharded batch == the single-process gradient of the concatenated batch (mean loss), and the ranks hold identical
+    parameters after K optimizer steps.  ``bf16``: the opt-in half-width exchange (utils/ddp.py), same statements at bf16
+    resolution."""
     import torch.multiprocessing as mp
-    from myrtle_vision.hip.functional import cross_entropy
-    from myrtle_vision.models.vit import ViT
     from myrtle_vision.utils.optim import ParamArena
     from myrtle_vision.utils.utils import seed_everything
-    port = 29700 + (os.getpid() % 200)
-    mp.spawn(_ddp_rank, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    port = 29700 + (os.getpid() % 200) + {"classification": 0, "segmentation": 211}[task] + (427 if exchange == "bf16" else 0)
+    mp.spawn(_ddp_rank, args=(2, port, str(tmp_path), task, exchange), nprocs=2, join=True)
     r0, r1 = torch.load(tmp_path / "r0.pt"), torch.load(tmp_path / "r1.pt")
     assert torch.equal(r0["param"], r1["param"]) and torch.equal(r0["grad"], r1["grad"])
     seed_everything(100)                                                    # rank 0's initial weights
-    vit = ViT(precision="bf16", q_format="FP32", decoder="classification", image_size=224, patch_size=16, num_classes=10,
-              dim=128, depth=2, heads=2, mlp_dim=256, dropout=0.0, emb_dropout=0.0).cuda()
+    vit = _ddp_model(task)
     arena = ParamArena(vit.named_parameters(), skip=vit.unused_parameter_names())
     assert torch.equal(arena.flat_param.cpu(), r0["param"])
-    g = torch.Generator().manual_seed(5)
-    X, Y = torch.randn(8, 3, 224, 224, generator=g), torch.randint(0, 10, (8,), generator=g)
-    cross_entropy(vit(X.cuda()), Y.cuda()).backward()
+    X, Y = _ddp_data(task)
+    _ddp_loss(task, vit, X.cuda(), Y.cuda()).backward()
     arena.sync_grads()
     want, got = arena.flat_grad.cpu(), r0["grad"]
     # bf16 activations: the two shards round differently from the concatenated batch; compare at bf16 resolution
-    assert float((want - got).norm() / want.norm()) < 2e-2
+    e = float((want - got).norm() / want.norm())
+    assert e < 2e-2, e
     f0, f1 = torch.load(tmp_path / "final0.pt"), torch.load(tmp_path / "final1.pt")
     assert torch.equal(f0, f1)
 
