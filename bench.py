@@ -360,6 +360,8 @@ def main():
             if args.per_shape:
                 out["per_shape"] = {k: {"launches": v["launches"], "avg_us": round(v["avg_us"], 1), "tflops": round(v["tflops"], 1)}
                                     for k, v in sorted(timer.shape_summary().items())}
+        if os.environ.get("MV_COMMIT"):
+            out["commit"] = os.environ["MV_COMMIT"]              # set by tools/evidence.sh: which tree this line was measured on
         if world == 1 and not args.no_cpu_baseline and args.workload == "cls":
             out["cpu_baseline"] = cpu_baseline()
         print(json.dumps(out))

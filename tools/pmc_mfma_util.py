@@ -11,6 +11,7 @@ was executing -- a per-CLOCK figure: multiply by the clock the kernel actually h
 (which assumes 2.4 GHz).  bench.py reads ``kernels.<family>.mfma_util`` and ``block.mfma_util`` from the resulting file.
 """
 import json
+import os
 import sqlite3
 import sys
 
@@ -41,7 +42,7 @@ def main():
                 f["sq_busy"] += d.get("SQ_BUSY_CYCLES", 0.0)
     out = {"source": "rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE over bench.py "
                      "--steps 2 --warmup 1 --no-cpu-baseline (tools/pmc_mfma_util.py); util = MFMA busy cycles / (GRBM_GUI_ACTIVE/8 "
-                     "x 1024 SIMDs)", "kernels": {}}
+                     "x 1024 SIMDs)", "commit": os.environ.get("MV_COMMIT"), "kernels": {}}
     for k, f in fam.items():
         if f["launches"]:
             out["kernels"][k] = {"launches": f["launches"], "cycles_per_launch": f["cycles"] / f["launches"],

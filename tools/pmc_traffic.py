@@ -10,6 +10,7 @@ FETCH_SIZE and WRITE_SIZE do not fit one pass (TCC counter budget); both are KiB
 is DOUBLED; WRITE_SIZE is exact.  bench.py reads kernels.<family>.hbm_bytes_per_launch from the resulting file.
 """
 import json
+import os
 import sqlite3
 import sys
 
@@ -32,7 +33,7 @@ def main():
     res = {"source": "rocprofv3 --kernel-trace --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) over "
                      "bench.py --steps 2 --warmup 1 --no-cpu-baseline; FETCH_SIZE doubled per the gfx950 correction "
                      "(tools/pmc_traffic.py)",
-           "kernels": {}}
+           "commit": os.environ.get("MV_COMMIT"), "kernels": {}}
     for fam in FAMILIES:
         if fam in fetch and fam in write:
             nf, f = fetch[fam]
