@@ -84,24 +84,38 @@ def test_converted_int8_model_matches_oracle(name, kw, tol):
     assert (got.argmax(1) == want.argmax(1))[safe].all()
 
 
-def test_converted_int8_batch_1024_contains_its_images():
-    """BASELINE config 5's own size (ViT-B/16, batch 1024, forward only): finite logits, and an image's logits do not
-    depend on the batch around it -- the 8 images evaluated alone give the same logits as inside the 1024 (per-tensor
-    quantiser parameters are frozen, integer products are exact; only kernel variants differ between M = 1 576 and
-    201 728 rows)."""
+def test_converted_int8_batch_1024_properties():
+    """BASELINE config 5's own size (ViT-B/16, batch 1024, forward only), through size-independent properties:
+
+    * finite logits, not a constant function;
+    * EXACT batch-permutation equivariance at full size: the 1024 images in another order give bit-identical logits per
+      image (per-tensor quantiser parameters are frozen, every kernel's arithmetic for a row is independent of its
+      position) -- the statement that no image's result depends on its neighbours;
+    * an image evaluated ALONE (M = 1 576 rows: other kernel variants, the module-by-module path) agrees with itself inside
+      the 1024 to the quantisation-noise envelope only: fp32 results that differ in the last bit in front of an 8-bit
+      quantiser flip a code (1/255 of the tensor's range), and twelve blocks of discontinuous quantisers amplify that
+      seed until it saturates at the quantisers' own noise level (measured block by block:
+      profiles/r03_int8_path_divergence.txt -- 4e-9 after the embedding, 3e-5 after block 2, 2.6e-3 after block 11).
+      Bound: the same 3e-2 as against the oracle; class indices equal wherever the top-2 margin exceeds the difference."""
     gen = torch.Generator().manual_seed(11)
     calib = [torch.randn(16, 3, 224, 224, generator=gen) for _ in range(2)]
     vit, cfg, params = _converted(BASE, calib)
     vit.convert()
     vit.eval()
     big = torch.randn(1024, 3, 224, 224, generator=gen).cuda()
+    perm = torch.randperm(1024, generator=gen).cuda()
+    idx = torch.tensor([0, 1, 255, 256, 511, 777, 1022, 1023], device="cuda")
     with torch.no_grad():
         all_ = vit(big).float()
-        idx = torch.tensor([0, 1, 255, 256, 511, 777, 1022, 1023], device="cuda")
+        shuffled = vit(big[perm]).float()
         alone = vit(big[idx]).float()
     assert all_.shape == (1024, 1000) and bool(torch.isfinite(all_).all())
-    d = float((all_[idx] - alone).norm() / alone.norm())
-    report("int8/vit_b batch-1024 vs the same 8 images alone (rel-L2)", d)
-    assert d < 1e-5
-    assert torch.equal(all_[idx].argmax(1), alone.argmax(1))
     assert len(set(all_.argmax(1).tolist())) > 1               # not a constant function
+    assert torch.equal(shuffled, all_[perm])                   # bit-identical, all 1024 images
+    scale = float(alone.abs().max())
+    d = float((all_[idx] - alone).abs().max()) / scale
+    report("int8/vit_b batch-1024 vs the same 8 images alone (max, of max|logit|)", d)
+    assert d < 3e-2
+    top2 = alone.sort(dim=1).values[:, -2:]
+    safe = ((top2[:, 1] - top2[:, 0]) / scale) > 2 * d
+    assert torch.equal(all_[idx].argmax(1)[safe], alone.argmax(1)[safe])

@@ -8,10 +8,17 @@ step; ``lr_scheduler.step(epoch)`` with the 0-based epoch at epoch END), utils/m
 One optimizer step per "epoch" here so that the learning rate CHANGES between the six steps (warm-up over two epochs,
 then the cosine): [warmup_lr, warmup_lr, mid-warm-up, cos(2), cos(3), cos(4)].
 
-Statistic.  Adam divides by sqrt(v): where a gradient element is ~0 the update's SIGN is decided by rounding noise, so a
-handful of the 1.5 M elements move by up to 2 lr per step on either side.  Parameters are therefore compared in relative
-L2 per tensor (VERDICT: <= 1e-5 of the parameter), and the UPDATE p_final - p_initial -- the far stricter statistic --
-relative to its own norm."""
+Statistic.  Adam divides by sqrt(v), so an element's update carries its gradient's RELATIVE error -- rms/|g| times the
+tensor-level error -- and where the exact gradient is ZERO the update is +-lr of pure rounding noise on either side.  The K
+third of every ``to_qkv.bias`` is such a place: softmax is invariant to a constant added to every key's score, so the K bias
+has no gradient at all (measured: 24 % update error on that tensor, 1e-4 on every other).  Per tensor, in relative L2:
+
+* every element of every tensor (the K third of to_qkv.bias aside): |p - p_oracle| <= 1e-5 |p| (VERDICT's bound; measured
+  <= 1.7e-6) and <= 5e-4 of the UPDATE p_final - p_initial, the far stricter statistic (measured <= 1.0e-4);
+* the well-conditioned elements (oracle gradient >= 1e-3 of the tensor's rms gradient at every step: 96-100 % of a tensor):
+  <= 1e-6 of the parameter, <= 2e-4 of the update (measured 2.7e-7 / 4.9e-5);
+* every element, the K bias included: Adam's own bound |p - p_oracle| <= 2 sum(lr).
+The per-tensor table of a run is written to MV_TEST_REPORT (profiles/r03_parity_measured.txt)."""
 import os
 
 import pytest
@@ -27,6 +34,7 @@ from test_vit_parity import report  # noqa: E402
 KW = dict(decoder="classification", image_size=224, patch_size=16, num_classes=45, dim=192, depth=2, heads=3, mlp_dim=768)
 SCHED = dict(base_lr=1e-3, t_initial=8, lr_min=1e-5, warmup_t=2, warmup_lr_init=1e-4)
 STEPS, BATCH, WD = 6, 4, 0.05
+COND = float(os.environ.get("MV_TRAJ_COND", "1e-3"))      # well-conditioned: |g| >= COND * rms(g) at every step
 
 
 def _batch(i):
@@ -38,18 +46,22 @@ def _oracle_trajectory():
     params = {k: torch.nn.Parameter(v.clone()) for k, v in det_state_dict(cfg.param_shapes()).items()}
     opt = reference_adamw(list(params.items()), lr=SCHED["base_lr"], weight_decay=WD)
     lr, losses, lrs = SCHED["warmup_lr_init"], [], []         # timm sets warmup_lr_init at construction
+    cond = {}                                                  # min over steps of |g| / rms(g), per element
     for i in range(STEPS):
         img, labels = _batch(i)
         _, loss, grads = loss_and_grads({k: v.detach() for k, v in params.items()}, img, labels, cfg)
         for k, p in params.items():
             p.grad = grads[k]                                 # None for the two detection-only parameters: AdamW skips them
+            if grads[k] is not None:
+                r = grads[k].abs() / grads[k].pow(2).mean().sqrt().clamp_min(1e-30)
+                cond[k] = r if k not in cond else torch.minimum(cond[k], r)
         for g in opt.param_groups:
             g["lr"] = lr
         opt.step()
         losses.append(float(loss))
         lrs.append(lr)
         lr = cosine_lr(i, **SCHED)                            # lr_scheduler.step(epoch) at epoch end, 0-based (train.py:287)
-    return {k: v.detach() for k, v in params.items()}, losses, lrs
+    return {k: v.detach() for k, v in params.items()}, losses, lrs, {k: v >= COND for k, v in cond.items()}
 
 
 def _hip_objects(precision):
@@ -100,32 +112,46 @@ def _hip_trajectory(precision, tmp_path, resume_at=None):
     return {k: v.detach().float().cpu() for k, v in vit.state_dict().items()}, losses, lrs
 
 
-def _compare(tag, got, want, init):
-    worst_p = worst_u = 0.0
+def _compare(tag, got, want, init, well, lr_sum):
+    """-> worst per-tensor (err/param all, err/update all, err/param conditioned, err/update conditioned)."""
+    worst = [0.0, 0.0, 0.0, 0.0]
+    D = KW["dim"]
     for k, w in want.items():
         if k in ("pos_embedding_det", "det_tokens"):
             assert torch.equal(got[k], init[k])               # never touched by either optimizer
             continue
-        e_p = float((got[k] - w).norm() / w.norm())
-        e_u = float((got[k] - w).norm() / (w - init[k]).norm())
-        worst_p, worst_u = max(worst_p, e_p), max(worst_u, e_u)
-    report(f"trajectory/{tag} parameters rel-L2", worst_p)
-    report(f"trajectory/{tag} update rel-L2", worst_u)
-    return worst_p, worst_u
+        d, u, m = got[k] - w, w - init[k], well[k]
+        assert float(d.abs().max()) <= 2.0 * lr_sum * 1.001, k            # Adam's bound, every element
+        if k.endswith("to_qkv.bias"):                         # drop the K third: its exact gradient is zero
+            keep = torch.ones_like(m)
+            keep[D:2 * D] = False
+            d, u, w, m = d[keep], u[keep], w[keep], m[keep]
+        frac = float(m.float().mean())
+        assert frac > 0.95, (k, frac)
+        e = [float(d.norm() / w.norm()), float(d.norm() / u.norm()), float(d[m].norm() / w[m].norm()), float(d[m].norm() / u[m].norm())]
+        worst = [max(a, b) for a, b in zip(worst, e)]
+        if os.environ.get("MV_TEST_REPORT"):
+            with open(os.environ["MV_TEST_REPORT"], "a") as f:
+                f.write(f"#   trajectory/{tag} {k}: err/param {e[0]:.2e} err/update {e[1]:.2e} | conditioned ({frac:.4f} of the "
+                        f"elements) err/param {e[2]:.2e} err/update {e[3]:.2e}\n")
+    for name, v in zip(("parameters rel-L2", "update rel-L2", "parameters rel-L2 (well-conditioned elements)",
+                        "update rel-L2 (well-conditioned elements)"), worst):
+        report(f"trajectory/{tag} {name}", v)
+    return worst
 
 
 def test_fp32_trajectory_matches_oracle_and_resume_is_bit_exact(tmp_path):
     torch.set_num_threads(8)
-    want, want_losses, want_lrs = _oracle_trajectory()
+    want, want_losses, want_lrs, well = _oracle_trajectory()
     init = det_state_dict(ViTConfig(**KW).param_shapes())
     assert len(set(want_lrs)) >= 4                             # the schedule really changes along the way
     got, losses, lrs = _hip_trajectory("fp32", tmp_path)
     assert lrs == pytest.approx(want_lrs, rel=1e-12)
     for a, b in zip(losses, want_losses):
         assert abs(a - b) < 1e-4 * abs(b)
-    worst_p, worst_u = _compare("fp32 vs oracle", got, want, init)
-    assert worst_p < 1e-5
-    assert worst_u < 2e-2                                      # see the module docstring: near-zero gradient elements under Adam
+    p_all, u_all, p_cond, u_cond = _compare("fp32 vs oracle", got, want, init, well, sum(want_lrs))
+    assert p_all < 1e-5 and u_all < 5e-4
+    assert p_cond < 1e-6 and u_cond < 2e-4
     # save -> reload at step 3 -> continue == uninterrupted, bit for bit (model, optimizer moments, step count, schedule)
     res, res_losses, res_lrs = _hip_trajectory("fp32", tmp_path, resume_at=3)
     assert res_lrs == lrs and res_losses == losses
@@ -134,17 +160,17 @@ def test_fp32_trajectory_matches_oracle_and_resume_is_bit_exact(tmp_path):
 
 
 def test_bf16_trajectory_stays_within_its_drift_bound(tmp_path):
-    """The benchmarked arithmetic over the same six steps: losses within 2e-2, parameters within 1e-3 (relative L2) of the
-    fp32 oracle trajectory -- bf16 gradients are 1e-2 accurate, Adam turns that into a few percent of each update -- and
-    its own resume is bit-exact."""
+    """The benchmarked arithmetic over the same six steps: losses within 2e-2, parameters within 1.5e-3 (relative L2 per
+    tensor) of the fp32 oracle trajectory, updates within 5 % -- bf16 gradients are 1e-2 accurate as tensors -- and its own
+    resume is bit-exact."""
     torch.set_num_threads(8)
-    want, want_losses, _ = _oracle_trajectory()
+    want, want_losses, want_lrs, well = _oracle_trajectory()
     init = det_state_dict(ViTConfig(**KW).param_shapes())
     got, losses, lrs = _hip_trajectory("bf16", tmp_path)
     for a, b in zip(losses, want_losses):
         assert abs(a - b) < 2e-2 * abs(b)
-    worst_p, worst_u = _compare("bf16 vs oracle", got, want, init)
-    assert worst_p < 1e-3 and worst_u < 0.25
+    p_all, u_all, p_cond, u_cond = _compare("bf16 vs oracle", got, want, init, well, sum(want_lrs))
+    assert p_all < 1.5e-3 and u_all < 5e-2                     # measured 5.0e-4 / 2.2e-2
     res, res_losses, _ = _hip_trajectory("bf16", tmp_path, resume_at=3)
     assert res_losses == losses
     for k in got:
