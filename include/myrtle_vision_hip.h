@@ -141,6 +141,10 @@ int mv_attention_bwd(const void* qkv, const void* out, const void* dout, const f
  * barrier-free passes (N <= 288), 8 = the eight-wave kernel (N <= 320).  A variant that cannot take the length falls back
  * to auto. */
 int mv_attention_bwd_force(int variant);
+/* The same for mv_attention_fwd: 0 auto (N <= 208: 3, else 1), 3 = 13 key tiles in 53 KB of LDS, three workgroups per CU (N <= 208),
+ * 1 = one 16-query tile per wave and pass, 2 = a PAIR of query
+ * tiles per wave and pass (every K / V^T fragment read from LDS feeds two MFMAs; N <= 224, else falls back to 1). */
+int mv_attention_fwd_force(int variant);
 /* The same attention core in EXACT fp32 arithmetic on the f32-input matrix cores, forward only: qkv fp32 [B, N, 3, H, 64],
  * out fp32 [B, N, H*64]; N <= 272.  For the paths that need fp32 values and no gradient (converted PyTorchINT8 model,
  * precision="fp32" evaluation): same products and sums as mv_gemm_f32 + mv_softmax_fwd + mv_gemm_f32 up to summation order,

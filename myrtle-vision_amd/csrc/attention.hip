@@ -226,6 +226,283 @@ __global__ __launch_bounds__(256, (NKT <= 18 ? 2 : 1)) void attn_fwd_kernel(cons
   }
 }
 
+// ------------------------------------------------------------------------------------------------
+// forward, two 16-query tiles per wave and pass: every K row fragment and every V^T fragment read from LDS feeds TWO MFMAs
+// ------------------------------------------------------------------------------------------------
+// attn_fwd_kernel reads one 1 KB fragment from LDS per MFMA.  The LDS delivers 128 B/clk per CU, i.e. a quarter of that per
+// SIMD when all four read: 32 cycles per fragment against the 16 cycles its MFMA takes -- by phase ablation the S and P.V
+// phases (61 of 101 us) ran at the fragment rate, not the matrix rate.  Here a wave owns a PAIR of query tiles: the same
+// four K fragments of a key-tile pair feed eight MFMAs, the same V^T fragment two, so the fragment traffic per FLOP is
+// halved (the effect of a 32 x 32 x 16 tile, with the fragment maps of the 16 x 16 x 32 one); 13 query tiles = 7 pairs over
+// 4 waves (2, 2, 2, 1: 87 % balanced against 81 % for 4, 3, 3, 3 single tiles).  Scores of both tiles stay in registers
+// (2 x NKT x 4 fp32), so this form is for NKT <= 14 (N <= 224); longer sequences keep attn_fwd_kernel.
+template <int NKT>
+__global__ __launch_bounds__(256, 2) void attn_fwd2_kernel(const bf16_t* __restrict__ qkv, bf16_t* __restrict__ out,
+                                                           float* __restrict__ lse, int N, int H, float scale_log2e) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  constexpr int NP = NKT * 16;
+  char* sK = smem;
+  char* sV = smem + NP * 128;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 4;
+  const LaneOff L = make_lane_off(lane);
+  const int b = blockIdx.x / H, h = blockIdx.x % H;
+  const long D = (long)H * 64;
+  const bf16_t* base = qkv + (long)b * N * 3 * D + h * 64;
+  stage_kv_dma(base, D, N, sK, NP, sV, NP, wave, 4, lane);
+  const int nqt = (N + 15) >> 4, npair = (nqt + 1) >> 1;
+  auto load_q = [&](int qt, int ks) -> u32x4 {           // rows >= N (and the odd tile of the last pair) clamped: never stored
+    const int qrow = qt * 16 + (lane & 15);
+    return *reinterpret_cast<const u32x4*>(base + (long)(qrow < N ? qrow : N - 1) * 3 * D + 32 * ks + 8 * g);
+  };
+  const int qp0 = wave < npair ? wave : 0;
+  u32x4 qn[2][2] = {{load_q(2 * qp0, 0), load_q(2 * qp0, 1)}, {load_q(2 * qp0 + 1, 0), load_q(2 * qp0 + 1, 1)}};
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // this wave's K/V DMA pieces (and its first Q pair) have landed
+  __syncthreads();
+
+  for (int qp = wave; qp < npair; qp += 4) {
+    bf16x8 qf[2][2];
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+      qf[t][0] = __builtin_bit_cast(bf16x8, qn[t][0]);
+      qf[t][1] = __builtin_bit_cast(bf16x8, qn[t][1]);
+    }
+    if (qp + 4 < npair) {
+#pragma unroll
+      for (int t = 0; t < 2; ++t) {
+        qn[t][0] = load_q(2 * (qp + 4) + t, 0);
+        qn[t][1] = load_q(2 * (qp + 4) + t, 1);
+      }
+    }
+    f32x4 st[2][NKT];
+    float mx[2] = {-INFINITY, -INFINITY};
+#pragma unroll
+    for (int kp = 0; kp < NKT; kp += 2) {
+      const bf16x8 ka0 = row_frag128(sK, kp * 16, L.rf[0]), kb0 = row_frag128(sK, (kp + 1) * 16, L.rf[0]);
+      const bf16x8 ka1 = row_frag128(sK, kp * 16, L.rf[1]), kb1 = row_frag128(sK, (kp + 1) * 16, L.rf[1]);
+      f32x4 acc[2][2];
+#pragma unroll
+      for (int t = 0; t < 2; ++t) acc[t][0] = acc[t][1] = (f32x4){0.f, 0.f, 0.f, 0.f};
+      // four independent two-step chains (query tile t x key tile a | b), interleaved
+#pragma unroll
+      for (int t = 0; t < 2; ++t) {
+        acc[t][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ka0, qf[t][0], acc[t][0], 0, 0, 0);
+        acc[t][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kb0, qf[t][0], acc[t][1], 0, 0, 0);
+      }
+#pragma unroll
+      for (int t = 0; t < 2; ++t) {
+        acc[t][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ka1, qf[t][1], acc[t][0], 0, 0, 0);
+        acc[t][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kb1, qf[t][1], acc[t][1], 0, 0, 0);
+      }
+#pragma unroll
+      for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const int key = (kp + kk) * 16 + 4 * g + r;
+            const float v = key < N ? acc[t][kk][r] * scale_log2e : -INFINITY;
+            acc[t][kk][r] = v;
+            mx[t] = fmaxf(mx[t], v);
+          }
+          st[t][kp + kk] = acc[t][kk];
+        }
+      __builtin_amdgcn_sched_barrier(0);               // keep the K reads of later key tiles below these MFMAs (as attn_fwd_kernel)
+    }
+    float sum[2];
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+      mx[t] = fmaxf(mx[t], __shfl_xor(mx[t], 16, 64));
+      mx[t] = fmaxf(mx[t], __shfl_xor(mx[t], 32, 64));
+      float sm = 0.f;
+#pragma unroll
+      for (int kt = 0; kt < NKT; ++kt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const float p = __builtin_amdgcn_exp2f(st[t][kt][r] - mx[t]);
+          st[t][kt][r] = p;
+          sm += p;
+        }
+      sm += __shfl_xor(sm, 16, 64);
+      sm += __shfl_xor(sm, 32, 64);
+      sum[t] = sm;
+    }
+    f32x4 o[2][4];
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+      for (int dt = 0; dt < 4; ++dt) o[t][dt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int u = 0; u < NKT / 2; ++u) {
+      const bf16x8 pf0 = pack8(st[0][2 * u], st[0][2 * u + 1]), pf1 = pack8(st[1][2 * u], st[1][2 * u + 1]);
+#pragma unroll
+      for (int dt = 0; dt < 4; ++dt) {
+        const bf16x8 vf = tr_frag128(sV, 32 * u, L.tr[dt]);
+        o[0][dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf, pf0, o[0][dt], 0, 0, 0);
+        o[1][dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf, pf1, o[1][dt], 0, 0, 0);
+      }
+    }
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+      const int qrow = (2 * qp + t) * 16 + (lane & 15);
+      const float inv = 1.0f / sum[t];
+#pragma unroll
+      for (int dt = 0; dt < 4; ++dt) o[t][dt] *= inv;
+      const u32x4 w0 = pair16(o[t][0], o[t][1]), w1 = pair16(o[t][2], o[t][3]);     // executed by every lane (lane exchange)
+      if (qrow < N) {
+        bf16_t* orow = out + ((long)b * N + qrow) * D + h * 64;
+        *reinterpret_cast<u32x4*>(orow + pair16_off(0, g)) = w0;
+        *reinterpret_cast<u32x4*>(orow + pair16_off(2, g)) = w1;
+        if (g == 0) lse[((long)b * H + h) * N + qrow] = (mx[t] + __builtin_amdgcn_logf(sum[t])) * LN2;
+      }
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// forward, N <= 208: K and V in 2 x 208 rows = 53 248 B of LDS, THREE workgroups per CU
+// ------------------------------------------------------------------------------------------------
+// attn_fwd_kernel<14> rounds 197 keys up to 14 tiles (the P.V product walks key-tile PAIRS) = 57 344 B, and 160 KB of LDS then
+// hold two workgroups per CU; its 125 VGPRs would allow four.  The kernel's time is load + compute + store per workgroup with
+// little overlap inside one (phase ablation: 52 us of memory phases + 61 us of latency-bound compute against 96 us in all), so
+// what hides one workgroup's loads is ANOTHER workgroup's compute: residency is the lever.  Here the S phase walks the 13 real
+// key tiles (six pairs + one), V sits FIRST in LDS and K behind it: the P.V product's last pair reads "V rows 208..223" out of
+// K's first 16 rows -- finite values times p = 0 exactly (keys >= N are masked to -inf before the exponential), the same
+// argument as the clamped padding rows.  3 072 workgroups then take 4 rounds of 768 instead of 6 of 512.
+__global__ __launch_bounds__(256, 3) void attn_fwd13_kernel(const bf16_t* __restrict__ qkv, bf16_t* __restrict__ out,
+                                                            float* __restrict__ lse, int N, int H, float scale_log2e) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  constexpr int NKS = 13, NP = NKS * 16;
+  char* sV = smem;
+  char* sK = smem + NP * 128;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 4;
+  const LaneOff L = make_lane_off(lane);
+  const int b = blockIdx.x / H, h = blockIdx.x % H;
+  const long D = (long)H * 64;
+  const bf16_t* base = qkv + (long)b * N * 3 * D + h * 64;
+  // K first, then this wave's first Q tile, then V: the first S phase needs K and Q only, so V (25 KB) is still in flight
+  // under it.  Every wave issues exactly 7 pieces of each (26 pieces of 8 rows over 4 waves: the last two waves repeat piece
+  // 25 -- the same bytes to the same place), so one counted wait serves all waves.
+  const int prow = lane >> 3, pch = lane & 7;
+#pragma unroll
+  for (int i = 0; i < 7; ++i) {
+    const int pc = (wave + 4 * i) < NP / 8 ? (wave + 4 * i) : NP / 8 - 1;
+    const int row = 8 * pc + prow;
+    const long rr = row < N ? row : N - 1;
+    glds16(base + rr * 3 * D + D + (pch ^ (((row >> 1) & 3) << 1)) * 8, sK + pc * 1024);
+  }
+  const int nqt = (N + 15) >> 4;
+  auto load_q = [&](int qt, int ks) -> u32x4 {
+    const int qrow = qt * 16 + (lane & 15);
+    return *reinterpret_cast<const u32x4*>(base + (long)(qrow < N ? qrow : N - 1) * 3 * D + 32 * ks + 8 * g);
+  };
+  // the first Q tile through inline asm: a load hipcc can see would be waited for with vmcnt(0) while LDS-DMA is in flight
+  // (cdna guide 5, "three .s-level traps" (b)), draining the V pieces this order exists to keep flying
+  u32x4 qn0, qn1;
+  {
+    const int q0 = (wave < nqt ? wave : 0) * 16 + (lane & 15);
+    const bf16_t* qp = base + (long)(q0 < N ? q0 : N - 1) * 3 * D + 8 * g;
+    asm volatile("global_load_dwordx4 %0, %2, off\n\tglobal_load_dwordx4 %1, %2, off offset:64"
+                 : "=&v"(qn0), "=&v"(qn1) : "v"(qp) : "memory");
+  }
+#pragma unroll
+  for (int i = 0; i < 7; ++i) {
+    const int pc = (wave + 4 * i) < NP / 8 ? (wave + 4 * i) : NP / 8 - 1;
+    const int row = 8 * pc + prow;
+    const long rr = row < N ? row : N - 1;
+    glds16(base + rr * 3 * D + 2 * D + (pch ^ (((row >> 1) & 3) << 1)) * 8, sV + pc * 1024);
+  }
+  asm volatile("s_waitcnt vmcnt(7)" : "+v"(qn0), "+v"(qn1) : : "memory");     // K and Q landed; the 7 V pieces may still fly
+  __builtin_amdgcn_s_barrier();                        // raw: __syncthreads() would fence with vmcnt(0) and drain them
+  asm volatile("" ::: "memory");
+  bool v_ready = false;
+
+  for (int qt = wave; qt < nqt; qt += 4) {
+    const int qrow = qt * 16 + (lane & 15);
+    bf16x8 qf[2];
+    qf[0] = __builtin_bit_cast(bf16x8, qn0);
+    qf[1] = __builtin_bit_cast(bf16x8, qn1);
+    if (qt + 4 < nqt) {
+      qn0 = load_q(qt + 4, 0);
+      qn1 = load_q(qt + 4, 1);
+    }
+    f32x4 st[NKS + 1];
+    float mx = -INFINITY;
+#pragma unroll
+    for (int kp = 0; kp < NKS; kp += 2) {
+      const bool two = kp + 1 < NKS;                   // compile-time after unrolling
+      f32x4 acc[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+      const bf16x8 ka0 = row_frag128(sK, kp * 16, L.rf[0]), ka1 = row_frag128(sK, kp * 16, L.rf[1]);
+      if (two) {
+        const bf16x8 kb0 = row_frag128(sK, (kp + 1) * 16, L.rf[0]), kb1 = row_frag128(sK, (kp + 1) * 16, L.rf[1]);
+        acc[0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ka0, qf[0], acc[0], 0, 0, 0);
+        acc[1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kb0, qf[0], acc[1], 0, 0, 0);
+        acc[0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ka1, qf[1], acc[0], 0, 0, 0);
+        acc[1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kb1, qf[1], acc[1], 0, 0, 0);
+      } else {
+        acc[0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ka0, qf[0], acc[0], 0, 0, 0);
+        acc[0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ka1, qf[1], acc[0], 0, 0, 0);
+      }
+#pragma unroll
+      for (int t = 0; t < 2; ++t) {
+        if (t == 1 && !two) break;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int key = (kp + t) * 16 + 4 * g + r;
+          const float v = key < N ? acc[t][r] * scale_log2e : -INFINITY;
+          acc[t][r] = v;
+          mx = fmaxf(mx, v);
+        }
+        st[kp + t] = acc[t];
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+    float sum = 0.f;
+#pragma unroll
+    for (int kt = 0; kt < NKS; ++kt)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const float p = __builtin_amdgcn_exp2f(st[kt][r] - mx);
+        st[kt][r] = p;
+        sum += p;
+      }
+    st[NKS] = (f32x4){0.f, 0.f, 0.f, 0.f};             // the partner of key tile 12 in the last P.V pair: p = 0 for keys 208..223
+    sum += __shfl_xor(sum, 16, 64);
+    sum += __shfl_xor(sum, 32, 64);
+
+    if (!v_ready) {                                    // first pass only (wave-uniform): V must have landed in every wave
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();
+      v_ready = true;
+    }
+    f32x4 o[4];
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt) o[dt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int u = 0; u < (NKS + 1) / 2; ++u) {
+      const bf16x8 pf = pack8(st[2 * u], st[2 * u + 1]);
+#pragma unroll
+      for (int dt = 0; dt < 4; ++dt)
+        o[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(tr_frag128(sV, 32 * u, L.tr[dt]), pf, o[dt], 0, 0, 0);
+    }
+    const float inv = 1.0f / sum;
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt) o[dt] *= inv;
+    const u32x4 w0 = pair16(o[0], o[1]), w1 = pair16(o[2], o[3]);
+    if (qrow < N) {
+      bf16_t* orow = out + ((long)b * N + qrow) * D + h * 64;
+      *reinterpret_cast<u32x4*>(orow + pair16_off(0, g)) = w0;
+      *reinterpret_cast<u32x4*>(orow + pair16_off(2, g)) = w1;
+      if (g == 0) lse[((long)b * H + h) * N + qrow] = (mx + __builtin_amdgcn_logf(sum)) * LN2;
+    }
+  }
+  if (!v_ready) {                                      // a wave without a query tile (N < 64) still owes the workgroup its barrier
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+  }
+}
+
 // Column sums of dQ / dK / dV of one (image, head) = that head's slice of the to_qkv bias gradient for this image: the
 // wave-local sums (16 lanes with equal lane>>4 hold the 16 rows of a tile) go through LDS, and 192 threads write
 // colsum[b][which][h][d].  Deterministic: fixed shuffle tree, waves added in order.  Padded rows contribute exact zeros
@@ -995,6 +1272,12 @@ constexpr int bwd_smem(int nkt) { return nkt * 16 * 128 * 2 + 2 * 8192 + 2 * nkt
 
 namespace {
 std::atomic<int> g_bwd_variant{0};
+std::atomic<int> g_fwd_variant{getenv("MV_ATTN_FWD") ? atoi(getenv("MV_ATTN_FWD")) : 0};   // 0 auto | 1 one query tile per wave pass | 2 pairs
+}
+extern "C" int mv_attention_fwd_force(int variant) {
+  if (variant != 0 && variant != 1 && variant != 2 && variant != 3) return MV_ERR_UNSUPPORTED;
+  g_fwd_variant.store(variant, std::memory_order_relaxed);
+  return MV_OK;
 }
 extern "C" int mv_attention_bwd_force(int variant) {
   if (variant != 0 && variant != 2 && variant != 4 && variant != 8) return MV_ERR_UNSUPPORTED;
@@ -1009,7 +1292,17 @@ extern "C" int mv_attention_fwd(const void* qkv, void* out, float* lse, int B, i
   if (B == 0) return MV_OK;
   hipStream_t s = (hipStream_t)stream;
   const float sl = scale * LOG2E;
-  if (N <= 224) {
+  const int fv = g_fwd_variant.load(std::memory_order_relaxed);
+  if (N <= 208 && (fv == 3 || fv == 0)) {    // 13 key tiles, 53 248 B: three workgroups per CU
+    constexpr int smem13 = 2 * 13 * 16 * 128;
+    static const int a = set_smem(attn_fwd13_kernel, smem13);
+    if (a) return MV_ERR_LAUNCH;
+    attn_fwd13_kernel<<<B * H, 256, smem13, s>>>((const bf16_t*)qkv, (bf16_t*)out, lse, N, H, sl);
+  } else if (N <= 224 && fv == 2) {          // query-tile pairs per wave: half the LDS fragment traffic per FLOP
+    static const int a = set_smem(attn_fwd2_kernel<14>, fwd_smem(14));
+    if (a) return MV_ERR_LAUNCH;
+    attn_fwd2_kernel<14><<<B * H, 256, fwd_smem(14), s>>>((const bf16_t*)qkv, (bf16_t*)out, lse, N, H, sl);
+  } else if (N <= 224) {
     static const int a = set_smem(attn_fwd_kernel<14>, fwd_smem(14));
     if (a) return MV_ERR_LAUNCH;
     attn_fwd_kernel<14><<<B * H, 256, fwd_smem(14), s>>>((const bf16_t*)qkv, (bf16_t*)out, lse, N, H, sl);

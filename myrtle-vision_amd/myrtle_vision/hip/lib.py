@@ -39,6 +39,7 @@ SIGNATURES = {
     "mv_gemm_tn_bf16": ("pipipi" "iii" "i" "p" "pz" "p", _I),
     "mv_gemm_f32": ("pllll" "pllll" "pllll" "iii" "ii" "fi" "pi" "pli" "pl" "p", _I),
     "mv_attention_bwd_force": ("i", _I),
+    "mv_attention_fwd_force": ("i", _I),
     "mv_attention_fwd_f32_lse": ("ppp" "iii" "f" "p", _I),
     "mv_attention_bwd_f32": ("ppppp" "iii" "f" "p", _I),
     "mv_gemm_f32_force_fma": ("i", _I),

@@ -514,6 +514,18 @@ def test_attention_fused_fwd_bwd(ops, B, N, H):
     q, k, _ = qkv.double().view(B, N, 3, H, 64).permute(2, 0, 3, 1, 4)
     lse_ref = torch.logsumexp((q @ k.transpose(-2, -1)) * scale, dim=-1)
     assert float((lse.cpu().double() - lse_ref).abs().max()) < 1e-4
+    # every forward kernel (auto picked one): one query tile per wave pass, query-tile PAIRS sharing every K / V^T fragment
+    # (N <= 224), and the 13-key-tile form with three workgroups per CU (N <= 208) -- the same MFMA sequence per query row
+    # in all three, so the same bits (a variant that cannot take the length falls back)
+    from myrtle_vision.hip.lib import lib
+    for variant in (1, 2, 3):
+        lib().mv_attention_fwd_force(variant)
+        try:
+            out_v, lse_v = ops.attention_fwd(qkv.cuda(), B, N, H, scale)
+        finally:
+            lib().mv_attention_fwd_force(0)
+        assert relerr(out_v.float(), want) < 1.5e-2, variant
+        assert torch.equal(out_v, out) and torch.equal(lse_v, lse), variant
     part = torch.full((B, 3 * H * 64), float("nan"), device="cuda")
     dqkv = ops.attention_bwd(qkv.cuda(), out, dout.cuda(), lse, B, N, H, scale, colsum=part)
     got, ref = dqkv.float().cpu().view(B, N, 3, H, 64), ref_in.grad.view(B, N, 3, H, 64)

@@ -20,6 +20,20 @@ if os.environ.get("ATTN_BWD"):                      # 2 two-pass | 4 dS-through-
     from myrtle_vision.hip.lib import lib
     lib().mv_attention_bwd_force(int(os.environ["ATTN_BWD"]))
 out, lse = ops.attention_fwd(qkv, B, N, H, 0.125)
+if os.environ.get("FWD_AB"):                        # forward variants 1 (one query tile per wave pass) and 2 (pairs), alternating
+    from myrtle_vision.hip.lib import lib
+    best = {1: 1e9, 2: 1e9, 3: 1e9}
+    outs = {}
+    for _ in range(4):
+        for v in (1, 2, 3):
+            lib().mv_attention_fwd_force(v)
+            best[v] = min(best[v], timeit(lambda: ops.attention_fwd(qkv, B, N, H, 0.125)))
+            outs[v] = ops.attention_fwd(qkv, B, N, H, 0.125)
+    lib().mv_attention_fwd_force(0)
+    d = float((outs[1][0].float() - outs[2][0].float()).abs().max())
+    d3 = float((outs[1][0].float() - outs[3][0].float()).abs().max())
+    print(f"attention fwd variants: single tile {best[1]:7.1f} us | tile pairs {best[2]:7.1f} us | 13 tiles, 3 WG/CU {best[3]:7.1f} us | "
+          f"max |o1 - o2| {d:.3e} |o1 - o3| {d3:.3e}  lse equal {bool(torch.equal(outs[1][1], outs[2][1]))} {bool(torch.equal(outs[1][1], outs[3][1]))}")
 tf = timeit(lambda: ops.attention_fwd(qkv, B, N, H, 0.125))
 tb = timeit(lambda: ops.attention_bwd(qkv, out, dout, lse, B, N, H, 0.125))
 fl_f, fl_b = 4.0 * B * H * N * N * 64, 10.0 * B * H * N * N * 64
