@@ -184,6 +184,9 @@ def main():
     ap.add_argument("--timer-every", type=int, default=4,
                     help="bracket the GEMM launches with events on every k-th timed step only (event packets between "
                          "kernels cost ~3 %% of the step when every launch of every step is timed)")
+    ap.add_argument("--graph", action="store_true",
+                    help="capture the training step in ONE HIP graph and replay it (utils/graph.py): single GPU, static shapes; "
+                         "the event timer is off in this mode, so the line carries no per-kernel roofline section")
     ap.add_argument("--dry-run", action="store_true",
                     help="no compute: only the multi-process launch, rendezvous, barriers and the JSON line (CPU test)")
     args = ap.parse_args()
@@ -275,6 +278,17 @@ def main():
                 opt.step()
             return loss
 
+    if args.graph:
+        if args.workload == "infer-int8" or args.no_optimizer or world > 1 or force_dist:
+            raise SystemExit("--graph: single-GPU training workloads with the optimizer step")
+        from myrtle_vision.utils.graph import GraphedTrainStep
+        seg_fused = args.workload in ("seg", "seg256") and not args.seg_unfused
+        loss_fn = (lambda m, x, y: m.segmentation_loss(x, y)[0]) if seg_fused else (lambda m, x, y: cross_entropy(m(x), y))
+        graphed = GraphedTrainStep(vit, opt, loss_fn, img, labels)
+
+        def step():                                          # noqa: F811  (replaces the eager step)
+            return graphed(img, labels)
+        args.no_kernel_timer = True
     for _ in range(args.warmup):
         loss = step()
     timer = None if args.no_kernel_timer else ops.KernelTimer(sample_every=args.timer_every)
@@ -318,6 +332,7 @@ def main():
             "config": {"workload": WORKLOAD[args.workload] + ("" if not args.no_optimizer else " [optimizer step OFF]")
                        + (f" [q_format {args.q_format}]" if args.q_format else "")
                        + (" [attention core: fused bf16 kernel]" if args.int8_bf16_attention else ""),
+                       "step_launch": "one HIP graph replay per step" if args.graph else "eager (one launch per kernel)",
                        "per_gpu_batch": args.batch, "global_batch": args.batch * world,
                        "parallelism": f"dp{world}", "final_loss": round(final_loss, 4)},
         }

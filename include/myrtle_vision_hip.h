@@ -345,6 +345,11 @@ int mv_mask_resize_u8(const uint8_t* src, long img_stride, int Hs, int Ws, const
 int mv_adamw(float* p, const float* g, float* m, float* v, long n, float lr, float beta1, float beta2, float eps,
              float weight_decay, float bias_corr1, float bias_corr2, float grad_scale, const float* clip_coef,
              mv_stream_t stream);
+/* the same step with the scalars that change from step to step read from DEVICE memory: hyper = fp32 [3] = (lr, bias_corr1,
+ * bias_corr2).  A launch captured in a HIP graph (the whole training step of classification/train.py:239-279 replayed as one
+ * graph) then stays valid while the learning-rate schedule and the step count advance: the host rewrites three floats. */
+int mv_adamw_dev(float* p, const float* g, float* m, float* v, long n, const float* hyper, float beta1, float beta2, float eps,
+                 float weight_decay, float grad_scale, const float* clip_coef, mv_stream_t stream);
 /* ---- gradient clipping: torch.nn.utils.clip_grad_norm_(vit.parameters(), clip_grad), classification/train.py:265-270 ----
  * over the flat gradient array g[n]: out[0] = total_norm = ||g * grad_scale||_2, out[1] = min(1, max_norm / (total_norm + 1e-6)).
  * out stays on the device; pass out + 1 as mv_adamw's clip_coef (it multiplies every gradient there: no extra pass).

@@ -718,7 +718,12 @@ __global__ __launch_bounds__(256) void dropout_kernel(const T* __restrict__ x, T
 // ---- AdamW (torch.optim.AdamW semantics): p *= 1 - lr*wd; m,v update; p -= lr/bc1 * m / (sqrt(v)/sqrt(bc2) + eps)
 __global__ void adamw_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
                              float* __restrict__ v, long n, float lr, float b1, float b2, float eps, float wd, float bc1,
-                             float bc2, float gscale, const float* __restrict__ clip_coef) {
+                             float bc2, float gscale, const float* __restrict__ clip_coef, const float* __restrict__ hyper) {
+  if (hyper) {                                // mv_adamw_dev: the per-step scalars live on the device (captured launches stay valid)
+    lr = hyper[0];
+    bc1 = hyper[1];
+    bc2 = hyper[2];
+  }
   if (clip_coef) gscale *= clip_coef[0];      // clip_grad_norm_'s min(1, max_norm / (norm + 1e-6)), computed on the device
   const float step = lr / bc1, inv_sqrt_bc2 = rsqrtf(bc2);
   const long n4 = n >> 2;
@@ -1158,7 +1163,10 @@ extern "C" int mv_cross_entropy(const float* logits, const int64_t* labels, floa
   MV_REQUIRE(outer >= 0 && C > 0 && inner >= 1, MV_ERR_SHAPE);
   MV_REQUIRE(!dlogits || dl_dtype == MV_F32 || dl_dtype == MV_BF16, MV_ERR_UNSUPPORTED);
   MV_REQUIRE(!dlogits || inner > 1 || ld_dl >= C, MV_ERR_SHAPE);
-  if (hipMemsetAsync(loss_sum, 0, 4 * sizeof(float), S_) != hipSuccess) return MV_ERR_LAUNCH;
+  // zeroed by a KERNEL, not hipMemsetAsync: captured into a HIP graph (utils/graph.py) the memset node of ROCm 7.2 did not
+  // stay ordered in front of the kernels behind it from the second replay on (stat[2..3] garbage, the loss off or NaN while
+  // every gradient stayed right: tools/diag/graph_ce_only.py)
+  mv_zero_f32_kernel<<<1, 64, 0, S_>>>(loss_sum, 4);
   const long total = outer * inner;
   if (total == 0) return MV_OK;
   ce_label_scan_kernel<<<ew_grid(total), 256, 0, S_>>>(labels, total, C, loss_sum);
@@ -1210,7 +1218,18 @@ extern "C" int mv_adamw(float* p, const float* g, float* m, float* v, long n, fl
   if (n == 0) return MV_OK;
   MV_REQUIRE(mv_aligned16(p) && mv_aligned16(g) && mv_aligned16(m) && mv_aligned16(v), MV_ERR_ALIGN);
   adamw_kernel<<<ew_grid((n + 3) / 4), 256, 0, S_>>>(p, g, m, v, n, lr, beta1, beta2, eps, weight_decay, bias_corr1,
-                                                     bias_corr2, grad_scale, clip_coef);
+                                                     bias_corr2, grad_scale, clip_coef, nullptr);
+  MV_CHECK_LAUNCH();
+  return MV_OK;
+}
+
+extern "C" int mv_adamw_dev(float* p, const float* g, float* m, float* v, long n, const float* hyper, float beta1, float beta2,
+                            float eps, float weight_decay, float grad_scale, const float* clip_coef, mv_stream_t stream) {
+  MV_REQUIRE(n >= 0 && hyper != nullptr, MV_ERR_SHAPE);
+  if (n == 0) return MV_OK;
+  MV_REQUIRE(mv_aligned16(p) && mv_aligned16(g) && mv_aligned16(m) && mv_aligned16(v), MV_ERR_ALIGN);
+  adamw_kernel<<<ew_grid((n + 3) / 4), 256, 0, S_>>>(p, g, m, v, n, 0.f, beta1, beta2, eps, weight_decay, 1.f, 1.f, grad_scale,
+                                                     clip_coef, hyper);
   MV_CHECK_LAUNCH();
   return MV_OK;
 }

@@ -116,6 +116,11 @@ __device__ __forceinline__ void glds16_hidden(const void* gsrc, void* lds_wave_b
                : "memory");
 }
 
+// n floats <- 0 (tiny accumulators in front of atomics; a kernel rather than hipMemsetAsync: see mv_cross_entropy)
+static __global__ void mv_zero_f32_kernel(float* __restrict__ p, int n) {
+  for (int i = threadIdx.x; i < n; i += blockDim.x) p[i] = 0.f;
+}
+
 // out[c] (+)= sum over rows r of partial[r * ld + c]: the second stage of the deterministic two-stage reductions
 // (LayerNorm dgamma/dbeta/dx column sums, bias-gradient column sums).  One 1024-thread block per 16 columns (so even
 // a 768-column reduction spreads over 48+ CUs): lane l takes column l&15 and row phase l>>4 of its wave, the 64 row

@@ -224,7 +224,7 @@ extern "C" int mv_seg_ce_fwd(const float* small, const int64_t* labels, float* l
   MV_REQUIRE(lds <= SEG_LDS_LIMIT, MV_ERR_UNSUPPORTED);
   MV_REQUIRE(B <= 65535, MV_ERR_SHAPE);
   if (B == 0) {
-    if (hipMemsetAsync(stats, 0, 4 * sizeof(float), S_) != hipSuccess) return MV_ERR_LAUNCH;
+    mv_zero_f32_kernel<<<1, 64, 0, S_>>>(stats, 4);          // a kernel, not hipMemsetAsync: graph-capture safe (mv_cross_entropy)
     return MV_OK;
   }
   const int bpi = (int)(((long)H * W + SEG_PX_PER_BLOCK - 1) / SEG_PX_PER_BLOCK);

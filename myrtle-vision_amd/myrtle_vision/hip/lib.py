@@ -82,6 +82,7 @@ SIGNATURES = {
     "mv_image_resize_u8": ("plii" "pppp" "i" "p" "iii" "p", _I),
     "mv_mask_resize_u8": ("plii" "pp" "p" "iii" "p", _I),
     "mv_adamw": ("pppp" "l" "ffffffff" "p" "p", _I),
+    "mv_adamw_dev": ("pppp" "l" "p" "fffff" "p" "p", _I),
     "mv_grad_norm_workspace_bytes": ("", _Z),
     "mv_grad_norm_clip": ("pl" "ff" "p" "pz" "p", _I),
     "mv_dropout": ("ppi" "l" "f" "QQ" "p", _I),

@@ -169,13 +169,44 @@ class PreparedWeight:
     """bf16 copies of one nn.Linear weight [N_out, K_in]: ``w`` [N_out, pad8(K_in)] for the forward product and
     ``wt`` [K_in, pad8(N_out)] (transposed) for the input-gradient product; pads are zero."""
 
-    __slots__ = ("w", "wt", "ldw", "ldt", "n_out", "k_in", "version", "ptr", "ref")
+    __slots__ = ("w", "wt", "ldw", "ldt", "n_out", "k_in", "version", "ptr", "ref", "epoch")
 
 
 class _WeightPrepItem(ctypes.Structure):          # mv_weight_prep_item (include/myrtle_vision_hip.h)
     _fields_ = [("w", ctypes.c_void_p), ("w_bf16", ctypes.c_void_p), ("wt_bf16", ctypes.c_void_p), ("ldw", ctypes.c_int),
                 ("ldt", ctypes.c_int), ("R", ctypes.c_int), ("C", ctypes.c_int), ("tiles_x", ctypes.c_int),
                 ("first_block", ctypes.c_int)]
+
+
+# Cache epoch: the prepared copies of a weight are valid while (its _version, the epoch) are unchanged.  The epoch moves when
+# (a) ``invalidate_weight_caches()`` is called -- ParamArena.bump_versions() after a raw-pointer write (the AdamW kernel), a
+# replayed HIP graph (utils.graph) -- or (b) ANY registered arena buffer is written through torch (its ``_version`` counts
+# in-place ops on the flat tensor: loading into the arena, an EMA, a custom collective), which a parameter's own version
+# counter never sees.  One integer compare per lookup; nothing is refreshed until a weight is used again.
+_generation = [0]
+_arena_refs = []
+
+
+def register_arena(flat: torch.Tensor):
+    _arena_refs.append(weakref.ref(flat))
+
+
+def invalidate_weight_caches():
+    _generation[0] += 1
+
+
+def cache_epoch() -> int:
+    e = _generation[0]
+    dead = False
+    for r in _arena_refs:
+        t = r()
+        if t is None:
+            dead = True
+        else:
+            e += t._version
+    if dead:
+        _arena_refs[:] = [r for r in _arena_refs if r() is not None]
+    return e
 
 
 _prepared = {}   # id(parameter) -> PreparedWeight (identity-keyed: tensors define == elementwise); entries die with the tensor
@@ -186,11 +217,12 @@ def _refresh_stale(device):
     """After an optimizer step EVERY prepared weight is stale: refresh them all in one launch (mv_weight_prep_batch)
     instead of one ~7 us launch per nn.Linear at its first use."""
     stale = []
+    epoch = cache_epoch()
     for pw in list(_prepared.values()):                      # a finalizer may pop entries while we look
         w = pw.ref() if pw.ref is not None else None
         if w is None or pw.w.device != device or not w.is_contiguous():
             continue
-        if pw.version != w._version or pw.ptr != w.data_ptr():
+        if pw.version != w._version or pw.ptr != w.data_ptr() or pw.epoch != epoch:
             stale.append((pw, w))
     if not stale:
         return
@@ -210,20 +242,21 @@ def _refresh_stale(device):
     table, count, total = ent
     check(lib().mv_weight_prep_batch(_p(table), count, total, _s()), "weight_prep_batch", count=count)
     for pw, w in stale:
-        pw.version, pw.ptr = w._version, w.data_ptr()
+        pw.version, pw.ptr, pw.epoch = w._version, w.data_ptr(), epoch
 
 
 def prepared_weight(weight: torch.Tensor) -> PreparedWeight:
     """Cached bf16 / transposed-bf16 copies, refreshed when the parameter changed (``_version`` or storage)."""
     key = id(weight)
     pw = _prepared.get(key)
-    if pw is not None and pw.version == weight._version and pw.ptr == weight.data_ptr():
+    epoch = cache_epoch()
+    if pw is not None and pw.version == weight._version and pw.ptr == weight.data_ptr() and pw.epoch == epoch:
         return pw
     require_cuda(weight)
     n_out, k_in = weight.shape
     if pw is not None and pw.n_out == n_out and pw.k_in == k_in and pw.w.device == weight.device and weight.is_contiguous():
         _refresh_stale(weight.device)                       # this weight and every other stale one
-        if pw.version == weight._version and pw.ptr == weight.data_ptr():
+        if pw.version == weight._version and pw.ptr == weight.data_ptr() and pw.epoch == epoch:
             return pw
     if pw is None or pw.n_out != n_out or pw.k_in != k_in or pw.w.device != weight.device:
         pw = PreparedWeight()
@@ -240,7 +273,7 @@ def prepared_weight(weight: torch.Tensor) -> PreparedWeight:
         wd = wd.contiguous()
     check(lib().mv_weight_prep(_p(wd), _p(pw.w), pw.ldw, _p(pw.wt), pw.ldt, n_out, k_in, _s()), "weight_prep",
           R=n_out, C=k_in)
-    pw.version, pw.ptr = weight._version, weight.data_ptr()
+    pw.version, pw.ptr, pw.epoch = weight._version, weight.data_ptr(), epoch
     return pw
 
 
@@ -358,7 +391,7 @@ def split_act(x, rows, cols, ldx, colsum_out=None):
 
 
 class _SplitWeight:
-    __slots__ = ("version", "ptr", "fwd", "dx")
+    __slots__ = ("version", "ptr", "fwd", "dx", "epoch")
 
 
 _split_weights = {}
@@ -369,11 +402,12 @@ def split_weight(weight: torch.Tensor, which: str) -> torch.Tensor:
     transposed weight, dx = dy W); refreshed when the parameter changed."""
     key = id(weight)
     sw = _split_weights.get(key)
-    if sw is None or sw.version != weight._version or sw.ptr != weight.data_ptr():
+    epoch = cache_epoch()
+    if sw is None or sw.version != weight._version or sw.ptr != weight.data_ptr() or sw.epoch != epoch:
         if sw is None:
             weakref.finalize(weight, _split_weights.pop, key, None)
         sw = _split_weights[key] = _SplitWeight()
-        sw.version, sw.ptr, sw.fwd, sw.dx = weight._version, weight.data_ptr(), None, None
+        sw.version, sw.ptr, sw.fwd, sw.dx, sw.epoch = weight._version, weight.data_ptr(), None, None, epoch
     n_out, k_in = weight.shape
     if which == "fwd":
         if sw.fwd is None:
@@ -1037,10 +1071,15 @@ def mask_prepare(mask, yi, xi, flip, add=0):
     return out
 
 
-def adamw_step(p, g, m, v, *, lr, beta1, beta2, eps, weight_decay, step, grad_scale=1.0, clip_coef=None):
+def adamw_step(p, g, m, v, *, lr, beta1, beta2, eps, weight_decay, step, grad_scale=1.0, clip_coef=None, hyper=None):
     """In-place AdamW on flat fp32 tensors (torch.optim.AdamW semantics).  ``clip_coef``: fp32 device scalar multiplied
-    into every gradient (``grad_norm_clip``)."""
-    require_cuda(p, g, m, v, clip_coef)
+    into every gradient (``grad_norm_clip``).  ``hyper`` (fp32 [3] on the device: lr, 1 - beta1^step, 1 - beta2^step)
+    replaces ``lr`` / ``step``: what a launch captured in a HIP graph reads, see ``utils.optim.AdamW.use_device_scalars``."""
+    require_cuda(p, g, m, v, clip_coef, hyper)
+    if hyper is not None:
+        check(lib().mv_adamw_dev(_p(p), _p(g), _p(m), _p(v), p.numel(), _p(hyper), beta1, beta2, eps, weight_decay, grad_scale,
+                                 _p(clip_coef), _s()), "adamw_dev", n=p.numel())
+        return
     bc1 = 1.0 - beta1 ** step
     bc2 = 1.0 - beta2 ** step
     check(lib().mv_adamw(_p(p), _p(g), _p(m), _p(v), p.numel(), lr, beta1, beta2, eps, weight_decay, bc1, bc2,

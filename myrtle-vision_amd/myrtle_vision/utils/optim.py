@@ -59,6 +59,9 @@ class ParamArena:
                 p.data = self.flat_param[o:o + n].view(p.shape)
                 p.grad = None
                 ops.register_grad_slot(p, self.flat_grad[o:o + n])      # backward kernels write d/dp here directly
+        # any torch-side in-place write to the flat buffer (loading into the arena, an EMA, a custom collective) moves the
+        # weight caches' epoch by itself; raw-pointer writes (the AdamW kernel) announce themselves through bump_versions()
+        ops.register_arena(self.flat_param)
 
     def slot(self, j):
         o = self.offsets[j]
@@ -89,6 +92,7 @@ class ParamArena:
         """The AdamW kernel writes through raw pointers: tell autograd / the bf16 weight cache the data changed."""
         for p in self.params:
             torch.autograd.graph.increment_version(p)
+        ops.invalidate_weight_caches()
 
 
 class AdamW:
@@ -108,6 +112,37 @@ class AdamW:
         self.grad_scale = 1.0            # e.g. 1/world_size after a SUM all-reduce
         self.max_grad_norm = None        # train_config.clip_grad: clip_grad_norm_ folded into the step (train.py:265-270)
         self.last_grad_norm = None       # device tensor [total_norm, clip coefficient] of the last clipped step
+        self._hyper = None               # use_device_scalars(): per-group fp32 [3] (lr, bias_corr1, bias_corr2) on the device
+
+    # -- per-step scalars on the device (HIP-graph capture: utils/graph.py) ---------------------------------------------
+    def use_device_scalars(self, ring: int = 32):
+        """From now on the kernels read lr and the two bias corrections from device memory instead of launch arguments, so a
+        captured ``step()`` stays valid while the schedule and the step count advance.  ``advance()`` (called by ``step()``
+        itself outside a capture, by the graph's replayer otherwise) bumps the step count and sends the new values: pinned
+        staging slots in a ring, each guarded by an event, so the host may run many steps ahead of the device."""
+        dev = self.arena.flat_param.device
+        self._hyper = {g["name"]: torch.zeros(3, dtype=torch.float32, device=dev) for g in self.param_groups}
+        self._stage = [torch.zeros(len(self.param_groups), 3, dtype=torch.float32).pin_memory() for _ in range(ring)]
+        self._stage_done = [None] * ring
+        self._stage_i = 0
+
+    def advance(self):
+        """step_count += 1 and (lr, 1 - beta1^t, 1 - beta2^t) of every group -> the device, on the current stream."""
+        self.step_count += 1
+        b1, b2 = self.defaults["betas"]
+        bc1, bc2 = 1.0 - b1 ** self.step_count, 1.0 - b2 ** self.step_count
+        i = self._stage_i
+        self._stage_i = (i + 1) % len(self._stage)
+        if self._stage_done[i] is not None:
+            self._stage_done[i].synchronize()           # the copy that last read this slot has run (normally long ago)
+        host = self._stage[i]
+        for r, g in enumerate(self.param_groups):
+            host[r, 0], host[r, 1], host[r, 2] = g["lr"], bc1, bc2
+        for r, g in enumerate(self.param_groups):
+            self._hyper[g["name"]].copy_(host[r], non_blocking=True)
+        ev = torch.cuda.Event()
+        ev.record()
+        self._stage_done[i] = ev
 
     def zero_grad(self, set_to_none: bool = False):
         self.arena.zero_grad()
@@ -115,7 +150,10 @@ class AdamW:
     @torch.no_grad()
     def step(self):
         self.arena.sync_grads()
-        self.step_count += 1
+        if self._hyper is None:
+            self.step_count += 1
+        elif not torch.cuda.is_current_stream_capturing():
+            self.advance()                # inside a capture the replayer advances (utils/graph.py)
         b1, b2 = self.defaults["betas"]
         a = self.arena
         coef = None
@@ -130,7 +168,7 @@ class AdamW:
                 ops.adamw_step(a.flat_param[lo:hi], a.flat_grad[lo:hi], self.exp_avg[lo:hi], self.exp_avg_sq[lo:hi],
                                lr=g["lr"], beta1=b1, beta2=b2, eps=self.defaults["eps"],
                                weight_decay=g["weight_decay"], step=self.step_count, grad_scale=self.grad_scale,
-                               clip_coef=coef)
+                               clip_coef=coef, hyper=None if self._hyper is None else self._hyper[g["name"]])
         a.bump_versions()
 
     # checkpoint format = torch.optim.AdamW.state_dict() of the optimizer the reference builds (classification/train.py:

@@ -200,6 +200,89 @@ def test_ddp_two_ranks_match_single_process(tmp_path, task, exchange):
     assert torch.equal(f0, f1)
 
 
+@pytest.mark.parametrize("task", ["classification", "segmentation"])
+def test_graphed_step_equals_eager_step(task):
+    """utils/graph.py: the training step captured in ONE HIP graph and replayed gives, bit for bit, the parameters of the
+    eager step (same kernels, same order, same addresses of the scalars' VALUES): three replays on three different batches
+    with a learning-rate change in between (the schedule reaches the captured AdamW launch through device memory), then an
+    eager evaluation forward that must see the LAST parameters (the weight caches' epoch moved)."""
+    from myrtle_vision.hip.functional import cross_entropy
+    from myrtle_vision.models.vit import ViT
+    from myrtle_vision.utils.graph import GraphedTrainStep
+    from myrtle_vision.utils.optim import AdamW, ParamArena
+    from myrtle_vision.utils.utils import seed_everything
+    kw = dict(image_size=224, patch_size=16, dim=128, depth=2, heads=2, mlp_dim=256, dropout=0.0, emb_dropout=0.0, **_DDP_KW[task])
+    loss_fn = (lambda m, x, y: m.segmentation_loss(x, y)[0]) if task == "segmentation" else (lambda m, x, y: cross_entropy(m(x), y))
+    g = torch.Generator().manual_seed(9)
+    nc = kw["num_classes"]
+    batches = [(torch.randn(4, 3, 224, 224, generator=g).cuda(),
+                (torch.randint(0, nc, (4,), generator=g) if task == "classification"
+                 else torch.randint(0, nc, (4, 224, 224), generator=g)).cuda()) for _ in range(4)]
+    lrs = [1e-3, 1e-3, 4e-4, 7e-4]
+
+    def build():
+        seed_everything(21)
+        vit = ViT(precision="bf16", q_format="FP32", **kw).cuda().train()
+        opt = AdamW(ParamArena(vit.named_parameters(), skip=vit.unused_parameter_names()), lr=1e-3, weight_decay=0.05)
+        opt.max_grad_norm = 1.0                                              # the clip coefficient is a device scalar as well
+        return vit, opt
+
+    def set_lr(opt, lr):
+        for grp in opt.param_groups:
+            grp["lr"] = lr
+
+    # eager reference: 3 warm-up steps on batch 0 (what GraphedTrainStep's constructor performs), then batches 1..3
+    vit_e, opt_e = build()
+    losses_e = []
+    for i in [0, 0, 0, 1, 2, 3]:
+        set_lr(opt_e, lrs[i])
+        opt_e.zero_grad()
+        loss = loss_fn(vit_e, *batches[i])
+        loss.backward()
+        opt_e.step()
+        losses_e.append(float(loss))
+    vit_g, opt_g = build()
+    graphed = GraphedTrainStep(vit_g, opt_g, loss_fn, *batches[0], warmup=3)
+    assert opt_g.step_count == 3
+    losses_g = []
+    for i in (1, 2, 3):
+        set_lr(opt_g, lrs[i])
+        losses_g.append(float(graphed(*batches[i])))
+    torch.cuda.synchronize()
+    assert opt_g.step_count == opt_e.step_count == 6
+    assert losses_g == losses_e[3:]
+    assert torch.equal(opt_g.arena.flat_param, opt_e.arena.flat_param)
+    assert torch.equal(opt_g.exp_avg, opt_e.exp_avg) and torch.equal(opt_g.exp_avg_sq, opt_e.exp_avg_sq)
+    # an eager forward AFTER the replays uses the updated parameters (bf16 weight copies re-prepared)
+    vit_g.eval(), vit_e.eval()
+    with torch.no_grad():
+        assert torch.equal(vit_g(batches[0][0]), vit_e(batches[0][0]))
+
+
+def test_direct_arena_write_refreshes_weight_copies():
+    """a torch-side in-place write to ``arena.flat_param`` (an EMA, loading into the arena) is seen by the bf16
+    weight caches without any bump_versions() call -- the arena buffer's own version counter is part of the cache epoch."""
+    from myrtle_vision.models.vit import ViT
+    from myrtle_vision.utils.optim import ParamArena
+    from myrtle_vision.utils.utils import seed_everything
+    seed_everything(4)
+    kw = dict(decoder="classification", image_size=224, patch_size=16, num_classes=7, dim=128, depth=1, heads=2, mlp_dim=256)
+    vit = ViT(precision="bf16", q_format="FP32", **kw).cuda().eval()
+    arena = ParamArena(vit.named_parameters(), skip=vit.unused_parameter_names())
+    x = torch.randn(2, 3, 224, 224, generator=torch.Generator().manual_seed(1)).cuda()
+    with torch.no_grad():
+        a = vit(x).clone()
+        arena.flat_param.mul_(0.5)                                           # no bump_versions()
+        b = vit(x).clone()
+        seed_everything(4)
+        ref = ViT(precision="bf16", q_format="FP32", **kw).cuda().eval()
+        for p in ref.parameters():
+            p.mul_(0.5)
+        want = ref(x)
+    assert not torch.equal(a, b)
+    assert torch.equal(b, want)                                              # same halved weights, same kernels: same bits
+
+
 def test_int8_quantized_evaluation_path(tmp_path):
     """classification/test_quantize.py with q_format PyTorchINT8 (BASELINE config 5's entry point): the model is moved to
     the GPU FIRST and prepared afterwards, so the observers must be created on the device (the min/max kernel updates
