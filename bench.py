@@ -46,7 +46,8 @@ VIT_B = dict(decoder="classification", image_size=224, patch_size=16, num_classe
 def _latest_profile(suffix):
     """Newest committed profiles/rNN_<suffix> (rounds sort lexicographically), parsed, or None."""
     import glob
-    files = sorted(glob.glob(os.path.join(ROOT, "profiles", f"r[0-9][0-9]_{suffix}")))
+    # rNN_<suffix> or rNN_<tag>_<suffix> (tools/evidence.sh names its outputs <tag>_<suffix>, e.g. r03_b_pmc_traffic.json)
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", f"r[0-9][0-9]_*{suffix}")))
     if not files:
         return None
     try:

@@ -119,16 +119,7 @@ __device__ __forceinline__ void nt_colsum_flush(float (&cs)[4][4], float* __rest
 // erf to |err| <= 1.5e-7 (Abramowitz-Stegun 7.1.26) on v_rcp_f32 / v_exp_f32: ~13 VALU ops instead of libm erff's
 // branchy ~40.  Used only where the result is rounded to bf16 (2^-9) anyway; the fp32 parity path keeps erff.
 // Also returns e = exp(-u^2), which GELU' needs as its Gaussian factor.
-__device__ __forceinline__ float erf_fast(float u, float& e) {
-  const float au = fabsf(u);
-  const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f, au, 1.0f));
-  float p = fmaf(1.061405429f, t, -1.453152027f);
-  p = fmaf(p, t, 1.421413741f);
-  p = fmaf(p, t, -0.284496736f);
-  p = fmaf(p, t, 0.254829592f);
-  e = __builtin_amdgcn_exp2f(-1.4426950408889634f * u * u);
-  return copysignf(fmaf(-p * t, e, 1.0f), u);
-}
+__device__ __forceinline__ float erf_fast(float u, float& e) { return mv_erf_fast(u, e); }
 __device__ __forceinline__ float gelu_fast(float x) {
   float e;
   return 0.5f * x * (1.0f + erf_fast(x * 0.70710678118654752440f, e));

@@ -70,12 +70,34 @@ __device__ __forceinline__ float dgelu_f(float x) {
   return cdf + x * pdf;
 }
 
+// erf to |error| <= 1.5e-7 (Abramowitz-Stegun 7.1.26) on v_rcp_f32 / v_exp_f32: ~13 VALU operations against libm erff's
+// branchy ~40.  Also returns e = exp(-u^2) (the Gaussian factor GELU' needs).
+__device__ __forceinline__ float mv_erf_fast(float u, float& e) {
+  const float au = fabsf(u);
+  const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f, au, 1.0f));
+  float p = fmaf(1.061405429f, t, -1.453152027f);
+  p = fmaf(p, t, 1.421413741f);
+  p = fmaf(p, t, -0.284496736f);
+  p = fmaf(p, t, 0.254829592f);
+  e = __builtin_amdgcn_exp2f(-1.4426950408889634f * u * u);
+  return copysignf(fmaf(-p * t, e, 1.0f), u);
+}
+__device__ __forceinline__ float mv_gelu_fast(float x) {
+  float e;
+  const float h = 0.5f * x;
+  return fmaf(h, mv_erf_fast(x * 0.70710678118654752440f, e), h);     // explicit fma: the same bits in every kernel that inlines it
+}
+
 // Per-tensor affine quantiser (torch.fake_quantize_per_tensor_affine / MinMaxObserver qparams): the integer code q - zp of x.
-// PRE = 1: GELU (erf form, the unfused gelu kernel's function) applied to x first.  ONE definition for the standalone
-// quantiser kernels and for the producers that fuse it into their epilogue, so fused and unfused paths agree bit for bit.
+// PRE = 1: GELU (erf form) applied to x first.  ONE definition for the standalone quantiser kernels and for the producers
+// that fuse it into their epilogue, so fused and unfused paths agree bit for bit.  Round 3: the GELU in front of an 8-bit
+// quantiser is the 1.5e-7-accurate erf above, not libm's erff -- the exact erf was ~60 k VALU cycles per 256 x 256 tile in
+// fc1's int8 epilogue, more than that tile's main loop; against a quantiser step of 1/255 of the tensor's range, 1.5e-7 moves
+// a code only where the exact value sits within 1.5e-7 of a rounding boundary (about one element in 10^5, by one code:
+// tests/test_hip_ops.py), the size of an fp32 rounding in front of the same quantiser.
 template <int PRE>
 __device__ __forceinline__ float affine_code_one(float x, float inv, float zp, float qmin, float qmax) {
-  if (PRE == 1) x = gelu_f(x);
+  if (PRE == 1) x = mv_gelu_fast(x);
   float q = rintf(x * inv) + zp;
   q = fminf(fmaxf(q, qmin), qmax);
   return q - zp;

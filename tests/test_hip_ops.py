@@ -894,9 +894,11 @@ def test_int8_codes_gemm_equals_fake_quant_linear(ops, M, N, K):
     wq = torch.fake_quantize_per_tensor_affine(w, s_w, 0, -128, 127)
     want = torch.nn.functional.linear(xq.double(), wq.double(), b.double())
     xc = ops.quant_affine_codes(x.cuda(), M, K, s_x, z_x, 0, 255)
-    # the GELU pre-op is the unfused gelu followed by the same quantiser, bit for bit
-    assert torch.equal(ops.quant_affine_codes(x.cuda(), M, K, s_x, z_x, 0, 255, pre_gelu=True),
-                       ops.quant_affine_codes(ops.gelu_fwd(x.cuda()), M, K, s_x, z_x, 0, 255))
+    # the GELU pre-op is the unfused (exact-erf) gelu followed by the same quantiser up to the pre-op's 1.5e-7-accurate erf:
+    # a code may move by one where the exact value sits within 1.5e-7 of a rounding boundary (about 1 element in 10^5)
+    fused_codes = ops.quant_affine_codes(x.cuda(), M, K, s_x, z_x, 0, 255, pre_gelu=True).float()
+    plain_codes = ops.quant_affine_codes(ops.gelu_fwd(x.cuda()), M, K, s_x, z_x, 0, 255).float()
+    assert float((fused_codes - plain_codes).abs().max()) <= 1.0 and float((fused_codes != plain_codes).float().mean()) < 2e-4
     assert xc.shape == (M, (K + 7) & ~7) and xc.dtype == torch.bfloat16
     codes = xc[:, :K].float().cpu()
     assert torch.equal(codes, torch.round(xq / s_x))                     # the integer (q - z), exactly
@@ -953,9 +955,10 @@ def test_int8_mfma_gemm_is_the_exact_integer_product(ops, M, N, K):
     out_b = torch.empty(M, N, device="cuda", dtype=torch.bfloat16)
     ops.linear_i8(x8, w8.cuda(), M, N, K, s_x * s_w, b.cuda(), icorr.cuda(), out_b)
     assert torch.equal(out_b, out.bfloat16())
-    # the GELU pre-op of the int8 quantiser == unfused gelu then quantise
-    assert torch.equal(ops.quant_affine_i8(x.cuda(), M, K, s_x, z_x, pre_gelu=True),
-                       ops.quant_affine_i8(ops.gelu_fwd(x.cuda()), M, K, s_x, z_x))
+    # the GELU pre-op of the int8 quantiser == unfused (exact-erf) gelu then quantise, up to the fast erf's rare one-code moves
+    fused8 = ops.quant_affine_i8(x.cuda(), M, K, s_x, z_x, pre_gelu=True).float()
+    plain8 = ops.quant_affine_i8(ops.gelu_fwd(x.cuda()), M, K, s_x, z_x).float()
+    assert float((fused8 - plain8).abs().max()) <= 1.0 and float((fused8 != plain8).float().mean()) < 2e-4
 
 
 def test_int8_vit_base_dim_matches_torch_fake_quant():
