@@ -66,6 +66,7 @@ struct EpiArgs {
   // contraction slice t / ks_tiles (ks_len elements long) and writes slab t / ks_tiles (ks_slab elements apart)
   int ks_tiles, ks_len;
   long ks_slab;
+  int no_prefetch;      // A/B switch (mv_gemm_force_variant 2567): the 8-phase epilogue loads each quadrant's aux tile itself
 };
 
 // 16-byte output store of the NT epilogues
@@ -176,9 +177,49 @@ __device__ __forceinline__ u32x4 pair_swap_bf16(const float (&va)[4], const floa
   return (u32x4){r0[0], r1[0], r0[1], r1[1]};
 }
 
-template <int EPI, typename CT>
+// The aux operand of one 64 x 64 quadrant, loaded AHEAD of the epilogue that consumes it.  The 8-phase kernel finishes its two
+// quadrant-rows one after the other; each nt_epilogue call used to begin with its own aux loads, so the second call's loads
+// (a full memory round trip while every CU of the chip is in its store burst) sat exposed between the first call's stores and
+// the second call's arithmetic.  With both quadrants' loads issued before the first call, the second quadrant's data arrives
+// under the first one's arithmetic and stores.  RESIDUAL: the fp32 residual tile (64 VGPRs per quadrant; the second
+// accumulator half is parked in LDS meanwhile); MUL8: the gelu' codes (4 x 16 bytes per lane).
+template <int EPI>
+struct EpiPre {
+  float4 ax[EPI == MV_EPI_RESIDUAL ? 4 : 1][EPI == MV_EPI_RESIDUAL ? 4 : 1];
+  u32x4 xq[EPI == MV_EPI_MUL8 ? 4 : 1];
+};
+template <int EPI>
+__device__ __forceinline__ void nt_epi_prefetch(EpiPre<EPI>& P, int m0, int n0, int wm, int wn, int lane, const EpiArgs& ep) {
+  const int mb = m0 + wm * 64 + (lane & 15), nb = n0 + wn * 64 + 4 * (lane >> 4);
+  if constexpr (EPI == MV_EPI_RESIDUAL) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+        P.ax[i][j] = *reinterpret_cast<const float4*>(reinterpret_cast<const float*>(ep.aux) + (long)(mb + i * 16) * ep.ld_aux + nb + j * 16);
+  } else if constexpr (EPI == MV_EPI_MUL8) {
+    const unsigned char* a8 = reinterpret_cast<const unsigned char*>(ep.aux);
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+      P.xq[i] = *reinterpret_cast<const u32x4*>(a8 + (long)(mb + i * 16) * ep.ld_aux + n0 + wn * 64 + 16 * (lane >> 4));
+  }
+}
+// wave-uniform: may this quadrant's aux be prefetched (the conditions of nt_epilogue's fast paths that read it that way)?
+template <int EPI>
+__device__ __forceinline__ bool nt_epi_prefetch_ok(int M, int N, int m0, int n0, int ldc, const EpiArgs& ep) {
+  const bool interior = (m0 + BM <= M) && (n0 + BN <= N) && ((ldc & 3) == 0) && ((ep.ld_aux & 3) == 0) &&
+                        ((ep.ld_out2 & 3) == 0) && ((reinterpret_cast<uintptr_t>(ep.bias) & 15) == 0);
+  if constexpr (EPI == MV_EPI_MUL8)
+    return interior && (ep.ld_aux & 15) == 0 && (reinterpret_cast<uintptr_t>(ep.aux) & 15) == 0;
+  return interior && EPI == MV_EPI_RESIDUAL;
+}
+
+template <int EPI, typename CT, bool PRE = false>
 __device__ __forceinline__ void nt_epilogue(f32x4 (&acc)[4][4], CT* __restrict__ C, int ldc, int M, int N, int m0, int n0,
-                                            int wm, int wn, int lane, const EpiArgs& ep, const float* bias_lds = nullptr) {
+                                            int wm, int wn, int lane, const EpiArgs& ep, const float* bias_lds = nullptr,
+                                            const EpiPre<EPI>& pre = EpiPre<EPI>{}) {
+  // PRE: this quadrant's aux tile is already in ``pre`` (nt_epi_prefetch; the caller checked nt_epi_prefetch_ok, i.e. the
+  // interior fast path below is the one that runs)
   // bias_lds (persistent kernel): the bias of this 128-column region staged in LDS (zeros when there is none); indexed
   // relative to the region, so the epilogue issues no global load at all
   // (m0, n0) = origin of the 128x128 region this call covers; wave (wm, wn) owns its 64x64 quadrant
@@ -242,6 +283,10 @@ __device__ __forceinline__ void nt_epilogue(f32x4 (&acc)[4][4], CT* __restrict__
       for (int i = 0; i < 4; ++i)
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
+          if constexpr (EPI == MV_EPI_RESIDUAL && PRE) {    // loaded ahead by the kernel (nt_epi_prefetch)
+            ax[i][j] = pre.ax[i][j];
+            continue;
+          }
           const long arow = (EPI == MV_EPI_EMBED) ? prow[i] : (mb + i * 16);
           ax[i][j] = *reinterpret_cast<const float4*>(reinterpret_cast<const float*>(ep.aux) + arow * ep.ld_aux + nb + j * 16);
         }
@@ -257,7 +302,8 @@ __device__ __forceinline__ void nt_epilogue(f32x4 (&acc)[4][4], CT* __restrict__
         u32x4 x[4];
 #pragma unroll
         for (int i = 0; i < 4; ++i)
-          x[i] = *reinterpret_cast<const u32x4*>(a8 + (long)(mb + i * 16) * ep.ld_aux + n0 + wn * 64 + 16 * (lane >> 4));
+          x[i] = PRE ? pre.xq[i]
+                     : *reinterpret_cast<const u32x4*>(a8 + (long)(mb + i * 16) * ep.ld_aux + n0 + wn * 64 + 16 * (lane >> 4));
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
           const u32x2_t s01 = __builtin_amdgcn_permlane16_swap(x[i][0], x[i][1], false, false);
@@ -1160,6 +1206,24 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_8phase_kernel(const bf16_t* __
 #pragma unroll
       for (int j = 0; j < 4; ++j) parked[(i * 4 + j) * 64] = acc[4 + i][j];
   }
+  // both quadrant-rows' aux tiles are requested now; the second one lands under the first one's arithmetic and stores
+  constexpr bool can_pre = (EPI == MV_EPI_RESIDUAL || EPI == MV_EPI_MUL8) && !KSPLIT;
+  if constexpr (can_pre) {
+    if (!is_half && !ep.no_prefetch && nt_epi_prefetch_ok<EPI>(M, N, m0 + 128 * wm, n0 + 128 * (wn >> 1), ldc, ep)) {
+      EpiPre<EPI> pre0, pre1;
+      nt_epi_prefetch<EPI>(pre0, m0 + 128 * wm, n0 + 128 * (wn >> 1), 0, wn & 1, lane, ep);
+      nt_epi_prefetch<EPI>(pre1, m0 + 128 * wm, n0 + 128 * (wn >> 1), 1, wn & 1, lane, ep);
+      nt_epilogue<EPI, CT, true>(*reinterpret_cast<f32x4(*)[4][4]>(&acc[0]), C, ldc, M, N, m0 + 128 * wm, n0 + 128 * (wn >> 1), 0,
+                                 wn & 1, lane, ep, nullptr, pre0);
+      f32x4 accb[4][4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) accb[i][j] = parked[(i * 4 + j) * 64];        // can_pre implies park
+      nt_epilogue<EPI, CT, true>(accb, C, ldc, M, N, m0 + 128 * wm, n0 + 128 * (wn >> 1), 1, wn & 1, lane, ep, nullptr, pre1);
+      return;
+    }
+  }
   nt_epilogue<EPI, CT>(*reinterpret_cast<f32x4(*)[4][4]>(&acc[0]), C, ldc, M, N, is_half ? m0 : m0 + 128 * wm,
                        n0 + 128 * (wn >> 1), is_half ? wm : 0, wn & 1, lane, ep);
   if (is_half) return;
@@ -1949,7 +2013,11 @@ int launch_nt(const void* A, int lda, const void* B, int ldb, void* C, int ldc, 
   // otherwise two 128x128 workgroups per CU overlap each other's epilogues better.  Where the ring kernel would be
   // picked and K % 128 == 0, the 8-phase kernel replaces it (+6-14 % on every ViT-B shape: whole 128-byte lines per
   // DMA row, 16-MFMA phases).  MV_GEMM_TILE = 128 | 256 | 2564 (ring) | 2568 (8-phase) forces a variant (tuning, tests).
-  const int force = g_force_nt.load(std::memory_order_relaxed);
+  int force = g_force_nt.load(std::memory_order_relaxed);
+  if (force == 2567) {                                   // automatic dispatch, aux prefetch of the 8-phase epilogue off (A/B)
+    force = 0;
+    ep.no_prefetch = 1;
+  }
   const bool ring_ok = K > 0 && K % BKR == 0;
   const bool ring_pick = ring_ok && ((long)t2m * t2n >= 1024 || (K >= 2048 && (long)t2m * t2n >= 256));
   const bool p8_ok = K >= 128 && K % 128 == 0 && (long)M * lda < (1L << 31) && (long)N * ldb < (1L << 31);
@@ -2203,7 +2271,7 @@ extern "C" int mv_gemm_nt_i8(const void* A, int lda, const void* B, int ldb, voi
 
 extern "C" int mv_gemm_force_variant(int nt_variant, int tn_variant) {
   const bool nt_ok = nt_variant == 0 || nt_variant == 128 || nt_variant == 256 || nt_variant == 2564 ||
-                     nt_variant == 2568 || nt_variant == 25680 || nt_variant == 2569;
+                     nt_variant == 2568 || nt_variant == 25680 || nt_variant == 2569 || nt_variant == 2567;
   const bool tn_ok = tn_variant == 0 || tn_variant == 128 || tn_variant == 256;
   MV_REQUIRE(nt_ok && tn_ok, MV_ERR_UNSUPPORTED);
   g_force_nt.store(nt_variant, std::memory_order_relaxed);
