@@ -67,6 +67,7 @@ struct EpiArgs {
   int ks_tiles, ks_len;
   long ks_slab;
   int no_prefetch;      // A/B switch (mv_gemm_force_variant 2567): the 8-phase epilogue loads each quadrant's aux tile itself
+  int eager_waits;      // A/B switch (2566): the round-1 wait placement of the 8-phase main loop (whole next K-tile at phases 4 / 8)
 };
 
 // 16-byte output store of the NT epilogues
@@ -951,8 +952,9 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_ring_kernel(const bf16_t* __re
 //  * every phase all 512 threads stage ONE slot (2 global_load_lds_dwordx4 each; rows are whole 128-byte lines):
 //      phase: 1        2        3        4        5        6        7        8
 //      slot : A_q1[t+1] B_q0[t+2] A_q0[t+2] B_q1[t+2] A_q1[t+2] B_q0[t+3] A_q0[t+3] B_q1[t+3]
-//    and waits only twice: vmcnt(6) in phase 4 (everything up to phase 1 landed = K-tile t+1 complete, read in phases
-//    5-7) and in phase 8 (K-tile t+2 complete).  Three slots (48 KiB) stay in flight across those waits.
+//    Round 1 waited only twice: vmcnt(6) in phase 4 (everything up to phase 1 landed = K-tile t+1 complete, read in phases
+//    5-7) and in phase 8 (K-tile t+2 complete): three slots (48 KiB) in flight across those waits.  Round 3 waits for each
+//    slot in the phase before the one that reads it (vmcnt(10) in phases 1, 2, 4, 5, 6, 8: five slots in flight; see P8_KTILE).
 //  * a phase is  [ds_reads | stage | (waits) | barrier | lgkmcnt(0) | 16 MFMA | barrier];  waves 4-7 run ONE BARRIER
 //    behind waves 0-3, so the reads + DMA issue of one group overlap the MFMAs of the other on every SIMD.
 //    RAW: a vmcnt wait sits before a phase's first barrier and the data is read in the NEXT phase, so both groups have
@@ -1101,7 +1103,20 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_8phase_kernel(const bf16_t* __
   }
 // one K-tile (4 phases) out of buffer d_; ST_ = 1: stage per the schedule (k-tile indices t1_, t2_ for the two buffers'
 // next contents), ST_ = 0: the drained tail.  WAIT_: asm string of the phase-4/8 wait.
-#define P8_KTILE(d_, ST_, first_slot_buf_, first_slot_kt_, next_buf_, next_kt_, after_buf_, after_kt_, WAIT_, STAGE_FIRST_) \
+// Waits.  The round-1 schedule waited twice per eight phases ("vmcnt(6)" in phases 4 and 8: the whole NEXT K-tile landed), which
+// gives the slot staged last before the wait (A_q1, staged in phase 1/5) only THREE phases -- about 1 us at the kernel's pace -- to
+// arrive, although it is first read three phases after the wait.  The throughput of a latency-bound L2 -> LDS stream is bytes in
+// flight / latency (the kernel moves ~18 B/clk/CU with 48 KiB in flight and ~1.5 us of loaded latency), so the waits are now placed
+// where the data is needed: each slot is waited for in the phase BEFORE the one that reads it (the RAW rule of the header: wait
+// before a phase's first barrier, read in the next phase) and not earlier --
+//      phase 4 / 8: B_q0, A_q0 of the next K-tile (read in phase 5 / 1)      phase 1 / 5: B_q1 of this K-tile (read in phase 2 / 6)
+//      phase 2 / 6: A_q1 of this K-tile (read in phase 3 / 7)                phase 3 / 7: nothing
+// In the steady state exactly five slots (10 DMA instructions) have been issued after the slot(s) being waited for at every one of
+// those points, so every wait is vmcnt(10): FIVE slots (80 KiB) stay in flight across the waits instead of three, with the same
+// staging times (the WAR argument is unchanged) and the same 128 KiB of LDS.  W1_/W2_/W4_ are the counts of a full tile; half items
+// (no A_q1 slot, three slots per K-tile) keep the round-1 waits (H4_), as does a launch with ep.eager_waits (A/B switch 2566).
+#define P8_WAIT(N_) asm volatile("s_waitcnt vmcnt(" #N_ ")" ::: "memory");
+#define P8_KTILE(d_, ST_, first_slot_buf_, first_slot_kt_, next_buf_, next_kt_, W1_, W2_, W4_, H4_, STAGE_FIRST_)        \
   {                                                                                                          \
     /* phase 1/5 */                                                                                          \
     P8_READ_B(bf0, d_, P8_BQ0)                                                                               \
@@ -1110,6 +1125,7 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_8phase_kernel(const bf16_t* __
     __builtin_amdgcn_sched_barrier(0);                                                                       \
     if (STAGE_FIRST_ && !is_half) P8_STAGE(first_slot_buf_, P8_AQ1, first_slot_kt_)                          \
     asm volatile("s_waitcnt lgkmcnt(8)" ::: "memory"); /* the 4 B_q0 reads (issued first) have returned */   \
+    if (lazy) { W1_ }                                                                                        \
     P8_BAR()                                                                                                 \
     P8_LGKM0()                                                                                               \
     P8_MFMA(0, 0, bf0)                                                                                       \
@@ -1118,6 +1134,7 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_8phase_kernel(const bf16_t* __
     P8_READ_B(bf1, d_, P8_BQ1)                                                                               \
     __builtin_amdgcn_sched_barrier(0);                                                                       \
     if (ST_) P8_STAGE(next_buf_, P8_BQ0, next_kt_)                                                           \
+    if (lazy) { W2_ }                                                                                        \
     P8_BAR()                                                                                                 \
     P8_LGKM0()                                                                                               \
     P8_MFMA(0, 2, bf1)                                                                                       \
@@ -1132,15 +1149,16 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_8phase_kernel(const bf16_t* __
     P8_BAR()                                                                                                 \
     /* phase 4/8 */                                                                                          \
     if (ST_) P8_STAGE(next_buf_, P8_BQ1, next_kt_)                                                           \
-    asm volatile(WAIT_ ::: "memory");                                                                        \
+    if (lazy) { W4_ } else { H4_ }                                                                           \
     P8_BAR()                                                                                                 \
     if (!is_half) P8_MFMA(4, 0, bf0)                                                                         \
     P8_BAR()                                                                                                 \
   }
 
+  const bool lazy = !is_half && !ep.eager_waits;          // wave-uniform
   P8_STAGE(0, P8_BQ0, 0) P8_STAGE(0, P8_AQ0, 0) P8_STAGE(0, P8_BQ1, 0) if (!is_half) P8_STAGE(0, P8_AQ1, 0)
   P8_STAGE(1, P8_BQ0, 1) P8_STAGE(1, P8_AQ0, 1) P8_STAGE(1, P8_BQ1, 1)
-  asm volatile("s_waitcnt vmcnt(6)" ::: "memory");     // K-tile 0 landed (the 3 youngest slots may be in flight)
+  if (lazy) { P8_WAIT(10) } else { P8_WAIT(6) }           // B_q0, A_q0 of K-tile 0 landed | the whole K-tile 0
   P8_BAR()
   if (__builtin_amdgcn_readfirstlane(wave) >= 4) P8_BAR()      // waves 4-7 run one barrier behind
   int kt = 0;
@@ -1149,14 +1167,15 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_8phase_kernel(const bf16_t* __
 #endif
   for (; kt < nk - 2; kt += 2) {
     // phases 1-4: compute buffer 0 (K-tile kt); stage A_q1[kt+1] -> buffer 1, then B_q0/A_q0/B_q1[kt+2] -> buffer 0
-    P8_KTILE(0, 1, 1, kt + 1, 0, kt + 2, 0, 0, "s_waitcnt vmcnt(6)", 1)
+    P8_KTILE(0, 1, 1, kt + 1, 0, kt + 2, P8_WAIT(10), P8_WAIT(10), P8_WAIT(10), P8_WAIT(6), 1)
     // phases 5-8: compute buffer 1 (K-tile kt+1); stage A_q1[kt+2] -> buffer 0, then B_q0/A_q0/B_q1[kt+3] -> buffer 1
-    P8_KTILE(1, 1, 0, kt + 2, 1, kt + 3, 0, 0, "s_waitcnt vmcnt(6)", 1)
+    P8_KTILE(1, 1, 0, kt + 2, 1, kt + 3, P8_WAIT(10), P8_WAIT(10), P8_WAIT(10), P8_WAIT(6), 1)
   }
-  // peeled last iteration: only K-tile nk-1's A_q1 is still to be staged
-  P8_KTILE(0, 0, 1, kt + 1, 0, 0, 0, 0, "s_waitcnt vmcnt(0)", 1)
-  P8_KTILE(1, 0, 0, 0, 0, 0, 0, 0, "", 0)
+  // peeled last iteration: only K-tile nk-1's A_q1 is still to be staged; the queue drains 10 -> 8 -> 4 -> 2 -> 0
+  P8_KTILE(0, 0, 1, kt + 1, 0, 0, P8_WAIT(10), P8_WAIT(8), P8_WAIT(4), P8_WAIT(0), 1)
+  P8_KTILE(1, 0, 0, 0, 0, 0, P8_WAIT(2), P8_WAIT(0), , , 0)
   if (__builtin_amdgcn_readfirstlane(wave) < 4) P8_BAR()
+#undef P8_WAIT
 #undef P8_KTILE
 #undef P8_LGKM0
 #undef P8_BAR
@@ -2018,6 +2037,10 @@ int launch_nt(const void* A, int lda, const void* B, int ldb, void* C, int ldc, 
     force = 0;
     ep.no_prefetch = 1;
   }
+  if (force == 2566) {                                   // automatic dispatch, round-1 wait placement in the 8-phase main loop (A/B)
+    force = 0;
+    ep.eager_waits = 1;
+  }
   const bool ring_ok = K > 0 && K % BKR == 0;
   const bool ring_pick = ring_ok && ((long)t2m * t2n >= 1024 || (K >= 2048 && (long)t2m * t2n >= 256));
   const bool p8_ok = K >= 128 && K % 128 == 0 && (long)M * lda < (1L << 31) && (long)N * ldb < (1L << 31);
@@ -2271,7 +2294,7 @@ extern "C" int mv_gemm_nt_i8(const void* A, int lda, const void* B, int ldb, voi
 
 extern "C" int mv_gemm_force_variant(int nt_variant, int tn_variant) {
   const bool nt_ok = nt_variant == 0 || nt_variant == 128 || nt_variant == 256 || nt_variant == 2564 ||
-                     nt_variant == 2568 || nt_variant == 25680 || nt_variant == 2569 || nt_variant == 2567;
+                     nt_variant == 2568 || nt_variant == 25680 || nt_variant == 2569 || nt_variant == 2567 || nt_variant == 2566;
   const bool tn_ok = tn_variant == 0 || tn_variant == 128 || tn_variant == 256;
   MV_REQUIRE(nt_ok && tn_ok, MV_ERR_UNSUPPORTED);
   g_force_nt.store(nt_variant, std::memory_order_relaxed);

@@ -22,12 +22,15 @@ from myrtle_vision.utils.utils import seed_everything  # noqa: E402
 import myrtle_vision.hip.functional as _F  # noqa: E402
 
 GELU_AB = "GELU_BITS" in os.environ
-VARIANTS = [int(v) for v in os.environ.get("GELU_BITS" if GELU_AB else "NT_VARIANTS", "0,2569").split(",")]
+TN_AB = "TN_VARIANTS" in os.environ              # TN_VARIANTS=2564,2565: dW ring kernel with four / five stages
+VARIANTS = [int(v) for v in os.environ.get("GELU_BITS" if GELU_AB else "TN_VARIANTS" if TN_AB else "NT_VARIANTS", "0,2569").split(",")]
 
 
 def select(v):
     if GELU_AB:
         _F.GELU_GRAD_BITS = v
+    elif TN_AB:
+        lib().mv_gemm_force_variant(0, v)
     else:
         lib().mv_gemm_force_variant(v, 0)
 
