@@ -1902,6 +1902,26 @@ __global__ __launch_bounds__(512, 2) void gemm_tn_ring_kernel(const bf16_t* __re
 __global__ void splitk_reduce_kernel(const float* __restrict__ slabs, long slab_stride, int S, float* C, int ldc, int M,
                                      int N, int accumulate) {
   const long total = (long)M * N;
+  if (ldc == N && (total & 3) == 0 && (slab_stride & 3) == 0) {
+    // dense destination (every dW slot of the gradient arena): 16-byte accesses, no index division -- the scalar form below
+    // ran at 2.8 TB/s (15 us per launch, 49 launches per ViT-B step); same summation order per element, same bits
+    const long total4 = total >> 2;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total4; i += (long)gridDim.x * blockDim.x) {
+      float4 s = reinterpret_cast<const float4*>(slabs)[i];
+      s.x += 0.f; s.y += 0.f; s.z += 0.f; s.w += 0.f;     // the scalar form starts from 0.f + slab 0: -0.0 becomes +0.0 there
+      for (int k = 1; k < S; ++k) {
+        const float4 t = reinterpret_cast<const float4*>(slabs + (long)k * slab_stride)[i];
+        s.x += t.x; s.y += t.y; s.z += t.z; s.w += t.w;
+      }
+      float4* c = reinterpret_cast<float4*>(C) + i;
+      if (accumulate) {
+        const float4 o = *c;
+        s.x = o.x + s.x; s.y = o.y + s.y; s.z = o.z + s.z; s.w = o.w + s.w;
+      }
+      *c = s;
+    }
+    return;
+  }
   for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
     const int m = (int)(idx / N), n = (int)(idx - (long)m * N);
     float s = 0.f;
