@@ -67,6 +67,7 @@ struct EpiArgs {
   int ks_tiles, ks_len;
   long ks_slab;
   int no_prefetch;      // A/B switch (mv_gemm_force_variant 2567): the 8-phase epilogue loads each quadrant's aux tile itself
+  int glds_dma;         // A/B switch (2565): the 8-phase kernel stages its slots with global_load_lds (round 2) instead of buffer_load ... lds
   int eager_waits;      // A/B switch (2566): the round-1 wait placement of the 8-phase main loop (whole next K-tile at phases 4 / 8)
 };
 
@@ -978,7 +979,7 @@ typedef __attribute__((ext_vector_type(4))) int i32x4;
 constexpr int NT_BF16 = 0, NT_I8 = 1, NT_F16 = 2;
 typedef __attribute__((ext_vector_type(8))) _Float16 f16x8;
 
-template <int EPI, typename CT, int OPK = NT_BF16, bool KSPLIT = false>
+template <int EPI, typename CT, int OPK = NT_BF16, bool KSPLIT = false, bool BUFDMA = true>
 __global__ __launch_bounds__(512, 2) void gemm_nt_8phase_kernel(const bf16_t* __restrict__ A, int lda,
                                                                 const bf16_t* __restrict__ B, int ldb, CT* __restrict__ C,
                                                                 int ldc, int M, int N, int K, int tiles_n, EpiArgs ep,
@@ -1030,13 +1031,33 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_8phase_kernel(const bf16_t* __
     ps[P8_BQ0][i] = (unsigned)rb0 * (unsigned)ldb + ch * 8;
     ps[P8_BQ1][i] = (unsigned)rb1 * (unsigned)ldb + ch * 8;
   }
-  char* const wave_lds = smem + wave * 2048;
+  // the wave's staging destination as a provably wave-uniform value: the DMA's LDS base goes to M0 by scalar arithmetic
+  char* const wave_lds = smem + __builtin_amdgcn_readfirstlane(wave) * 2048;
+  // BUFDMA (round 3, default): the pieces are buffer_load_dwordx4 ... offen lds -- a wave-uniform descriptor (4 SGPRs) + the lane's
+  // 32-bit byte offset (constant over the K loop) + the K-tile's byte offset in an SGPR -- instead of global_load_lds_dwordx4 with
+  // a 64-bit per-lane address: no address arithmetic per piece, 16 fewer address VGPRs (the kernel's 10 spilled VGPRs are gone),
+  // and a cheaper request: +3...9 % on every ViT-B shape, 38.40 -> 37.67 ms in the step (NT_VARIANTS=2565,0 tools/ab_step.py;
+  // force 2565 = the global_load_lds form).  The descriptor's extent is the whole operand (rows are clamped, never beyond it).
+  const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(A), (short)0, (int)((unsigned)M * (unsigned)lda * 2u), 0x00020000);
+  const __amdgpu_buffer_rsrc_t rsB = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(B), (short)0, (int)((unsigned)N * (unsigned)ldb * 2u), 0x00020000);
+  constexpr bool buf_dma = BUFDMA;
 #define P8_STAGE(buf_, slot_, kt_)                                                      \
   {                                                                                     \
     char* l_ = wave_lds + ((buf_) * 4 + (slot_)) * P8_SLOT;                             \
-    const bf16_t* g_ = (((slot_) == P8_AQ0 || (slot_) == P8_AQ1) ? A : B) + (kt_) * 64; \
-    glds16(g_ + ps[slot_][0], l_);                                                      \
-    glds16(g_ + ps[slot_][1], l_ + 1024);                                               \
+    if constexpr (buf_dma) {                                                            \
+      const int so_ = (kt_) * 128;                                                      \
+      if ((slot_) == P8_AQ0 || (slot_) == P8_AQ1) {                                     \
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, LDS_PTR(void, l_), 16, (int)(ps[slot_][0] * 2u), so_, 0, 0);        \
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, LDS_PTR(void, l_ + 1024), 16, (int)(ps[slot_][1] * 2u), so_, 0, 0); \
+      } else {                                                                          \
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsB, LDS_PTR(void, l_), 16, (int)(ps[slot_][0] * 2u), so_, 0, 0);        \
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsB, LDS_PTR(void, l_ + 1024), 16, (int)(ps[slot_][1] * 2u), so_, 0, 0); \
+      }                                                                                 \
+    } else {                                                                            \
+      const bf16_t* g_ = (((slot_) == P8_AQ0 || (slot_) == P8_AQ1) ? A : B) + (kt_) * 64; \
+      glds16(g_ + ps[slot_][0], l_);                                                    \
+      glds16(g_ + ps[slot_][1], l_ + 1024);                                             \
+    }                                                                                   \
   }
 
   f32x4 acc[8][4];
@@ -2057,6 +2078,10 @@ int launch_nt(const void* A, int lda, const void* B, int ldb, void* C, int ldc, 
     force = 0;
     ep.no_prefetch = 1;
   }
+  if (force == 2565) {                                   // automatic dispatch, global_load_lds staging in the 8-phase kernel (A/B)
+    force = 0;
+    ep.glds_dma = 1;
+  }
   if (force == 2566) {                                   // automatic dispatch, round-1 wait placement in the 8-phase main loop (A/B)
     force = 0;
     ep.eager_waits = 1;
@@ -2089,6 +2114,15 @@ int launch_nt(const void* A, int lda, const void* B, int ldb, void* C, int ldc, 
         MV_CHECK_LAUNCH();
         return MV_OK;
       }
+    }
+    if (ep.glds_dma) {
+      static const int ab = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_nt_8phase_kernel<EPI, CT, NT_BF16, false, false>),
+                                                hipFuncAttributeMaxDynamicSharedMemorySize, P8_SMEM) == hipSuccess ? 0 : -1;
+      if (ab) return MV_ERR_LAUNCH;
+      gemm_nt_8phase_kernel<EPI, CT, NT_BF16, false, false><<<full + 2 * (tiles - full), 512, P8_SMEM, s>>>(
+          (const bf16_t*)A, lda, (const bf16_t*)B, ldb, (CT*)C, ldc, M, N, K, t2n, ep, full, 0);
+      MV_CHECK_LAUNCH();
+      return MV_OK;
     }
     gemm_nt_8phase_kernel<EPI, CT><<<full + 2 * (tiles - full), 512, P8_SMEM, s>>>(
         (const bf16_t*)A, lda, (const bf16_t*)B, ldb, (CT*)C, ldc, M, N, K, t2n, ep, full, 0);
@@ -2314,7 +2348,7 @@ extern "C" int mv_gemm_nt_i8(const void* A, int lda, const void* B, int ldb, voi
 
 extern "C" int mv_gemm_force_variant(int nt_variant, int tn_variant) {
   const bool nt_ok = nt_variant == 0 || nt_variant == 128 || nt_variant == 256 || nt_variant == 2564 ||
-                     nt_variant == 2568 || nt_variant == 25680 || nt_variant == 2569 || nt_variant == 2567 || nt_variant == 2566;
+                     nt_variant == 2568 || nt_variant == 25680 || nt_variant == 2569 || nt_variant == 2567 || nt_variant == 2566 || nt_variant == 2565;
   const bool tn_ok = tn_variant == 0 || tn_variant == 128 || tn_variant == 256;
   MV_REQUIRE(nt_ok && tn_ok, MV_ERR_UNSUPPORTED);
   g_force_nt.store(nt_variant, std::memory_order_relaxed);
