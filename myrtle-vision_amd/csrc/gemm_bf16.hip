@@ -1782,7 +1782,7 @@ struct TnSeg {
   int tiles;
   int a[6], b[6];
 };
-template <int S, bool SEG = false>
+template <int S, bool SEG = false, bool BUFDMA = true>
 __global__ __launch_bounds__(512, 2) void gemm_tn_ring_kernel(const bf16_t* __restrict__ A, int lda,
                                                               const bf16_t* __restrict__ B, int ldb, float* __restrict__ C,
                                                               long ldc, long slab_stride, int M, int N, int Kc, int tiles_n,
@@ -1801,8 +1801,9 @@ __global__ __launch_bounds__(512, 2) void gemm_tn_ring_kernel(const bf16_t* __re
   float* Cs = C + (long)split * slab_stride;
 
   // wave w stages rows [8 (w&3), +8) of panel (w>>2) of both operands: 2 + 2 wave-instructions of 4 rows x 256 B
-  const bf16_t* pa[2];
-  const bf16_t* pb[2];
+  // staging sources as 32-bit BYTE offsets from A / B (buffer-descriptor DMA, bufdma16_hidden): lane part here, the stage's
+  // row offset in an SGPR
+  unsigned pa[2], pb[2];
 #pragma unroll
   for (int i = 0; i < 2; ++i) {
     const int row = 8 * (wave & 3) + 4 * i + (lane >> 4);
@@ -1811,10 +1812,11 @@ __global__ __launch_bounds__(512, 2) void gemm_tn_ring_kernel(const bf16_t* __re
     // SEG: a segment is M (N) columns wide, the row stride covers all six
     const int wa = SEG ? ((M + 7) & ~7) : lda, wb = SEG ? ((N + 7) & ~7) : ldb;
     const int ca = (m0 + col + 8 <= wa) ? m0 + col : 0, cb = (n0 + col + 8 <= wb) ? n0 + col : 0;
-    pa[i] = A + (long)((SEG ? 0 : kt0 * BKR) + row) * lda + ca;
-    pb[i] = B + (long)((SEG ? 0 : kt0 * BKR) + row) * ldb + cb;
+    pa[i] = 2u * ((unsigned)row * (unsigned)lda + (unsigned)ca);
+    pb[i] = 2u * ((unsigned)row * (unsigned)ldb + (unsigned)cb);
   }
   char* const wave_lds = smem + (wave >> 2) * 8192 + 8 * (wave & 3) * 256;
+  const mv_srd_t rsA = mv_make_srd(A, 0xFFFFFFFCu), rsB = mv_make_srd(B, 0xFFFFFFFCu);   // whole-operand extents (< 4 GiB: checked by the host)
   const long astep = (long)BKR * lda, bstep = (long)BKR * ldb;
   // SEG: running (segment, stage-in-segment) of the NEXT stage to issue; stages are issued strictly in order
   int seg_s = SEG ? kt0 / seg.tiles : 0, seg_r = SEG ? kt0 - seg_s * seg.tiles : 0;
@@ -1823,9 +1825,17 @@ __global__ __launch_bounds__(512, 2) void gemm_tn_ring_kernel(const bf16_t* __re
   {                                                                                    \
     char* la_ = wave_lds + (slot_) * RSTAGE_BYTES;                                     \
     char* lb_ = la_ + 16384;                                                           \
-    const long ao_ = SEG ? seg_ao : (kt_) * astep, bo_ = SEG ? seg_bo : (kt_) * bstep; \
-    glds16_hidden(pa[0] + ao_, la_);   glds16_hidden(pa[1] + ao_, la_ + 1024);         \
-    glds16_hidden(pb[0] + bo_, lb_);   glds16_hidden(pb[1] + bo_, lb_ + 1024);         \
+    const unsigned ao_ = 2u * (unsigned)(SEG ? seg_ao : (kt0 + (kt_)) * astep);         \
+    const unsigned bo_ = 2u * (unsigned)(SEG ? seg_bo : (kt0 + (kt_)) * bstep);         \
+    if constexpr (BUFDMA) {                                                            \
+      bufdma16_hidden(rsA, pa[0], ao_, la_);   bufdma16_hidden(rsA, pa[1], ao_, la_ + 1024);   \
+      bufdma16_hidden(rsB, pb[0], bo_, lb_);   bufdma16_hidden(rsB, pb[1], bo_, lb_ + 1024);   \
+    } else {                                     /* round-2 form: 64-bit lane addresses (A/B: TN force 2565) */ \
+      const char* ga_ = reinterpret_cast<const char*>(A) + ao_;                        \
+      const char* gb_ = reinterpret_cast<const char*>(B) + bo_;                        \
+      glds16_hidden(ga_ + pa[0], la_);   glds16_hidden(ga_ + pa[1], la_ + 1024);       \
+      glds16_hidden(gb_ + pb[0], lb_);   glds16_hidden(gb_ + pb[1], lb_ + 1024);       \
+    }                                                                                  \
     if constexpr (SEG) {                                                               \
       seg_ao += astep;                                                                 \
       seg_bo += bstep;                                                                 \
@@ -2234,6 +2244,7 @@ extern "C" int mv_gemm_tn_bf16_x6(const void* A6, const void* B6, float* C, int 
                                   size_t workspace_bytes, mv_stream_t stream) {
   MV_REQUIRE(M > 0 && N > 0 && rows > 0, MV_ERR_SHAPE);
   MV_REQUIRE(M % 8 == 0 && N % 8 == 0 && rows % BKR == 0, MV_ERR_UNSUPPORTED);
+  MV_REQUIRE((long)rows * 6 * M * 2 < (1L << 32) && (long)rows * 6 * N * 2 < (1L << 32), MV_ERR_UNSUPPORTED);   // 32-bit byte offsets of the DMA
   MV_REQUIRE(mv_aligned16(A6) && mv_aligned16(B6) && mv_aligned16(C) && mv_aligned16(workspace), MV_ERR_ALIGN);
   const int Kc = 6 * rows;
   MV_REQUIRE(workspace_bytes >= mv_gemm_tn_workspace_bytes(M, N, Kc), MV_ERR_WORKSPACE);
@@ -2349,7 +2360,7 @@ extern "C" int mv_gemm_nt_i8(const void* A, int lda, const void* B, int ldb, voi
 extern "C" int mv_gemm_force_variant(int nt_variant, int tn_variant) {
   const bool nt_ok = nt_variant == 0 || nt_variant == 128 || nt_variant == 256 || nt_variant == 2564 ||
                      nt_variant == 2568 || nt_variant == 25680 || nt_variant == 2569 || nt_variant == 2567 || nt_variant == 2566 || nt_variant == 2565;
-  const bool tn_ok = tn_variant == 0 || tn_variant == 128 || tn_variant == 256;
+  const bool tn_ok = tn_variant == 0 || tn_variant == 128 || tn_variant == 256 || tn_variant == 2565;
   MV_REQUIRE(nt_ok && tn_ok, MV_ERR_UNSUPPORTED);
   g_force_nt.store(nt_variant, std::memory_order_relaxed);
   g_force_tn.store(tn_variant, std::memory_order_relaxed);
@@ -2421,7 +2432,7 @@ extern "C" int mv_gemm_tn_bf16(const void* A, int lda, const void* B, int ldb, f
     }
     return MV_OK;
   }
-  const bool ring = tn_use_ring(M, N, Kc);
+  const bool ring = tn_use_ring(M, N, Kc) && (long)Kc * lda * 2 < (1L << 32) && (long)Kc * ldb * 2 < (1L << 32);   // 32-bit byte offsets
   // (An 8-phase port of this kernel -- the gemm_nt_8phase_kernel schedule with [64 kc][128 col] slots -- measured 10-15 %
   // SLOWER than the ring in the same process, 851 vs 968 and 909 vs 1031 TFLOP/s: the ring's DMA rows are whole
   // 256-byte lines already, so the port only added barriers and halved the bytes in flight.  Not kept.)
@@ -2432,7 +2443,14 @@ extern "C" int mv_gemm_tn_bf16(const void* A, int lda, const void* B, int ldb, f
   if (ring) {
     static const int a4 = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_tn_ring_kernel<4>),
                                               hipFuncAttributeMaxDynamicSharedMemorySize, 4 * RSTAGE_BYTES) == hipSuccess ? 0 : -1;
-    if (a4) return MV_ERR_LAUNCH;
+    static const int a4g = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_tn_ring_kernel<4, false, false>),
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, 4 * RSTAGE_BYTES) == hipSuccess ? 0 : -1;
+    if (a4 || a4g) return MV_ERR_LAUNCH;
+    if (g_force_tn.load(std::memory_order_relaxed) == 2565)
+      gemm_tn_ring_kernel<4, false, false><<<tiles_mn * pl.splits, 512, 4 * RSTAGE_BYTES, s>>>(
+          (const bf16_t*)A, lda, (const bf16_t*)B, ldb, direct ? C : workspace, direct ? (long)ldc : (long)N,
+          direct ? 0 : slab_stride, M, N, Kc, pl.tiles_n, tiles_mn, pl.steps_per_split, TnSeg{});
+    else
     gemm_tn_ring_kernel<4><<<tiles_mn * pl.splits, 512, 4 * RSTAGE_BYTES, s>>>(
         (const bf16_t*)A, lda, (const bf16_t*)B, ldb, direct ? C : workspace, direct ? (long)ldc : (long)N,
         direct ? 0 : slab_stride, M, N, Kc, pl.tiles_n, tiles_mn, pl.steps_per_split, TnSeg{});

@@ -143,6 +143,24 @@ static __global__ void mv_zero_f32_kernel(float* __restrict__ p, int n) {
   for (int i = threadIdx.x; i < n; i += blockDim.x) p[i] = 0.f;
 }
 
+// The same LDS-DMA piece as buffer_load_dwordx4 ... offen lds, hidden from the compiler like glds16_hidden: a wave-uniform buffer
+// descriptor (4 SGPRs: base, extent, raw-buffer format word) + the lane's 32-bit BYTE offset + a wave-uniform byte offset in an
+// SGPR.  No 64-bit per-lane address exists, so a kernel keeps one 32-bit offset per staging row instead of a pointer pair and
+// advances along the contraction with scalar arithmetic; measured on the 8-phase NT kernel: +3...9 % per ViT-B shape.
+typedef __attribute__((ext_vector_type(4))) int mv_srd_t;
+__device__ __forceinline__ mv_srd_t mv_make_srd(const void* base, unsigned bytes) {
+  const unsigned long long p = (unsigned long long)base;
+  return (mv_srd_t){(int)(unsigned)p, (int)((unsigned)(p >> 32) & 0xffffu), (int)bytes, 0x00020000};
+}
+__device__ __forceinline__ void bufdma16_hidden(mv_srd_t srd, unsigned voff, unsigned soff, void* lds_wave_base) {
+  unsigned keep;
+  const unsigned dst = __builtin_amdgcn_readfirstlane((unsigned)(size_t)lds_wave_base);
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %4 offen lds\n\ts_mov_b32 m0, %0"
+               : "=&s"(keep)
+               : "v"(voff), "s"(srd), "s"(dst), "s"(soff)
+               : "memory");
+}
+
 // out[c] (+)= sum over rows r of partial[r * ld + c]: the second stage of the deterministic two-stage reductions
 // (LayerNorm dgamma/dbeta/dx column sums, bias-gradient column sums).  One 1024-thread block per 16 columns (so even
 // a 768-column reduction spreads over 48+ CUs): lane l takes column l&15 and row phase l>>4 of its wave, the 64 row
