@@ -66,7 +66,7 @@ const char* mv_error_string(int code);
 /* number of bytes of workspace mv_gemm_tn_bf16 / mv_layernorm_bwd want for these sizes */
 size_t mv_gemm_tn_workspace_bytes(int M, int N, int Kc);
 /* Tuning / test hook (no reference counterpart): force a kernel variant for the following mv_gemm_nt_bf16 (0 auto | 128 | 256 | 2564 ring | 2568
- * 8-phase | 2569 persistent 8-phase | 2567 automatic dispatch with the 8-phase epilogue's aux prefetch off | 2566 automatic dispatch with the round-1 wait placement of the 8-phase main loop | 2565 automatic dispatch with global_load_lds instead of buffer_load ... lds staging in the 8-phase kernel) and mv_gemm_tn_bf16 (0 auto | 128 | 256 ring) calls of this process; a forced variant that cannot run a
+ * 8-phase | 2569 persistent 8-phase | 2567 automatic dispatch with the 8-phase epilogue's aux prefetch off | 2565 automatic dispatch with global_load_lds instead of buffer_load ... lds staging in the 8-phase kernel) and mv_gemm_tn_bf16 (0 auto | 128 | 256 ring) calls of this process; a forced variant that cannot run a
  * shape (alignment of K) falls back to the automatic choice.  Results are identical up to fp32 summation order. */
 int mv_gemm_force_variant(int nt_variant, int tn_variant);
 size_t mv_layernorm_bwd_workspace_bytes(int rows, int dim);

@@ -31,6 +31,7 @@
 #include "mv_common.h"
 
 #include <atomic>
+#include <type_traits>
 
 #ifndef MV_ABLATE
 #define MV_ABLATE 0   // diagnostic builds only (tools/ablate_gemm.sh); 0 in the product
@@ -68,7 +69,6 @@ struct EpiArgs {
   long ks_slab;
   int no_prefetch;      // A/B switch (mv_gemm_force_variant 2567): the 8-phase epilogue loads each quadrant's aux tile itself
   int glds_dma;         // A/B switch (2565): the 8-phase kernel stages its slots with global_load_lds (round 2) instead of buffer_load ... lds
-  int eager_waits;      // A/B switch (2566): the round-1 wait placement of the 8-phase main loop (whole next K-tile at phases 4 / 8)
 };
 
 // 16-byte output store of the NT epilogues
@@ -1003,7 +1003,7 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_8phase_kernel(const bf16_t* __
     t = full_tiles + (idx >> 1);
     half = idx & 1;
   }
-  const bool is_half = half >= 0;                // wave-uniform
+  const bool is_half_rt = half >= 0;             // wave-uniform
   if constexpr (KSPLIT) {                        // K = the slice length; the bias rides on slice 0 only
     const int ks = t / ep.ks_tiles;
     t -= ks * ep.ks_tiles;
@@ -1012,6 +1012,12 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_8phase_kernel(const bf16_t* __
     C += (long)ks * ep.ks_slab;
     if (ks) ep.bias = nullptr;
   }
+  // Whole tiles and half items run the same text with ``is_half`` a COMPILE-TIME constant (a generic lambda instantiated twice,
+  // selected once per workgroup): as a run-time flag it put twelve scalar branches into every two K-tiles of the main loop --
+  // around the A_q1 reads, the phase-3/4 MFMA clusters, the staging of A_q1 and the per-slot waits -- each a basic-block boundary
+  // the scheduler could not move reads or waits across.
+  auto body = [&](auto half_tag) {
+  constexpr bool is_half = decltype(half_tag)::value;
   const int m0 = (t / tiles_n) * BM2 + (is_half ? 128 * half : 0), n0 = (t % tiles_n) * BN2;
 
   // staging: wave w moves pieces 2w and 2w+1 of a slot (1 KiB = 8 slot rows of 128 B each); lane l -> row l>>3, 16-byte
@@ -1135,7 +1141,8 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_8phase_kernel(const bf16_t* __
 // In the steady state exactly five slots (10 DMA instructions) have been issued after the slot(s) being waited for at every one of
 // those points, so every wait is vmcnt(10): FIVE slots (80 KiB) stay in flight across the waits instead of three, with the same
 // staging times (the WAR argument is unchanged) and the same 128 KiB of LDS.  W1_/W2_/W4_ are the counts of a full tile; half items
-// (no A_q1 slot, three slots per K-tile) keep the round-1 waits (H4_), as does a launch with ep.eager_waits (A/B switch 2566).
+// (no A_q1 slot, three slots per K-tile) keep the round-1 waits (H4_).  (Measured against the round-1 placement with a run-time
+// switch, since removed: +0...3.8 % per shape, 37.16 vs 37.27 ms in the step.)
 #define P8_WAIT(N_) asm volatile("s_waitcnt vmcnt(" #N_ ")" ::: "memory");
 #define P8_KTILE(d_, ST_, first_slot_buf_, first_slot_kt_, next_buf_, next_kt_, W1_, W2_, W4_, H4_, STAGE_FIRST_)        \
   {                                                                                                          \
@@ -1176,7 +1183,7 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_8phase_kernel(const bf16_t* __
     P8_BAR()                                                                                                 \
   }
 
-  const bool lazy = !is_half && !ep.eager_waits;          // wave-uniform
+  constexpr bool lazy = !is_half;
   P8_STAGE(0, P8_BQ0, 0) P8_STAGE(0, P8_AQ0, 0) P8_STAGE(0, P8_BQ1, 0) if (!is_half) P8_STAGE(0, P8_AQ1, 0)
   P8_STAGE(1, P8_BQ0, 1) P8_STAGE(1, P8_AQ0, 1) P8_STAGE(1, P8_BQ1, 1)
   if (lazy) { P8_WAIT(10) } else { P8_WAIT(6) }           // B_q0, A_q0 of K-tile 0 landed | the whole K-tile 0
@@ -1280,6 +1287,9 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_8phase_kernel(const bf16_t* __
       for (int j = 0; j < 4; ++j) acc2[i][j] = acc[4 + i][j];
   }
   nt_epilogue<EPI, CT>(acc2, C, ldc, M, N, m0 + 128 * wm, n0 + 128 * (wn >> 1), 1, wn & 1, lane, ep);
+  };
+  if (is_half_rt) body(std::true_type{});
+  else body(std::false_type{});
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -2092,10 +2102,6 @@ int launch_nt(const void* A, int lda, const void* B, int ldb, void* C, int ldc, 
     force = 0;
     ep.glds_dma = 1;
   }
-  if (force == 2566) {                                   // automatic dispatch, round-1 wait placement in the 8-phase main loop (A/B)
-    force = 0;
-    ep.eager_waits = 1;
-  }
   const bool ring_ok = K > 0 && K % BKR == 0;
   const bool ring_pick = ring_ok && ((long)t2m * t2n >= 1024 || (K >= 2048 && (long)t2m * t2n >= 256));
   const bool p8_ok = K >= 128 && K % 128 == 0 && (long)M * lda < (1L << 31) && (long)N * ldb < (1L << 31);
@@ -2359,7 +2365,7 @@ extern "C" int mv_gemm_nt_i8(const void* A, int lda, const void* B, int ldb, voi
 
 extern "C" int mv_gemm_force_variant(int nt_variant, int tn_variant) {
   const bool nt_ok = nt_variant == 0 || nt_variant == 128 || nt_variant == 256 || nt_variant == 2564 ||
-                     nt_variant == 2568 || nt_variant == 25680 || nt_variant == 2569 || nt_variant == 2567 || nt_variant == 2566 || nt_variant == 2565;
+                     nt_variant == 2568 || nt_variant == 25680 || nt_variant == 2569 || nt_variant == 2567 || nt_variant == 2565;
   const bool tn_ok = tn_variant == 0 || tn_variant == 128 || tn_variant == 256 || tn_variant == 2565;
   MV_REQUIRE(nt_ok && tn_ok, MV_ERR_UNSUPPORTED);
   g_force_nt.store(nt_variant, std::memory_order_relaxed);
