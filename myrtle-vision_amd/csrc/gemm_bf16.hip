@@ -633,7 +633,7 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(const bf16_t* __restric
 // ------------------------------------------------------------------------------------------------
 // glds16 (LDS-DMA, 16 B per lane): mv_common.h
 
-template <int EPI, typename CT>
+template <int EPI, typename CT, bool BUFDMA = true>
 __global__ __launch_bounds__(256, 2) void gemm_nt_glds_kernel(const bf16_t* __restrict__ A, int lda,
                                                               const bf16_t* __restrict__ B, int ldb, CT* __restrict__ C,
                                                               int ldc, int M, int N, int K, int tiles_n, EpiArgs ep) {
@@ -646,26 +646,41 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_glds_kernel(const bf16_t* __re
   // Wave w stages rows [32w, 32w+32) of both tiles: 4 wave-instructions of 8 rows x 128 B each.  Lane L lands at
   // LDS (row 8i + L/8, physical chunk L%8) and therefore fetches LOGICAL chunk (L%8) ^ swz(row) of that row.
   // Rows beyond M / N are clamped to the last valid row (their products only reach outputs that are never stored).
-  const bf16_t* pa[4];
-  const bf16_t* pb[4];
+  // BUFDMA (round 3; the dispatcher checks that the operands' byte extents fit 32 bits): buffer_load ... lds with a wave-uniform
+  // descriptor, the lane's 32-bit byte offset and the K offset in an SGPR, as in gemm_nt_8phase_kernel; else 64-bit lane pointers
+  unsigned pa[4], pb[4];                       // BUFDMA: element offsets from A / B
+  const bf16_t* qa[4];                         // else: lane pointers
+  const bf16_t* qb[4];
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
     const int row = 32 * wave + 8 * i + (lane >> 3);
     const int ch = (lane & 7) ^ (((row >> 1) & 3) << 1);
     const int ar = m0 + row < M ? m0 + row : M - 1, br = n0 + row < N ? n0 + row : N - 1;
-    pa[i] = A + (long)ar * lda + ch * 8;
-    pb[i] = B + (long)br * ldb + ch * 8;
+    pa[i] = (unsigned)ar * (unsigned)lda + ch * 8;
+    pb[i] = (unsigned)br * (unsigned)ldb + ch * 8;
+    qa[i] = A + (long)ar * lda + ch * 8;
+    qb[i] = B + (long)br * ldb + ch * 8;
   }
-  char* const wave_lds = smem + 32 * wave * 128;
+  char* const wave_lds = smem + 32 * __builtin_amdgcn_readfirstlane(wave) * 128;
+  const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(A), (short)0, (int)((unsigned)M * (unsigned)lda * 2u), 0x00020000);
+  const __amdgpu_buffer_rsrc_t rsB = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(B), (short)0, (int)((unsigned)N * (unsigned)ldb * 2u), 0x00020000);
 #define NT_ISSUE(stage_, kt_)                                                          \
   {                                                                                    \
     char* la_ = wave_lds + (stage_) * STAGE_BYTES;                                     \
     char* lb_ = la_ + BM * BK * 2;                                                     \
-    const int ko_ = (kt_) * BK;                                                        \
-    glds16(pa[0] + ko_, la_);          glds16(pa[1] + ko_, la_ + 1024);                \
-    glds16(pa[2] + ko_, la_ + 2048);   glds16(pa[3] + ko_, la_ + 3072);                \
-    glds16(pb[0] + ko_, lb_);          glds16(pb[1] + ko_, lb_ + 1024);                \
-    glds16(pb[2] + ko_, lb_ + 2048);   glds16(pb[3] + ko_, lb_ + 3072);                \
+    if constexpr (BUFDMA) {                                                            \
+      const int so_ = (kt_) * BK * 2;                                                  \
+      _Pragma("unroll") for (int i_ = 0; i_ < 4; ++i_) {                               \
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, LDS_PTR(void, la_ + 1024 * i_), 16, (int)(pa[i_] * 2u), so_, 0, 0); \
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsB, LDS_PTR(void, lb_ + 1024 * i_), 16, (int)(pb[i_] * 2u), so_, 0, 0); \
+      }                                                                                \
+    } else {                                                                           \
+      const int ko_ = (kt_) * BK;                                                      \
+      glds16(qa[0] + ko_, la_);          glds16(qa[1] + ko_, la_ + 1024);              \
+      glds16(qa[2] + ko_, la_ + 2048);   glds16(qa[3] + ko_, la_ + 3072);              \
+      glds16(qb[0] + ko_, lb_);          glds16(qb[1] + ko_, lb_ + 1024);              \
+      glds16(qb[2] + ko_, lb_ + 2048);   glds16(qb[3] + ko_, lb_ + 3072);              \
+    }                                                                                  \
   }
 
   f32x4 acc[4][4];
@@ -1710,27 +1725,28 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_glds_kernel(const bf16_t* __re
   float* Cs = C + (long)split * slab_stride;
 
   // wave w stages kc rows [16w, 16w+16) of both tiles: 4 wave-instructions of 4 rows x 256 B
-  const bf16_t* pa[4];
-  const bf16_t* pb[4];
+  unsigned pa[4], pb[4];                       // BYTE offsets from A / B (buffer-descriptor DMA; extents checked by the host)
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
     const int row = 16 * wave + 4 * i + (lane >> 4);
     const int ch = (lane & 15) ^ (((row & 3) << 2) | ((row >> 2) & 3));
     const int ca = (m0 + ch * 8 + 8 <= lda) ? m0 + ch * 8 : 0, cb = (n0 + ch * 8 + 8 <= ldb) ? n0 + ch * 8 : 0;
-    pa[i] = A + (long)(kt0 * BK + row) * lda + ca;
-    pb[i] = B + (long)(kt0 * BK + row) * ldb + cb;
+    pa[i] = 2u * ((unsigned)(kt0 * BK + row) * (unsigned)lda + (unsigned)ca);
+    pb[i] = 2u * ((unsigned)(kt0 * BK + row) * (unsigned)ldb + (unsigned)cb);
   }
-  char* const wave_lds = smem + 16 * wave * 256;
-  const long astep = (long)BK * lda, bstep = (long)BK * ldb;
+  char* const wave_lds = smem + 16 * __builtin_amdgcn_readfirstlane(wave) * 256;
+  const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(A), (short)0, (int)0xFFFFFFFCu, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rsB = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(B), (short)0, (int)0xFFFFFFFCu, 0x00020000);
+  const unsigned astep = 2u * BK * (unsigned)lda, bstep = 2u * BK * (unsigned)ldb;      // bytes per K-step
 #define TN_ISSUE(stage_, kt_)                                                          \
   {                                                                                    \
     char* la_ = wave_lds + (stage_) * STAGE_BYTES;                                     \
     char* lb_ = la_ + BK * BM * 2;                                                     \
-    const long ao_ = (kt_) * astep, bo_ = (kt_) * bstep;                               \
-    glds16(pa[0] + ao_, la_);          glds16(pa[1] + ao_, la_ + 1024);                \
-    glds16(pa[2] + ao_, la_ + 2048);   glds16(pa[3] + ao_, la_ + 3072);                \
-    glds16(pb[0] + bo_, lb_);          glds16(pb[1] + bo_, lb_ + 1024);                \
-    glds16(pb[2] + bo_, lb_ + 2048);   glds16(pb[3] + bo_, lb_ + 3072);                \
+    const int ao_ = (int)((unsigned)(kt_) * astep), bo_ = (int)((unsigned)(kt_) * bstep); \
+    _Pragma("unroll") for (int i_ = 0; i_ < 4; ++i_) {                                 \
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, LDS_PTR(void, la_ + 1024 * i_), 16, (int)pa[i_], ao_, 0, 0); \
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsB, LDS_PTR(void, lb_ + 1024 * i_), 16, (int)pb[i_], bo_, 0, 0); \
+    }                                                                                  \
   }
 
   f32x4 acc[4][4];
@@ -2083,6 +2099,7 @@ template <int EPI, typename CT>
 int launch_nt(const void* A, int lda, const void* B, int ldb, void* C, int ldc, int M, int N, int K, EpiArgs ep,
               hipStream_t s) {
   static const int attr = set_smem(gemm_nt_kernel<EPI, CT>) | set_smem(gemm_nt_glds_kernel<EPI, CT>) |
+                          set_smem(gemm_nt_glds_kernel<EPI, CT, false>) |
                           (hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_nt_glds256_kernel<EPI, CT>),
                                                hipFuncAttributeMaxDynamicSharedMemorySize, SMEM2_BYTES) == hipSuccess ? 0 : -1);
   if (attr != 0) return MV_ERR_LAUNCH;
@@ -2154,9 +2171,14 @@ int launch_nt(const void* A, int lda, const void* B, int ldb, void* C, int ldc, 
   } else if (force == 256 && K > 0 && K % BK == 0)
     gemm_nt_glds256_kernel<EPI, CT><<<t2m * t2n, 512, SMEM2_BYTES, s>>>((const bf16_t*)A, lda, (const bf16_t*)B, ldb,
                                                                          (CT*)C, ldc, M, N, K, t2n, ep);
-  else if (K > 0 && K % BK == 0)
-    gemm_nt_glds_kernel<EPI, CT><<<tiles_m * tiles_n, 256, SMEM_BYTES, s>>>((const bf16_t*)A, lda, (const bf16_t*)B, ldb,
-                                                                             (CT*)C, ldc, M, N, K, tiles_n, ep);
+  else if (K > 0 && K % BK == 0) {
+    if ((long)M * lda < (1L << 31) && (long)N * ldb < (1L << 31))       // 32-bit byte offsets of the buffer-descriptor DMA
+      gemm_nt_glds_kernel<EPI, CT><<<tiles_m * tiles_n, 256, SMEM_BYTES, s>>>((const bf16_t*)A, lda, (const bf16_t*)B, ldb,
+                                                                               (CT*)C, ldc, M, N, K, tiles_n, ep);
+    else
+      gemm_nt_glds_kernel<EPI, CT, false><<<tiles_m * tiles_n, 256, SMEM_BYTES, s>>>((const bf16_t*)A, lda, (const bf16_t*)B, ldb,
+                                                                                      (CT*)C, ldc, M, N, K, tiles_n, ep);
+  }
   else
     gemm_nt_kernel<EPI, CT><<<tiles_m * tiles_n, 256, SMEM_BYTES, s>>>((const bf16_t*)A, lda, (const bf16_t*)B, ldb,
                                                                         (CT*)C, ldc, M, N, K, tiles_n, ep);
@@ -2460,7 +2482,7 @@ extern "C" int mv_gemm_tn_bf16(const void* A, int lda, const void* B, int ldb, f
     gemm_tn_ring_kernel<4><<<tiles_mn * pl.splits, 512, 4 * RSTAGE_BYTES, s>>>(
         (const bf16_t*)A, lda, (const bf16_t*)B, ldb, direct ? C : workspace, direct ? (long)ldc : (long)N,
         direct ? 0 : slab_stride, M, N, Kc, pl.tiles_n, tiles_mn, pl.steps_per_split, TnSeg{});
-  } else if (Kc > 0 && Kc % BK == 0)
+  } else if (Kc > 0 && Kc % BK == 0 && (long)Kc * lda * 2 < (1L << 32) && (long)Kc * ldb * 2 < (1L << 32))
     gemm_tn_glds_kernel<<<tiles_mn * pl.splits, 256, SMEM_BYTES, s>>>(
         (const bf16_t*)A, lda, (const bf16_t*)B, ldb, direct ? C : workspace, direct ? (long)ldc : (long)N,
         direct ? 0 : slab_stride, M, N, Kc, pl.tiles_n, tiles_mn, pl.steps_per_split);
