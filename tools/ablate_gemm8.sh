@@ -7,7 +7,7 @@ CS=myrtle-vision_amd/csrc
 if [ "$1" != "run" ]; then
   for m in 8 16; do
     mkdir -p tools/_ablate/o$m
-    for f in layernorm attention gemm_f32 elementwise seg_tail image_prep; do cp myrtle-vision_amd/lib/$f.o tools/_ablate/o$m/; done
+    for f in layernorm attention attention_f32 gemm_f32 elementwise seg_tail image_prep; do cp myrtle-vision_amd/lib/$f.o tools/_ablate/o$m/; done
     hipcc --offload-arch=gfx950 -O3 -fPIC -std=c++17 -I include -DMV_ABLATE=$m -c $CS/gemm_bf16.hip -o tools/_ablate/o$m/gemm_bf16.o
     TL=$(python -c "import importlib.util,os;print(os.path.join(list(importlib.util.find_spec('torch').submodule_search_locations)[0],'lib'))")
     g++ -shared -fPIC -o tools/_ablate/libgemm_ablate$m.so tools/_ablate/o$m/*.o -L$TL -l:libamdhip64.so -Wl,-rpath,$TL:/opt/rocm/lib
