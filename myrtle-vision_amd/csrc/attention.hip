@@ -520,11 +520,11 @@ __device__ __forceinline__ float rowsum16(float v) {
 }
 template <int NW>
 __device__ __forceinline__ void attn_colsum_store(const float* red, float* __restrict__ gout, long D, int tid) {
-  if (tid < 192) {
+  for (int c = tid; c < 192; c += 64 * NW) {              // (64 NW threads call this)
     float t = 0.f;
 #pragma unroll
-    for (int w = 0; w < NW; ++w) t += red[w * 192 + tid];
-    gout[(long)(tid >> 6) * D + (tid & 63)] = t;          // which = tid / 64, d = tid % 64
+    for (int w = 0; w < NW; ++w) t += red[w * 192 + c];
+    gout[(long)(c >> 6) * D + (c & 63)] = t;              // which = c / 64, d = c % 64
   }
 }
 
@@ -729,12 +729,25 @@ __global__ __launch_bounds__(512, 1) void attn_bwd_kernel(const bf16_t* __restri
 // phases between barriers have nothing to overlap with.  This variant keeps the same mathematics and fragment maps but
 // fits two workgroups on a CU: single-buffered Q/dO pair and dS^T (two barriers per query pair instead of one), V
 // trimmed to the 13 real key tiles -> 79,616 B.  Wave w owns key tiles w, w+4, w+8, w+12 (128 accumulator VGPRs).
-__global__ __launch_bounds__(256, 2) void attn_bwd4_kernel(const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ out,
+#ifdef MV_ATTN_TRACE
+// diagnostic build (tools/diag/attn_timeline.py): per-workgroup time stamps (100 MHz s_memrealtime), wave 0 only
+__device__ unsigned long long g_attn_trace[16 * 4096];
+extern "C" int mv_debug_attn_trace(void* dst) {
+  return hipMemcpyFromSymbol(dst, HIP_SYMBOL(g_attn_trace), sizeof(g_attn_trace)) == hipSuccess ? 0 : -1;
+}
+#define ATTN_STAMP(v_) v_ = __builtin_amdgcn_s_memrealtime();
+#define ATTN_ACC(acc_, from_, to_) acc_ += (to_) - (from_);
+#else
+#define ATTN_STAMP(v_)
+#define ATTN_ACC(acc_, from_, to_)
+#endif
+template <int NW>   // waves per workgroup: 4 (256 registers per lane) or 2 (one wave per SIMD: 512)
+__global__ __launch_bounds__(64 * NW, NW / 2) void attn_bwd4_kernel(const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ out,
                                                            const bf16_t* __restrict__ dout, const float* __restrict__ lse,
                                                            bf16_t* __restrict__ dqkv, float* __restrict__ colsum, int N, int H,
                                                            float scale) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  constexpr int NKT = 13, NPK = 224, NPV = 208, NQP = 7, KPW = 4;
+  constexpr int NKT = 13, NPK = 224, NPV = 208, NQP = 7, KPW = (NKT + NW - 1) / NW, NT = 64 * NW;
   char* sK = smem;                           // [224][64] bf16 (rows >= N zero; rows 208..223 exist for the key-pair reads)
   char* sV = sK + NPK * 128;                 // [208][64]
   char* sPair = sV + NPV * 128;              // Q[32][64], dO[32][64]
@@ -752,20 +765,30 @@ __global__ __launch_bounds__(256, 2) void attn_bwd4_kernel(const bf16_t* __restr
   bf16_t* dbase = dqkv + (long)b * N * 3 * D + h * 64;
   const u32x4 zero4 = {0u, 0u, 0u, 0u};
   const float c2 = scale * LOG2E;
+  unsigned long long ts0 = 0, ts1 = 0, ts2 = 0, ta = 0, tb = 0, tc = 0, td = 0, a_s = 0, a_b1 = 0, a_q = 0, a_b2 = 0;
+  ATTN_STAMP(ts0)
 
+#ifdef MV_ATTN_STAGGER
+  // diagnostic: the second workgroup of every CU's first round starts late, so the two resident workgroups run out of phase
+  if (blockIdx.x >= 256 && blockIdx.x < 512)
+    for (int i = 0; i < MV_ATTN_STAGGER; ++i) __builtin_amdgcn_s_sleep(127);
+#endif
   // K, V by DMA (the serialized register path was 112 of this kernel's 313 us: stage_kv_dma)
-  stage_kv_dma(base, D, N, sK, NPK, sV, NPV, wave, 4, lane);
-  for (int idx = tid; idx < NPK * 4; idx += 256) reinterpret_cast<u32x4*>(sDS)[idx] = zero4;   // padding key rows stay 0
-  if (tid < NPK) {
-    const int row = tid;
+  stage_kv_dma(base, D, N, sK, NPK, sV, NPV, wave, NW, lane);
+  // dS^T rows no wave ever writes must read as zero in the dQ phase.  Two waves (192 < N): the 14 key tiles are all written (the
+  // masked keys and wave 1's tile 13 as exact zeros) -- nothing to clear.
+  if (NW == 4)
+    for (int idx = tid; idx < NPK * 4; idx += NT) reinterpret_cast<u32x4*>(sDS)[idx] = zero4;
+  for (int row = tid; row < NPK; row += NT) {
     float l2 = INFINITY;
     if (row < N && !(MV_ATTN_ABLATE & 8)) l2 = lse[((long)b * H + h) * N + row] * LOG2E;
     sLse[row] = l2;
   }
 
-  // pair staging: 2 tiles x 32 rows x 8 chunks = 512 chunks, two per thread
+  // pair staging: 2 tiles x 32 rows x 8 chunks = 512 chunks, PE = 512 / NT per thread (the first half Q, the second dO)
+  constexpr int PE = 512 / NT;
   auto load_pair = [&](int u, int e) -> u32x4 {
-    const int idx = tid + 256 * e;
+    const int idx = tid + NT * e;
     const int which = idx >> 8, row = (idx >> 3) & 31, ch = idx & 7;
     const int q = 32 * u + row;
     const bf16_t* src = which == 0 ? base + ch * 8 : dobase + ch * 8;
@@ -775,7 +798,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd4_kernel(const bf16_t* __restr
     return *reinterpret_cast<const u32x4*>(src + (long)(q < N ? q : N - 1) * ld);
   };
   auto store_pair = [&](int e, u32x4 v) {
-    const int idx = tid + 256 * e;
+    const int idx = tid + NT * e;
     const int which = idx >> 8, row = (idx >> 3) & 31, ch = idx & 7;
     *reinterpret_cast<u32x4*>(sPair + which * 4096 + sw128(row, ch)) = v;
   };
@@ -783,11 +806,12 @@ __global__ __launch_bounds__(256, 2) void attn_bwd4_kernel(const bf16_t* __restr
   // 8 elements of dO (load_pair(u, 1)), loads the same 8 of O, and the row's 8 threads (consecutive lanes) add up.  (Computed
   // for all 208 rows before the loop, this cost 53 of the kernel's 282 us: 16 dependent-latency loads per thread with
   // nothing to hide under.)
-  auto load_o = [&](int u) -> u32x4 {
-    const int q = 32 * u + (tid >> 3);
+  // (the thread's dO chunk e = PE / 2 + j is row (tid >> 3) + (NT / 8) j, chunk tid & 7: the same row and chunk of O)
+  auto load_o = [&](int u, int j) -> u32x4 {
+    const int q = 32 * u + (tid >> 3) + (NT / 8) * j;
     return *reinterpret_cast<const u32x4*>(obase + (long)(q < N ? q : N - 1) * D + (tid & 7) * 8);
   };
-  auto put_delta = [&](int u, u32x4 dov, u32x4 ov) {
+  auto put_delta = [&](int u, int j, u32x4 dov, u32x4 ov) {
     const bf16x8 av = __builtin_bit_cast(bf16x8, dov), bv = __builtin_bit_cast(bf16x8, ov);
     float dl = 0.f;
 #pragma unroll
@@ -795,7 +819,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd4_kernel(const bf16_t* __restr
     dl += __shfl_xor(dl, 1);
     dl += __shfl_xor(dl, 2);
     dl += __shfl_xor(dl, 4);
-    if ((tid & 7) == 0) sDelta[32 * u + (tid >> 3)] = (MV_ATTN_ABLATE & 8) ? 0.f : dl;
+    if ((tid & 7) == 0) sDelta[32 * u + (tid >> 3) + (NT / 8) * j] = (MV_ATTN_ABLATE & 8) ? 0.f : dl;
   };
 
   f32x4 adk[KPW][4], adv[KPW][4];
@@ -808,26 +832,144 @@ __global__ __launch_bounds__(256, 2) void attn_bwd4_kernel(const bf16_t* __restr
     }
 
   {
-    const u32x4 q0 = load_pair(0, 0), d0 = load_pair(0, 1), o0 = load_o(0);
-    store_pair(0, q0);
-    store_pair(1, d0);
-    put_delta(0, d0, o0);
+    u32x4 x0[PE], o0[PE / 2];
+#pragma unroll
+    for (int e = 0; e < PE; ++e) x0[e] = load_pair(0, e);
+#pragma unroll
+    for (int j = 0; j < PE / 2; ++j) o0[j] = load_o(0, j);
+#pragma unroll
+    for (int e = 0; e < PE; ++e) store_pair(e, x0[e]);
+#pragma unroll
+    for (int j = 0; j < PE / 2; ++j) put_delta(0, j, x0[PE / 2 + j], o0[j]);
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // this wave's K/V DMA pieces have landed
   __syncthreads();
+  ATTN_STAMP(ts1)
 
   const char* sQ = sPair;
   const char* sDO = sPair + 4096;
   const int nkt_valid = (N + 15) >> 4;
   f32x4 dqs0 = {0.f, 0.f, 0.f, 0.f}, dqs1 = {0.f, 0.f, 0.f, 0.f};   // running column sums of this wave's two dQ tiles
   for (int u = 0; u < NQP; ++u) {
-    u32x4 nx0 = zero4, nx1 = zero4, nxo = zero4;
+    ATTN_STAMP(ta)
+    u32x4 nx[PE], nxo[PE / 2];
+#pragma unroll
+    for (int e = 0; e < PE; ++e) nx[e] = zero4;
+#pragma unroll
+    for (int j = 0; j < PE / 2; ++j) nxo[j] = zero4;
     if (u + 1 < NQP && !(MV_ATTN_ABLATE & 4)) {
-      nx0 = load_pair(u + 1, 0);
-      nx1 = load_pair(u + 1, 1);
-      nxo = load_o(u + 1);
+#pragma unroll
+      for (int e = 0; e < PE; ++e) nx[e] = load_pair(u + 1, e);
+#pragma unroll
+      for (int j = 0; j < PE / 2; ++j) nxo[j] = load_o(u + 1, j);
     }
-    if (32 * u < N && !(MV_ATTN_ABLATE & 16)) {
+    if constexpr (NW == 2) {
+      if (32 * u < N) {
+        // Two waves of 512 registers: EVERY fragment of the query pair -- rows of Q and dO (S, dP), their transposes (dK, dV) --
+        // and the pair's lse / delta are read once per pair and wave, 16 KB, and only the K / V fragments (4 KB) per key tile;
+        // the four-wave form below reads 13 KB per key tile, 8 of them the pair's row fragments again (it has no registers
+        // to keep them in), and its S phase is bound by LDS bandwidth and by the length of its dependent chain.
+        bf16x8 dotr[4], qtr[4], qrow[2][2], dorow[2][2];
+        f32x4 lse4[2], dl4[2];
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+          lse4[t] = *reinterpret_cast<const f32x4*>(sLse + 32 * u + 16 * t + 4 * g);
+          dl4[t] = -*reinterpret_cast<const f32x4*>(sDelta + 32 * u + 16 * t + 4 * g);       // (negated: see stage A)
+#pragma unroll
+          for (int ks = 0; ks < 2; ++ks) {
+            qrow[t][ks] = row_frag128(sQ, t * 16, L.rf[ks]);
+            dorow[t][ks] = row_frag128(sDO, t * 16, L.rf[ks]);
+          }
+        }
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt) {
+          dotr[dt] = tr_frag128(sDO, 0, L.tr[dt]);
+          qtr[dt] = tr_frag128(sQ, 0, L.tr[dt]);
+        }
+        // One wave per SIMD is bound by what it can ISSUE: a 16x16x32 MFMA holds the vector issue port for 8 of its 16 cycles, a
+        // plain VALU operation costs 4, a transcendental 8 (MI355X_MICROARCH.md constants) -- so the 16 MFMAs of a key tile hide
+        // 128 cycles of VALU and everything beyond that is added time.  B is therefore cut to the minimum -- per element one fma
+        // and one exp2 (P), one multiply (dS: the MFMA accumulator of dP starts at -delta, and the softmax scale moves to the dK
+        // and dQ stores), half a bf16 pack each for P and dS -- and the file is compiled without SLP vectorisation (a packed
+        // f32 operation beside MFMAs costs more than the two scalar ones it replaces, same table).
+        // Software pipeline over the wave's seven key tiles (one wave per SIMD: nothing else hides a dependent chain).  Per tile
+        //   A: S = Q K^T, dP = dO V^T (8 MFMAs)   B: P, dS (exp and ~60 more VALU operations)   C: dV^T += dO^T P, dK^T += Q^T dS (8)
+        // and step i issues C(i-1) and A(i+1) -- sixteen MFMAs that depend on nothing in flight -- between the VALU operations
+        // of B(i); in source order each tile is A, B, C and the matrix unit idles through every B.  Both waves run seven tiles:
+        // wave 1's seventh is key tile 13 (K rows 208..223 are the padding rows, "V" rows the first of the pair buffer: finite
+        // bits), every key of it is masked, it accumulates and stores exact zeros and is never written out.
+        f32x4 sv[2][2], dpv[2][2];
+        bf16x8 kf[2][2], vf[2][2], pf[2], dsf[2];
+        auto read_kv = [&](int i) __attribute__((always_inline)) {
+#pragma unroll
+          for (int ks = 0; ks < 2; ++ks) {
+            kf[i & 1][ks] = row_frag128(sK, (wave + NW * i) * 16, L.rf[ks]);
+            vf[i & 1][ks] = row_frag128(sV, (wave + NW * i) * 16, L.rf[ks]);
+          }
+        };
+        auto stage_a = [&](int i) __attribute__((always_inline)) {
+#pragma unroll
+          for (int t = 0; t < 2; ++t) {
+            sv[i & 1][t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+            dpv[i & 1][t] = dl4[t];                       // the accumulator starts at -delta[q]: dP - delta leaves the MFMA
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+              sv[i & 1][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qrow[t][ks], kf[i & 1][ks], sv[i & 1][t], 0, 0, 0);
+              dpv[i & 1][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(dorow[t][ks], vf[i & 1][ks], dpv[i & 1][t], 0, 0, 0);
+            }
+          }
+        };
+        auto stage_b = [&](int i) __attribute__((always_inline)) {
+          const int key = (wave + NW * i) * 16 + (lane & 15);
+          f32x4 pp[2], ds[2];
+#pragma unroll
+          for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+              float pv = __builtin_amdgcn_exp2f(fmaf(sv[i & 1][t][r], c2, -lse4[t][r]));
+              if (i == KPW - 1) pv = key < N ? pv : 0.f;           // (192 < N: only key tile 12 holds padded keys; 13 all)
+              pp[t][r] = pv;
+              ds[t][r] = pv * dpv[i & 1][t][r];                    // dS / scale: dK and dQ take the factor at their stores
+            }
+          pf[i & 1] = pack8(pp[0], pp[1]);
+          const bf16x4 d0 = pack4(ds[0]), d1 = pack4(ds[1]);
+          dsf[i & 1] = cat8(d0, d1);
+          *reinterpret_cast<bf16x4*>(sDS + swds4(key, 0, g)) = d0;
+          *reinterpret_cast<bf16x4*>(sDS + swds4(key, 1, g)) = d1;
+        };
+        auto stage_c = [&](int i) __attribute__((always_inline)) {
+#pragma unroll
+          for (int dt = 0; dt < 4; ++dt) {
+            adv[i][dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(dotr[dt], pf[i & 1], adv[i][dt], 0, 0, 0);
+            adk[i][dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qtr[dt], dsf[i & 1], adk[i][dt], 0, 0, 0);
+          }
+        };
+        read_kv(0);
+        stage_a(0);
+        read_kv(1);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int i = 0; i < KPW; ++i) {
+          // this step's instructions: [C(i-1): 8 MFMA] [A(i+1): 8 MFMA] [reads of K/V(i+2)] [B(i): VALU, 2 LDS stores]
+          if (i >= 1) stage_c(i - 1);
+          if (i + 1 < KPW) stage_a(i + 1);
+          stage_b(i);
+          if (i + 2 < KPW) read_kv(i + 2);
+          // and the order they are to be issued in: one MFMA, four VALU, ...; the LDS traffic at the end
+          const int nm = (i >= 1 ? 8 : 0) + (i + 1 < KPW ? 8 : 0);
+#pragma unroll
+          for (int k = 0; k < nm; ++k) {
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);      // MFMA
+            __builtin_amdgcn_sched_group_barrier(0x002, 4, 0);      // VALU
+          }
+          __builtin_amdgcn_sched_group_barrier(0x002, 64, 0);       // whatever VALU is left
+          __builtin_amdgcn_sched_group_barrier(0x200, 2, 0);        // the two dS^T stores
+          __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);        // K/V fragment reads of tile i + 2
+          __builtin_amdgcn_sched_barrier(0);
+        }
+        stage_c(KPW - 1);
+      }
+    } else if (32 * u < N && !(MV_ATTN_ABLATE & 16)) {
       // The query pair's TRANSPOSED fragments (operands of the dV / dK products) do not depend on the key tile: read them
       // once per pair (8 fragments, 32 VGPRs) instead of once per key tile.  (Hoisting the row fragments as well spills.)
       bf16x8 dotr[4], qtr[4];
@@ -838,7 +980,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd4_kernel(const bf16_t* __restr
       }
 #pragma unroll
       for (int i = 0; i < KPW; ++i) {
-        const int kt = wave + 4 * i;
+        const int kt = wave + NW * i;
         if (kt >= nkt_valid || kt >= NKT) continue;
         const int key = kt * 16 + (lane & 15);
         f32x4 s[2], dp[2];
@@ -880,50 +1022,90 @@ __global__ __launch_bounds__(256, 2) void attn_bwd4_kernel(const bf16_t* __restr
         for (int t = 0; t < 2; ++t) *reinterpret_cast<bf16x4*>(sDS + swds4(key, t, g)) = pack4(ds[t]);
       }
     }
+    ATTN_STAMP(tb)
     __syncthreads();                                   // S-phase done everywhere: dS^T complete, Q/dO pair no longer read
+    ATTN_STAMP(tc)
     if (u + 1 < NQP && !(MV_ATTN_ABLATE & 4)) {
-      store_pair(0, nx0);
-      store_pair(1, nx1);
-      put_delta(u + 1, nx1, nxo);                      // read by the next iteration's S-phase, after the barrier below
+#pragma unroll
+      for (int e = 0; e < PE; ++e) store_pair(e, nx[e]);
+#pragma unroll
+      for (int j = 0; j < PE / 2; ++j) put_delta(u + 1, j, nx[PE / 2 + j], nxo[j]);   // read by the next S-phase, after the barrier below
     }
-    // dQ^T[d][q] = sum_key K^T[d][key] dS^T[key][q]: 2 q-tiles x 4 d-tiles = 8 output tiles, two per wave
+    // dQ^T[d][q] = sum_key K^T[d][key] dS^T[key][q]: 2 q-tiles x 4 d-tiles = 8 output tiles.  Four waves: two each (one q-tile,
+    // a d-tile pair); two waves: four each (both q-tiles of d-tile pair `wave`: the K^T fragments serve both)
     if (32 * u < N && !(MV_ATTN_ABLATE & 1)) {
-      const int t = wave >> 1;
-      const int trk0 = (wave & 1) ? L.tr[2] : L.tr[0], trk1 = (wave & 1) ? L.tr[3] : L.tr[1];
-      const int dsoff = swds4(4 * g + ((lane >> 2) & 3), t, lane & 3);   // rows 32 v + 4 g + q: (row >> 1) & 7 is the same for every v
-      f32x4 dq0 = {0.f, 0.f, 0.f, 0.f}, dq1 = {0.f, 0.f, 0.f, 0.f};
+      constexpr int QT = NW == 4 ? 1 : 2;
+      const int t0 = NW == 4 ? wave >> 1 : 0, dh = NW == 4 ? (wave & 1) : wave;
+      const int trk0 = dh ? L.tr[2] : L.tr[0], trk1 = dh ? L.tr[3] : L.tr[1];
+      int dsoff[QT];                                  // rows 32 v + 4 g + q: (row >> 1) & 7 is the same for every v
+#pragma unroll
+      for (int tq = 0; tq < QT; ++tq) dsoff[tq] = swds4(4 * g + ((lane >> 2) & 3), t0 + tq, lane & 3);
+      f32x4 dq[QT][2];
+#pragma unroll
+      for (int tq = 0; tq < QT; ++tq) dq[tq][0] = dq[tq][1] = (f32x4){0.f, 0.f, 0.f, 0.f};
       // All seven 32-key groups, unconditionally (groups beyond N hold zero dS^T rows -- zero-filled at the start, never
       // written -- against clamped finite K rows), two register sets: the six transposed reads of group v + 1 are in flight
       // while group v's two MFMAs run.  (As a rolled loop with a break each group was read -> wait -> MFMA: 16 % MFMA duty.)
-      bf16x8 dsv[2], kv0[2], kv1[2];
+      // ring depth: two waves have the registers (the S phase's fragments are dead here) to request ALL seven groups at once --
+      // one wave per SIMD hides an LDS round trip only behind its own MFMAs, and two groups in flight left it waiting
+      constexpr int RD = NW == 4 ? 2 : NQP;
+      bf16x8 dsv[RD][QT], kv0[RD], kv1[RD];
 #define ATTN_DQ_READ(buf_, v_)                                                  \
   {                                                                             \
-    const char* dsp_ = sDS + 2048 * (v_) + dsoff;                               \
-    dsv[buf_] = cat8(tr_read(dsp_), tr_read(dsp_ + 1024));                      \
+    _Pragma("unroll") for (int tq = 0; tq < QT; ++tq) {                         \
+      const char* dsp_ = sDS + 2048 * (v_) + dsoff[tq];                         \
+      dsv[buf_][tq] = cat8(tr_read(dsp_), tr_read(dsp_ + 1024));                \
+    }                                                                           \
     kv0[buf_] = tr_frag128(sK, 32 * (v_), trk0);                                \
     kv1[buf_] = tr_frag128(sK, 32 * (v_), trk1);                                \
   }
-      ATTN_DQ_READ(0, 0)
+#pragma unroll
+      for (int v = 0; v < RD - 1; ++v) ATTN_DQ_READ(v, v)
 #pragma unroll
       for (int v = 0; v < NQP; ++v) {
-        if (v + 1 < NQP) ATTN_DQ_READ((v + 1) & 1, v + 1)
-        dq0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kv0[v & 1], dsv[v & 1], dq0, 0, 0, 0);
-        dq1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kv1[v & 1], dsv[v & 1], dq1, 0, 0, 0);
+        if (v + RD - 1 < NQP) ATTN_DQ_READ((v + RD - 1) % RD, v + RD - 1)
+#pragma unroll
+        for (int tq = 0; tq < QT; ++tq) {
+          dq[tq][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kv0[v % RD], dsv[v % RD][tq], dq[tq][0], 0, 0, 0);
+          dq[tq][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kv1[v % RD], dsv[v % RD][tq], dq[tq][1], 0, 0, 0);
+        }
         __builtin_amdgcn_sched_barrier(0);
       }
 #undef ATTN_DQ_READ
-      const int q = 32 * u + 16 * t + (lane & 15);
-      const u32x4 dqw = pair16(dq0, dq1);
-      if (q < N) *reinterpret_cast<u32x4*>(dbase + (long)q * 3 * D + pair16_off(2 * (wave & 1), g)) = dqw;
-      dqs0 += dq0;
-      dqs1 += dq1;
+#pragma unroll
+      for (int tq = 0; tq < QT; ++tq) {
+        const int q = 32 * u + 16 * (t0 + tq) + (lane & 15);
+        if constexpr (NW == 2) {                             // dS^T came without the softmax scale
+          dq[tq][0] *= scale;
+          dq[tq][1] *= scale;
+        }
+        const u32x4 dqw = pair16(dq[tq][0], dq[tq][1]);      // (every lane executes the exchange)
+        if (q < N) *reinterpret_cast<u32x4*>(dbase + (long)q * 3 * D + pair16_off(2 * dh, g)) = dqw;
+        dqs0 += dq[tq][0];
+        dqs1 += dq[tq][1];
+      }
     }
+    ATTN_STAMP(td)
     __syncthreads();                                   // dS^T reads done; next Q/dO pair visible
+#ifdef MV_ATTN_TRACE
+    {
+      unsigned long long te;
+      ATTN_STAMP(te)
+      ATTN_ACC(a_s, ta, tb) ATTN_ACC(a_b1, tb, tc) ATTN_ACC(a_q, tc, td) ATTN_ACC(a_b2, td, te)
+    }
+#endif
   }
+  ATTN_STAMP(ts2)
 
+  if constexpr (NW == 2) {                                   // dS^T came without the softmax scale
+#pragma unroll
+    for (int i = 0; i < KPW; ++i)
+#pragma unroll
+      for (int dt = 0; dt < 4; ++dt) adk[i][dt] *= scale;
+  }
 #pragma unroll
   for (int i = 0; i < KPW; ++i) {
-    const int kt = wave + 4 * i;
+    const int kt = wave + NW * i;
     const int key = kt * 16 + (lane & 15);
     if (kt < nkt_valid && kt < NKT) {                     // wave-uniform: the lane exchange below runs on whole waves
 #pragma unroll
@@ -938,9 +1120,9 @@ __global__ __launch_bounds__(256, 2) void attn_bwd4_kernel(const bf16_t* __restr
   }
   if (colsum) {                                          // to_qkv bias-gradient partials of this (image, head)
     float* red = reinterpret_cast<float*>(sDS);          // the loop's last barrier freed dS^T
-    attn_colsum_zero<4>(red, tid, 256);
+    attn_colsum_zero<NW>(red, tid, NT);
     __syncthreads();
-    const int dq_d0 = 32 * (wave & 1);
+    const int dq_d0 = 32 * (NW == 4 ? (wave & 1) : wave);
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
       const float v0 = rowsum16(dqs0[r]), v1 = rowsum16(dqs1[r]);
@@ -967,8 +1149,23 @@ __global__ __launch_bounds__(256, 2) void attn_bwd4_kernel(const bf16_t* __restr
         }
       }
     __syncthreads();
-    attn_colsum_store<4>(red, colsum + (long)b * 3 * D + h * 64, D, tid);
+    attn_colsum_store<NW>(red, colsum + (long)b * 3 * D + h * 64, D, tid);
   }
+#ifdef MV_ATTN_TRACE
+  {
+    unsigned long long ts3, ts4;
+    ATTN_STAMP(ts3)
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    ATTN_STAMP(ts4)
+    if (tid == 0 && blockIdx.x < 4096) {
+      unsigned long long* tr = g_attn_trace + 16 * blockIdx.x;
+      tr[0] = ts0; tr[1] = ts1; tr[2] = ts2; tr[3] = ts3; tr[4] = ts4;
+      tr[5] = a_s; tr[6] = a_b1; tr[7] = a_q; tr[8] = a_b2;
+      tr[9] = __builtin_amdgcn_s_getreg(0xF804);
+      tr[10] = __builtin_amdgcn_s_getreg(0xF814);
+    }
+  }
+#endif
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1280,7 +1477,7 @@ extern "C" int mv_attention_fwd_force(int variant) {
   return MV_OK;
 }
 extern "C" int mv_attention_bwd_force(int variant) {
-  if (variant != 0 && variant != 2 && variant != 4 && variant != 8) return MV_ERR_UNSUPPORTED;
+  if (variant != 0 && variant != 2 && variant != 4 && variant != 5 && variant != 8) return MV_ERR_UNSUPPORTED;
   g_bwd_variant.store(variant, std::memory_order_relaxed);
   return MV_OK;
 }
@@ -1346,10 +1543,14 @@ extern "C" int mv_attention_bwd(const void* qkv, const void* out, const void* do
     }
   } else if (N <= 208 && !force8) {
     constexpr int smem4 = 224 * 128 + 208 * 128 + 8192 + 224 * 64 + 2 * 224 * 4;   // 79,616 B: two workgroups per CU
-    static const int a = set_smem(attn_bwd4_kernel, smem4);
+    static const int a = set_smem(attn_bwd4_kernel<4>, smem4) | set_smem(attn_bwd4_kernel<2>, smem4);
     if (a) return MV_ERR_LAUNCH;
-    attn_bwd4_kernel<<<B * H, 256, smem4, s>>>((const bf16_t*)qkv, (const bf16_t*)out, (const bf16_t*)dout, lse,
-                                              (bf16_t*)dqkv, colsum, N, H, scale);
+    if (forced == 5 && N > 192)                   // two waves of 512 registers per workgroup (7 + 6 key tiles)
+      attn_bwd4_kernel<2><<<B * H, 128, smem4, s>>>((const bf16_t*)qkv, (const bf16_t*)out, (const bf16_t*)dout, lse,
+                                                   (bf16_t*)dqkv, colsum, N, H, scale);
+    else
+      attn_bwd4_kernel<4><<<B * H, 256, smem4, s>>>((const bf16_t*)qkv, (const bf16_t*)out, (const bf16_t*)dout, lse,
+                                                   (bf16_t*)dqkv, colsum, N, H, scale);
   } else if (N <= 224) {
     static const int a = set_smem(attn_bwd_kernel<14, 2>, bwd_smem(14));
     if (a) return MV_ERR_LAUNCH;

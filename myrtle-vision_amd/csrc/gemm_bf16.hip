@@ -994,6 +994,16 @@ typedef __attribute__((ext_vector_type(4))) int i32x4;
 constexpr int NT_BF16 = 0, NT_I8 = 1, NT_F16 = 2;
 typedef __attribute__((ext_vector_type(8))) _Float16 f16x8;
 
+#if MV_ABLATE == 32
+// diagnostic build (tools/diag/p8_timeline.py): per-workgroup time stamps (100 MHz s_memrealtime) and hardware ids
+__device__ unsigned long long g_p8_trace[8 * 4096];
+extern "C" int mv_debug_p8_trace(void* dst) {
+  return hipMemcpyFromSymbol(dst, HIP_SYMBOL(g_p8_trace), sizeof(g_p8_trace)) == hipSuccess ? 0 : -1;
+}
+#define P8_STAMP(v_) v_ = __builtin_amdgcn_s_memrealtime();
+#else
+#define P8_STAMP(v_)
+#endif
 template <int EPI, typename CT, int OPK = NT_BF16, bool KSPLIT = false, bool BUFDMA = true>
 __global__ __launch_bounds__(512, 2) void gemm_nt_8phase_kernel(const bf16_t* __restrict__ A, int lda,
                                                                 const bf16_t* __restrict__ B, int ldb, CT* __restrict__ C,
@@ -1019,6 +1029,8 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_8phase_kernel(const bf16_t* __
     half = idx & 1;
   }
   const bool is_half_rt = half >= 0;             // wave-uniform
+  unsigned long long ts0 = 0, ts1 = 0, ts2 = 0;
+  P8_STAMP(ts0)
   if constexpr (KSPLIT) {                        // K = the slice length; the bias rides on slice 0 only
     const int ks = t / ep.ks_tiles;
     t -= ks * ep.ks_tiles;
@@ -1204,6 +1216,7 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_8phase_kernel(const bf16_t* __
   if (lazy) { P8_WAIT(10) } else { P8_WAIT(6) }           // B_q0, A_q0 of K-tile 0 landed | the whole K-tile 0
   P8_BAR()
   if (__builtin_amdgcn_readfirstlane(wave) >= 4) P8_BAR()      // waves 4-7 run one barrier behind
+  P8_STAMP(ts1)
   int kt = 0;
 #if MV_ABLATE == 16
   kt = nk - 2;                                   // diagnostic: only the peeled last iteration runs
@@ -1218,6 +1231,7 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_8phase_kernel(const bf16_t* __
   P8_KTILE(0, 0, 1, kt + 1, 0, 0, P8_WAIT(10), P8_WAIT(8), P8_WAIT(4), P8_WAIT(0), 1)
   P8_KTILE(1, 0, 0, 0, 0, 0, P8_WAIT(2), P8_WAIT(0), , , 0)
   if (__builtin_amdgcn_readfirstlane(wave) < 4) P8_BAR()
+  P8_STAMP(ts2)
 #undef P8_WAIT
 #undef P8_KTILE
 #undef P8_LGKM0
@@ -1305,6 +1319,21 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_8phase_kernel(const bf16_t* __
   };
   if (is_half_rt) body(std::true_type{});
   else body(std::false_type{});
+#if MV_ABLATE == 32
+  {
+    unsigned long long ts3, ts4;
+    P8_STAMP(ts3)                                  // all stores issued
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    P8_STAMP(ts4)                                  // ... and acknowledged
+    if (tid == 0 && blockIdx.x < 4096) {
+      unsigned long long* tr = g_p8_trace + 8 * blockIdx.x;
+      tr[0] = ts0; tr[1] = ts1; tr[2] = ts2; tr[3] = ts3; tr[4] = ts4;
+      tr[5] = __builtin_amdgcn_s_getreg(0xF804);   // HW_ID
+      tr[6] = __builtin_amdgcn_s_getreg(0xF814);   // XCC_ID
+      tr[7] = ((unsigned long long)(is_half_rt ? 1 : 0) << 32) | (unsigned)t;
+    }
+  }
+#endif
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -2076,7 +2105,12 @@ bool tn_use_ring(int M, int N, int Kc) {
   const int force = g_force_tn.load(std::memory_order_relaxed);                        // 128 | 256: tuning and tests
   if (Kc <= 0 || Kc % BKR != 0 || force == 128) return false;
   if (force == 256) return true;
-  return (long)M * N >= 256L * 256 * 4 && Kc >= 4096;   // >= 4 tiles and a contraction long enough to split over the chip
+  if (!((long)M * N >= 256L * 256 * 4 && Kc >= 4096)) return false;   // >= 4 tiles and a contraction long enough to split over the chip
+  // ... and enough (tile, split) items for most of the 256 CUs: a split keeps >= 16 stages, so a SHORT contraction over a
+  // small output (dW of proj at batch 32: 9 tiles x 13 splits = 117 workgroups) leaves half the chip idle, where the
+  // 128-tile kernel's 36 x 13 two-per-CU workgroups fill it (191 -> 250 TFLOP/s on that shape; tools/bench_gemm.py M=6304)
+  const TnPlan pl = tn_plan256(M, N, Kc);
+  return pl.tiles_m * pl.tiles_n * pl.splits >= 160;
 }
 
 template <typename K>
@@ -2122,8 +2156,9 @@ int launch_nt(const void* A, int lda, const void* B, int ldb, void* C, int ldc, 
   const bool ring_ok = K > 0 && K % BKR == 0;
   const bool ring_pick = ring_ok && ((long)t2m * t2n >= 1024 || (K >= 2048 && (long)t2m * t2n >= 256));
   const bool p8_ok = K >= 128 && K % 128 == 0 && (long)M * lda < (1L << 31) && (long)N * ldb < (1L << 31);
-  // 8-phase kernel: wherever the ring would be picked, and from one full round of the chip on (half-item tail)
-  const bool p8_pick = p8_ok && (ring_pick || (long)t2m * t2n >= NT_CUS);
+  // 8-phase kernel: wherever the ring would be picked, and from three quarters of one round of the chip on (half-item tail from
+  // one full round; 225 tiles -- the qkv projection at batch 32 -- run 780 TFLOP/s here against 657 as 900 128-tiles)
+  const bool p8_pick = p8_ok && (ring_pick || (long)t2m * t2n >= NT_CUS * 3 / 4);
   if (((force == 2568 || force == 25680 || force == 2569) && p8_ok) || (force == 0 && p8_pick)) {
     static const int a8 = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_nt_8phase_kernel<EPI, CT>),
                                               hipFuncAttributeMaxDynamicSharedMemorySize, P8_SMEM) == hipSuccess ? 0 : -1;

@@ -539,7 +539,7 @@ def test_attention_fused_fwd_bwd(ops, B, N, H):
     assert torch.equal(dq2, dqkv)
     # every backward kernel that takes this length (auto picked one of them above)
     from myrtle_vision.hip.lib import lib
-    for variant in [v for v, nmax in ((4, 208), (2, 288), (8, 320)) if N <= nmax]:
+    for variant in [v for v, nmax in ((4, 208), (5, 208), (2, 288), (8, 320)) if N <= nmax]:
         lib().mv_attention_bwd_force(variant)
         try:
             part2 = torch.full((B, 3 * H * 64), float("nan"), device="cuda")

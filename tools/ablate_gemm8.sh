@@ -1,11 +1,12 @@
 #!/bin/bash
 # Diagnostic: libmyrtle_vision_hip variants with parts of gemm_nt_8phase_kernel removed (results are WRONG by
-# construction): 8 = no epilogue, 16 = no main loop.   build here: tools/ablate_gemm8.sh ; GPU box: tools/ablate_gemm8.sh run
+# construction): 8 = no epilogue, 16 = no main loop; 32 = whole kernel with per-workgroup
+# time stamps (tools/diag/p8_timeline.py; MODES=32 tools/ablate_gemm8.sh).   build here: tools/ablate_gemm8.sh ; GPU box: tools/ablate_gemm8.sh run
 set -e
 cd "$(dirname "$0")/.."
 CS=myrtle-vision_amd/csrc
 if [ "$1" != "run" ]; then
-  for m in 8 16; do
+  for m in ${MODES:-8 16}; do
     mkdir -p tools/_ablate/o$m
     for f in layernorm attention attention_f32 gemm_f32 elementwise seg_tail image_prep; do cp myrtle-vision_amd/lib/$f.o tools/_ablate/o$m/; done
     hipcc --offload-arch=gfx950 -O3 -fPIC -std=c++17 -I include -DMV_ABLATE=$m -c $CS/gemm_bf16.hip -o tools/_ablate/o$m/gemm_bf16.o

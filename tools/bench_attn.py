@@ -34,6 +34,18 @@ if os.environ.get("FWD_AB"):                        # forward variants 1 (one qu
     d3 = float((outs[1][0].float() - outs[3][0].float()).abs().max())
     print(f"attention fwd variants: single tile {best[1]:7.1f} us | tile pairs {best[2]:7.1f} us | 13 tiles, 3 WG/CU {best[3]:7.1f} us | "
           f"max |o1 - o2| {d:.3e} |o1 - o3| {d3:.3e}  lse equal {bool(torch.equal(outs[1][1], outs[2][1]))} {bool(torch.equal(outs[1][1], outs[3][1]))}")
+if os.environ.get("BWD_AB"):                        # backward variants alternating in one process, e.g. BWD_AB=4,5
+    from myrtle_vision.hip.lib import lib
+    vs = [int(v) for v in os.environ["BWD_AB"].split(",")]
+    best, res = {v: 1e9 for v in vs}, {}
+    for _ in range(4):
+        for v in vs:
+            lib().mv_attention_bwd_force(v)
+            best[v] = min(best[v], timeit(lambda: ops.attention_bwd(qkv, out, dout, lse, B, N, H, 0.125)))
+            res[v] = ops.attention_bwd(qkv, out, dout, lse, B, N, H, 0.125).float()
+    lib().mv_attention_bwd_force(0)
+    print("attention bwd variants: " + " | ".join(f"{v}: {best[v]:7.1f} us" for v in vs) + " | max |d| vs first: " +
+          " ".join(f"{float((res[v] - res[vs[0]]).abs().max()):.3e}" for v in vs[1:]))
 tf = timeit(lambda: ops.attention_fwd(qkv, B, N, H, 0.125))
 tb = timeit(lambda: ops.attention_bwd(qkv, out, dout, lse, B, N, H, 0.125))
 fl_f, fl_b = 4.0 * B * H * N * N * 64, 10.0 * B * H * N * N * 64
