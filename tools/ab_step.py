@@ -23,7 +23,9 @@ import myrtle_vision.hip.functional as _F  # noqa: E402
 
 GELU_AB = "GELU_BITS" in os.environ
 TN_AB = "TN_VARIANTS" in os.environ              # TN_VARIANTS=2564,2565: dW ring kernel with four / five stages
-VARIANTS = [int(v) for v in os.environ.get("GELU_BITS" if GELU_AB else "TN_VARIANTS" if TN_AB else "NT_VARIANTS", "0,2569").split(",")]
+ATTN_AB = "ATTN_BWD_VARIANTS" in os.environ      # ATTN_BWD_VARIANTS=4,5: attention backward with four / two waves per workgroup
+VARIANTS = [int(v) for v in os.environ.get("GELU_BITS" if GELU_AB else "TN_VARIANTS" if TN_AB else "ATTN_BWD_VARIANTS" if ATTN_AB
+                                           else "NT_VARIANTS", "0,2569").split(",")]
 
 
 def select(v):
@@ -31,6 +33,8 @@ def select(v):
         _F.GELU_GRAD_BITS = v
     elif TN_AB:
         lib().mv_gemm_force_variant(0, v)
+    elif ATTN_AB:
+        lib().mv_attention_bwd_force(v)
     else:
         lib().mv_gemm_force_variant(v, 0)
 
