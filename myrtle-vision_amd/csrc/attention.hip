@@ -1492,23 +1492,23 @@ extern "C" int mv_attention_fwd(const void* qkv, void* out, float* lse, int B, i
   const int fv = g_fwd_variant.load(std::memory_order_relaxed);
   if (N <= 208 && (fv == 3 || fv == 0)) {    // 13 key tiles, 53 248 B: three workgroups per CU
     constexpr int smem13 = 2 * 13 * 16 * 128;
-    static const int a = set_smem(attn_fwd13_kernel, smem13);
+    const int a = MV_ONCE_PER_DEVICE(set_smem(attn_fwd13_kernel, smem13));
     if (a) return MV_ERR_LAUNCH;
     attn_fwd13_kernel<<<B * H, 256, smem13, s>>>((const bf16_t*)qkv, (bf16_t*)out, lse, N, H, sl);
   } else if (N <= 224 && fv == 2) {          // query-tile pairs per wave: half the LDS fragment traffic per FLOP
-    static const int a = set_smem(attn_fwd2_kernel<14>, fwd_smem(14));
+    const int a = MV_ONCE_PER_DEVICE(set_smem(attn_fwd2_kernel<14>, fwd_smem(14)));
     if (a) return MV_ERR_LAUNCH;
     attn_fwd2_kernel<14><<<B * H, 256, fwd_smem(14), s>>>((const bf16_t*)qkv, (bf16_t*)out, lse, N, H, sl);
   } else if (N <= 224) {
-    static const int a = set_smem(attn_fwd_kernel<14>, fwd_smem(14));
+    const int a = MV_ONCE_PER_DEVICE(set_smem(attn_fwd_kernel<14>, fwd_smem(14)));
     if (a) return MV_ERR_LAUNCH;
     attn_fwd_kernel<14><<<B * H, 256, fwd_smem(14), s>>>((const bf16_t*)qkv, (bf16_t*)out, lse, N, H, sl);
   } else if (N <= 288) {                   // 257 tokens at 256^2: 18 key tiles = 73.7 KB of K/V, still two workgroups per CU
-    static const int a = set_smem(attn_fwd_kernel<18>, fwd_smem(18));
+    const int a = MV_ONCE_PER_DEVICE(set_smem(attn_fwd_kernel<18>, fwd_smem(18)));
     if (a) return MV_ERR_LAUNCH;
     attn_fwd_kernel<18><<<B * H, 256, fwd_smem(18), s>>>((const bf16_t*)qkv, (bf16_t*)out, lse, N, H, sl);
   } else {
-    static const int a = set_smem(attn_fwd_kernel<20>, fwd_smem(20));
+    const int a = MV_ONCE_PER_DEVICE(set_smem(attn_fwd_kernel<20>, fwd_smem(20)));
     if (a) return MV_ERR_LAUNCH;
     attn_fwd_kernel<20><<<B * H, 256, fwd_smem(20), s>>>((const bf16_t*)qkv, (bf16_t*)out, lse, N, H, sl);
   }
@@ -1530,20 +1530,20 @@ extern "C" int mv_attention_bwd(const void* qkv, const void* out, const void* do
   if (N <= 288 && !force8 && two_pass) {
     if (N <= 224) {
       constexpr int smem = 2 * 224 * 128 + 2 * 224 * 4 + 4 * 192 * 4;
-      static const int a = set_smem(attn_bwd2p_kernel<7>, smem);
+      const int a = MV_ONCE_PER_DEVICE(set_smem(attn_bwd2p_kernel<7>, smem));
       if (a) return MV_ERR_LAUNCH;
       attn_bwd2p_kernel<7><<<B * H, 256, smem, s>>>((const bf16_t*)qkv, (const bf16_t*)out, (const bf16_t*)dout, lse,
                                                    (bf16_t*)dqkv, colsum, N, H, scale);
     } else {
       constexpr int smem = 2 * 288 * 128 + 2 * 288 * 4 + 4 * 192 * 4;
-      static const int a = set_smem(attn_bwd2p_kernel<9>, smem);
+      const int a = MV_ONCE_PER_DEVICE(set_smem(attn_bwd2p_kernel<9>, smem));
       if (a) return MV_ERR_LAUNCH;
       attn_bwd2p_kernel<9><<<B * H, 256, smem, s>>>((const bf16_t*)qkv, (const bf16_t*)out, (const bf16_t*)dout, lse,
                                                    (bf16_t*)dqkv, colsum, N, H, scale);
     }
   } else if (N <= 208 && !force8) {
     constexpr int smem4 = 224 * 128 + 208 * 128 + 8192 + 224 * 64 + 2 * 224 * 4;   // 79,616 B: two workgroups per CU
-    static const int a = set_smem(attn_bwd4_kernel<4>, smem4) | set_smem(attn_bwd4_kernel<2>, smem4);
+    const int a = MV_ONCE_PER_DEVICE(set_smem(attn_bwd4_kernel<4>, smem4) | set_smem(attn_bwd4_kernel<2>, smem4));
     if (a) return MV_ERR_LAUNCH;
     if (forced == 5 && N > 192)                   // two waves of 512 registers per workgroup (7 + 6 key tiles)
       attn_bwd4_kernel<2><<<B * H, 128, smem4, s>>>((const bf16_t*)qkv, (const bf16_t*)out, (const bf16_t*)dout, lse,
@@ -1552,12 +1552,12 @@ extern "C" int mv_attention_bwd(const void* qkv, const void* out, const void* do
       attn_bwd4_kernel<4><<<B * H, 256, smem4, s>>>((const bf16_t*)qkv, (const bf16_t*)out, (const bf16_t*)dout, lse,
                                                    (bf16_t*)dqkv, colsum, N, H, scale);
   } else if (N <= 224) {
-    static const int a = set_smem(attn_bwd_kernel<14, 2>, bwd_smem(14));
+    const int a = MV_ONCE_PER_DEVICE(set_smem(attn_bwd_kernel<14, 2>, bwd_smem(14)));
     if (a) return MV_ERR_LAUNCH;
     attn_bwd_kernel<14, 2><<<B * H, 512, bwd_smem(14), s>>>((const bf16_t*)qkv, (const bf16_t*)out, (const bf16_t*)dout,
                                                           lse, (bf16_t*)dqkv, colsum, N, H, scale);
   } else {
-    static const int a = set_smem(attn_bwd_kernel<20, 3>, bwd_smem(20));
+    const int a = MV_ONCE_PER_DEVICE(set_smem(attn_bwd_kernel<20, 3>, bwd_smem(20)));
     if (a) return MV_ERR_LAUNCH;
     attn_bwd_kernel<20, 3><<<B * H, 512, bwd_smem(20), s>>>((const bf16_t*)qkv, (const bf16_t*)out, (const bf16_t*)dout,
                                                           lse, (bf16_t*)dqkv, colsum, N, H, scale);

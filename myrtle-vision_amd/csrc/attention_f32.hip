@@ -440,8 +440,8 @@ template <int NT>
 int launch_attn_bwd_f32(const float* qkv, const float* out, const float* dout, const float* lse, float* dqkv, int B, int N,
                         int H, float scale, hipStream_t s) {
   constexpr size_t lds = ((size_t)2 * NT * 16 * AF_DH + 2 * NT * 16) * sizeof(float);
-  static const int attr = hipFuncSetAttribute(reinterpret_cast<const void*>(attn_bwd_f32_kernel<NT>),
-                                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) == hipSuccess ? 0 : -1;
+  const int attr = MV_ONCE_PER_DEVICE(hipFuncSetAttribute(reinterpret_cast<const void*>(attn_bwd_f32_kernel<NT>),
+                                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) == hipSuccess ? 0 : -1);
   if (attr) return MV_ERR_LAUNCH;
   attn_bwd_f32_kernel<NT><<<B * H, 512, lds, s>>>(qkv, out, dout, lse, dqkv, N, H, scale);
   MV_CHECK_LAUNCH();
@@ -452,8 +452,8 @@ template <int NT, bool Q8>
 int launch_attn_f32(const float* qkv, void* out, int B, int N, int H, float scale, float q_inv, float q_zp, hipStream_t s,
                     float* lse = nullptr) {
   constexpr size_t lds = (size_t)2 * NT * 16 * AF_DH * sizeof(float);
-  static const int attr = hipFuncSetAttribute(reinterpret_cast<const void*>(attn_fwd_f32_kernel<NT, Q8>),
-                                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) == hipSuccess ? 0 : -1;
+  const int attr = MV_ONCE_PER_DEVICE(hipFuncSetAttribute(reinterpret_cast<const void*>(attn_fwd_f32_kernel<NT, Q8>),
+                                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) == hipSuccess ? 0 : -1);
   if (attr) return MV_ERR_LAUNCH;
   static const int n_cu = [] {
     int dev = 0, n = 0;

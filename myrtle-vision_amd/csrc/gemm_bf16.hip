@@ -2132,10 +2132,10 @@ inline int nt_full_tiles(int tiles) {
 template <int EPI, typename CT>
 int launch_nt(const void* A, int lda, const void* B, int ldb, void* C, int ldc, int M, int N, int K, EpiArgs ep,
               hipStream_t s) {
-  static const int attr = set_smem(gemm_nt_kernel<EPI, CT>) | set_smem(gemm_nt_glds_kernel<EPI, CT>) |
+  const int attr = MV_ONCE_PER_DEVICE(set_smem(gemm_nt_kernel<EPI, CT>) | set_smem(gemm_nt_glds_kernel<EPI, CT>) |
                           set_smem(gemm_nt_glds_kernel<EPI, CT, false>) |
                           (hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_nt_glds256_kernel<EPI, CT>),
-                                               hipFuncAttributeMaxDynamicSharedMemorySize, SMEM2_BYTES) == hipSuccess ? 0 : -1);
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, SMEM2_BYTES) == hipSuccess ? 0 : -1));
   if (attr != 0) return MV_ERR_LAUNCH;
   const int tiles_m = mv_cdiv(M, BM), tiles_n = mv_cdiv(N, BN);
   const int t2m = mv_cdiv(M, BM2), t2n = mv_cdiv(N, BN2);
@@ -2160,8 +2160,8 @@ int launch_nt(const void* A, int lda, const void* B, int ldb, void* C, int ldc, 
   // one full round; 225 tiles -- the qkv projection at batch 32 -- run 780 TFLOP/s here against 657 as 900 128-tiles)
   const bool p8_pick = p8_ok && (ring_pick || (long)t2m * t2n >= NT_CUS * 3 / 4);
   if (((force == 2568 || force == 25680 || force == 2569) && p8_ok) || (force == 0 && p8_pick)) {
-    static const int a8 = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_nt_8phase_kernel<EPI, CT>),
-                                              hipFuncAttributeMaxDynamicSharedMemorySize, P8_SMEM) == hipSuccess ? 0 : -1;
+    const int a8 = MV_ONCE_PER_DEVICE(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_nt_8phase_kernel<EPI, CT>),
+                                              hipFuncAttributeMaxDynamicSharedMemorySize, P8_SMEM) == hipSuccess ? 0 : -1);
     if (a8) return MV_ERR_LAUNCH;
     const int tiles = t2m * t2n, full = force == 25680 ? tiles : nt_full_tiles(tiles);     // 25680: whole tiles only (A/B)
     // persistent variant (stores drain under the next tile): interior whole tiles, bias-only epilogues; 2569 forces it
@@ -2171,8 +2171,8 @@ int launch_nt(const void* A, int lda, const void* B, int ldb, void* C, int ldc, 
                        (reinterpret_cast<uintptr_t>(ep.bias) & 15) == 0 && ep.alpha == 1.0f;
     if (pp_ok && (force == PP_AUTO_FORCE || force == 2569)) {
       if constexpr (pp_epi) {
-        static const int ap = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_nt_8phase_persistent_kernel<EPI, CT>),
-                                                  hipFuncAttributeMaxDynamicSharedMemorySize, PP_SMEM) == hipSuccess ? 0 : -1;
+        const int ap = MV_ONCE_PER_DEVICE(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_nt_8phase_persistent_kernel<EPI, CT>),
+                                                  hipFuncAttributeMaxDynamicSharedMemorySize, PP_SMEM) == hipSuccess ? 0 : -1);
         if (ap) return MV_ERR_LAUNCH;
         gemm_nt_8phase_persistent_kernel<EPI, CT><<<full < NT_CUS ? full : NT_CUS, 512, PP_SMEM, s>>>(
             (const bf16_t*)A, lda, (const bf16_t*)B, ldb, (CT*)C, ldc, M, N, K, t2n, ep, full);
@@ -2184,8 +2184,8 @@ int launch_nt(const void* A, int lda, const void* B, int ldb, void* C, int ldc, 
       }
     }
     if (ep.glds_dma) {
-      static const int ab = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_nt_8phase_kernel<EPI, CT, NT_BF16, false, false>),
-                                                hipFuncAttributeMaxDynamicSharedMemorySize, P8_SMEM) == hipSuccess ? 0 : -1;
+      const int ab = MV_ONCE_PER_DEVICE(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_nt_8phase_kernel<EPI, CT, NT_BF16, false, false>),
+                                                hipFuncAttributeMaxDynamicSharedMemorySize, P8_SMEM) == hipSuccess ? 0 : -1);
       if (ab) return MV_ERR_LAUNCH;
       gemm_nt_8phase_kernel<EPI, CT, NT_BF16, false, false><<<full + 2 * (tiles - full), 512, P8_SMEM, s>>>(
           (const bf16_t*)A, lda, (const bf16_t*)B, ldb, (CT*)C, ldc, M, N, K, t2n, ep, full, 0);
@@ -2198,8 +2198,8 @@ int launch_nt(const void* A, int lda, const void* B, int ldb, void* C, int ldc, 
     return MV_OK;
   }
   if ((force == 2564 && ring_ok) || (force == 0 && ring_pick)) {
-    static const int a4 = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_nt_ring_kernel<EPI, CT, 4>),
-                                              hipFuncAttributeMaxDynamicSharedMemorySize, 4 * RSTAGE_BYTES) == hipSuccess ? 0 : -1;
+    const int a4 = MV_ONCE_PER_DEVICE(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_nt_ring_kernel<EPI, CT, 4>),
+                                              hipFuncAttributeMaxDynamicSharedMemorySize, 4 * RSTAGE_BYTES) == hipSuccess ? 0 : -1);
     if (a4) return MV_ERR_LAUNCH;
     gemm_nt_ring_kernel<EPI, CT, 4><<<t2m * t2n, 512, 4 * RSTAGE_BYTES, s>>>((const bf16_t*)A, lda, (const bf16_t*)B, ldb,
                                                                               (CT*)C, ldc, M, N, K, t2n, ep);
@@ -2286,8 +2286,8 @@ extern "C" int mv_gemm_nt_bf16_ksplit(const void* A, int lda, const void* B, int
   MV_REQUIRE(lda % 8 == 0 && ldb % 8 == 0 && lda >= K && ldb >= K, MV_ERR_ALIGN);
   MV_REQUIRE(mv_aligned16(A) && mv_aligned16(B) && mv_aligned16(slabs), MV_ERR_ALIGN);
   MV_REQUIRE((long)M * lda < (1L << 32) && (long)N * ldb < (1L << 32), MV_ERR_UNSUPPORTED);   // 32-bit staging offsets
-  static const int a8 = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_nt_8phase_kernel<MV_EPI_NONE, float, NT_BF16, true>),
-                                            hipFuncAttributeMaxDynamicSharedMemorySize, P8_SMEM) == hipSuccess ? 0 : -1;
+  const int a8 = MV_ONCE_PER_DEVICE(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_nt_8phase_kernel<MV_EPI_NONE, float, NT_BF16, true>),
+                                            hipFuncAttributeMaxDynamicSharedMemorySize, P8_SMEM) == hipSuccess ? 0 : -1);
   if (a8) return MV_ERR_LAUNCH;
   const int t2m = mv_cdiv(M, BM2), t2n = mv_cdiv(N, BN2);
   const int tiles = t2m * t2n, items = tiles * splits, full = nt_full_tiles(items);
@@ -2316,8 +2316,8 @@ extern "C" int mv_gemm_tn_bf16_x6(const void* A6, const void* B6, float* C, int 
   const int tiles_mn = pl.tiles_m * pl.tiles_n;
   const bool direct = pl.splits == 1;
   const long slab_stride = (long)M * N;
-  static const int a4 = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_tn_ring_kernel<4, true>),
-                                            hipFuncAttributeMaxDynamicSharedMemorySize, 4 * RSTAGE_BYTES) == hipSuccess ? 0 : -1;
+  const int a4 = MV_ONCE_PER_DEVICE(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_tn_ring_kernel<4, true>),
+                                            hipFuncAttributeMaxDynamicSharedMemorySize, 4 * RSTAGE_BYTES) == hipSuccess ? 0 : -1);
   if (a4) return MV_ERR_LAUNCH;
   TnSeg seg;
   seg.tiles = rows / BKR;
@@ -2343,8 +2343,8 @@ namespace {
 template <int EPI, typename CT>
 int launch_nt_i8(const void* A, int lda, const void* B, int ldb, void* C, int ldc, int M, int N, int K, EpiArgs ep,
                  hipStream_t s) {
-  static const int a8 = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_nt_8phase_kernel<EPI, CT, NT_I8>),
-                                            hipFuncAttributeMaxDynamicSharedMemorySize, P8_SMEM) == hipSuccess ? 0 : -1;
+  const int a8 = MV_ONCE_PER_DEVICE(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_nt_8phase_kernel<EPI, CT, NT_I8>),
+                                            hipFuncAttributeMaxDynamicSharedMemorySize, P8_SMEM) == hipSuccess ? 0 : -1);
   if (a8) return MV_ERR_LAUNCH;
   const int t2m = mv_cdiv(M, BM2), t2n = mv_cdiv(N, BN2);
   const int tiles = t2m * t2n, full = nt_full_tiles(tiles);
@@ -2360,8 +2360,8 @@ namespace {
 template <int EPI, typename CT>
 int launch_nt_f16(const void* A, int lda, const void* B, int ldb, void* C, int ldc, int M, int N, int K, EpiArgs ep,
                   hipStream_t s) {
-  static const int a8 = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_nt_8phase_kernel<EPI, CT, NT_F16>),
-                                            hipFuncAttributeMaxDynamicSharedMemorySize, P8_SMEM) == hipSuccess ? 0 : -1;
+  const int a8 = MV_ONCE_PER_DEVICE(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_nt_8phase_kernel<EPI, CT, NT_F16>),
+                                            hipFuncAttributeMaxDynamicSharedMemorySize, P8_SMEM) == hipSuccess ? 0 : -1);
   if (a8) return MV_ERR_LAUNCH;
   const int t2m = mv_cdiv(M, BM2), t2n = mv_cdiv(N, BN2);
   const int tiles = t2m * t2n, full = nt_full_tiles(tiles);
@@ -2473,7 +2473,7 @@ extern "C" int mv_gemm_tn_bf16(const void* A, int lda, const void* B, int ldb, f
   MV_REQUIRE(lda % 8 == 0 && ldb % 8 == 0 && lda >= ((M + 7) & ~7) && ldb >= ((N + 7) & ~7), MV_ERR_ALIGN);
   MV_REQUIRE(mv_aligned16(A) && mv_aligned16(B) && mv_aligned16(C) && mv_aligned16(workspace), MV_ERR_ALIGN);
   MV_REQUIRE(workspace_bytes >= mv_gemm_tn_workspace_bytes(M, N, Kc), MV_ERR_WORKSPACE);
-  static const int attr = set_smem(gemm_tn_kernel) | set_smem(gemm_tn_glds_kernel);
+  const int attr = MV_ONCE_PER_DEVICE(set_smem(gemm_tn_kernel) | set_smem(gemm_tn_glds_kernel));
   if (attr != 0) return MV_ERR_LAUNCH;
   hipStream_t s = (hipStream_t)stream;
   // A contraction that is not a whole number of the ring kernel's 32-row stages (197 tokens x a batch that is not a multiple
@@ -2504,10 +2504,10 @@ extern "C" int mv_gemm_tn_bf16(const void* A, int lda, const void* B, int ldb, f
   const bool direct = pl.splits == 1 && !accumulate;
   const long slab_stride = (long)M * N;
   if (ring) {
-    static const int a4 = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_tn_ring_kernel<4>),
-                                              hipFuncAttributeMaxDynamicSharedMemorySize, 4 * RSTAGE_BYTES) == hipSuccess ? 0 : -1;
-    static const int a4g = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_tn_ring_kernel<4, false, false>),
-                                               hipFuncAttributeMaxDynamicSharedMemorySize, 4 * RSTAGE_BYTES) == hipSuccess ? 0 : -1;
+    const int a4 = MV_ONCE_PER_DEVICE(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_tn_ring_kernel<4>),
+                                              hipFuncAttributeMaxDynamicSharedMemorySize, 4 * RSTAGE_BYTES) == hipSuccess ? 0 : -1);
+    const int a4g = MV_ONCE_PER_DEVICE(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_tn_ring_kernel<4, false, false>),
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, 4 * RSTAGE_BYTES) == hipSuccess ? 0 : -1);
     if (a4 || a4g) return MV_ERR_LAUNCH;
     if (g_force_tn.load(std::memory_order_relaxed) == 2565)
       gemm_tn_ring_kernel<4, false, false><<<tiles_mn * pl.splits, 512, 4 * RSTAGE_BYTES, s>>>(

@@ -7,6 +7,24 @@
 
 #include "../../include/myrtle_vision_hip.h"
 
+#include <atomic>
+// hipFuncSetAttribute acts on the CURRENT device.  The launchers raise a kernel's dynamic-LDS limit once and remember it; the memory is
+// per (call site, device), so a process that drives several GPUs -- not the one-process-per-GPU launch this library is written for, but
+// legal -- does not meet the default 64 KiB limit on its second device.  MV_ONCE_PER_DEVICE(expr): 0 when expr returned 0 on this device
+// (evaluated on first use there), -1 otherwise.
+#define MV_ONCE_PER_DEVICE(expr_)                                                                              \
+  ([&]() -> int {                                                                                              \
+    static std::atomic<signed char> st_[32] = {};                                                              \
+    int d_ = 0;                                                                                                \
+    if (hipGetDevice(&d_) != hipSuccess || d_ < 0 || d_ >= 32) return (expr_) == 0 ? 0 : -1;                   \
+    signed char s_ = st_[d_].load(std::memory_order_acquire);                                                  \
+    if (s_ == 0) {                                                                                             \
+      s_ = (expr_) == 0 ? 1 : -1;                                                                              \
+      st_[d_].store(s_, std::memory_order_release);                                                            \
+    }                                                                                                          \
+    return s_ == 1 ? 0 : -1;                                                                                   \
+  }())
+
 typedef __bf16 bf16_t;
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
 typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
