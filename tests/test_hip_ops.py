@@ -77,7 +77,8 @@ def test_layernorm_strided_rows(ops):
 
 # ---------------------------------------------------------------- bf16 MFMA GEMMs
 NT_SHAPES = [(1576, 192, 192), (1576, 576, 192), (394, 768, 768), (256, 1000, 768), (300, 45, 192), (129, 130, 200),
-             (64, 17, 72), (1, 8, 8), (2560, 3072, 768)]
+             (64, 17, 72), (1, 8, 8), (2560, 3072, 768),
+             (6304, 2304, 768), (6304, 768, 3072)]        # batch 32: 225 tiles of 256^2 (8-phase from 192 tiles on) | 75: stays on 128^2
 
 
 @pytest.mark.parametrize("M,N,K", NT_SHAPES)
@@ -301,8 +302,9 @@ def test_gemm_nt_embed_epilogue(ops):
 
 
 TN_SHAPES = [(1576, 192, 576), (1600, 192, 576), (4096, 200, 136), (1576, 768, 192), (5000, 768, 768), (256, 48, 768), (100, 136, 200), (63, 8, 8),
-             (20000, 3072, 768), (9456, 768, 2304), (19700, 3072, 768), (4097, 768, 768)]   # the last three: ragged contractions
-                                                                                       # (197 x 48 / x 100 rows): ring + tail
+             (20000, 3072, 768), (9456, 768, 2304), (19700, 3072, 768), (4097, 768, 768),   # these three: ragged contractions
+             (6304, 768, 768), (6304, 768, 2304)]   # batch 32: 9 tiles x 13 splits -> the 128-tile kernel | 27 x 9 -> the ring
+                                                                                    # (197 x 48 / x 100 rows): ring + tail
 
 
 @pytest.mark.parametrize("Kc,M,N", TN_SHAPES)
