@@ -137,7 +137,8 @@ int mv_attention_fwd(const void* qkv, void* out, float* lse, int B, int N, int H
 int mv_attention_bwd(const void* qkv, const void* out, const void* dout, const float* lse, void* dqkv, float* colsum,
                      int B, int N, int H, float scale, mv_stream_t stream);
 /* Test / tuning hook (process-global, atomic, like mv_gemm_force_variant): backward kernel for the following
- * mv_attention_bwd calls -- 0 auto (N <= 208: 4; N <= 288: 2; else 8), 4 = dS exchanged through LDS (N <= 208), 2 = two
+ * mv_attention_bwd calls -- 0 auto (N <= 208: 4; N <= 288: 2; else 8), 4 = dS exchanged through LDS (N <= 208), 5 = the same
+ * with two waves of 512 registers per workgroup (192 < N <= 208; equal results up to the placement of the softmax scale), 2 = two
  * barrier-free passes (N <= 288), 8 = the eight-wave kernel (N <= 320).  A variant that cannot take the length falls back
  * to auto. */
 int mv_attention_bwd_force(int variant);
