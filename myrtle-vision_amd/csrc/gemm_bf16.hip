@@ -1075,7 +1075,7 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_8phase_kernel(const bf16_t* __
   const __amdgpu_buffer_rsrc_t rsB = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(B), (short)0, (int)((unsigned)N * (unsigned)ldb * 2u), 0x00020000);
   constexpr bool buf_dma = BUFDMA;
 #define P8_STAGE(buf_, slot_, kt_)                                                      \
-  if (MV_ABLATE != 128) {                                                               \
+  if (!(MV_ABLATE >= 64 && (MV_ABLATE & 128))) {                                                               \
     char* l_ = wave_lds + ((buf_) * 4 + (slot_)) * P8_SLOT;                             \
     if constexpr (buf_dma) {                                                            \
       const int so_ = (kt_) * 128;                                                      \
@@ -1107,7 +1107,7 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_8phase_kernel(const bf16_t* __
   const char* const a_rd = smem + 64 * wm * 128;
   const char* const b_rd = smem + 32 * wn * 128;
   bf16x8 af[4][2], bf0[2][2], bf1[2][2];
-#if MV_ABLATE == 64
+#if MV_ABLATE >= 64 && (MV_ABLATE & 64)
   {                                              // diagnostic (no fragment reads): the MFMAs run on whatever these hold
     const bf16x8 seed = *reinterpret_cast<const bf16x8*>(A + 8 * lane);
 #pragma unroll
@@ -1117,7 +1117,7 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_8phase_kernel(const bf16_t* __
   }
 #endif
 #define P8_READ_A(buf_, slot_)                                                                               \
-  if (MV_ABLATE != 64) {                                                                                     \
+  if (!(MV_ABLATE >= 64 && (MV_ABLATE & 64))) {                                                                                     \
     const char* s_ = a_rd + ((buf_) * 4 + (slot_)) * P8_SLOT;                                                \
     _Pragma("unroll") for (int i = 0; i < 4; ++i) {                                                          \
       af[i][0] = *reinterpret_cast<const bf16x8*>(s_ + i * 2048 + rf0);                                      \
@@ -1125,7 +1125,7 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_8phase_kernel(const bf16_t* __
     }                                                                                                        \
   }
 #define P8_READ_B(dst_, buf_, slot_)                                                                         \
-  if (MV_ABLATE != 64) {                                                                                     \
+  if (!(MV_ABLATE >= 64 && (MV_ABLATE & 64))) {                                                                                     \
     const char* s_ = b_rd + ((buf_) * 4 + (slot_)) * P8_SLOT;                                                \
     _Pragma("unroll") for (int j = 0; j < 2; ++j) {                                                          \
       dst_[j][0] = *reinterpret_cast<const bf16x8*>(s_ + j * 2048 + rf0);                                    \
@@ -1133,7 +1133,7 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_8phase_kernel(const bf16_t* __
     }                                                                                                        \
   }
 #define P8_MFMA(mb_, nb_, bfx_)                                                                              \
-  if (MV_ABLATE == 256) { /* diagnostic (no MFMAs): the fragments are still "used", so their reads stay */   \
+  if (MV_ABLATE >= 64 && (MV_ABLATE & 256)) { /* diagnostic (no MFMAs): the fragments are still "used", so their reads stay */   \
     _Pragma("unroll") for (int ks = 0; ks < 2; ++ks) {                                                       \
       _Pragma("unroll") for (int i = 0; i < 4; ++i) asm volatile("" ::"v"(af[i][ks]));                       \
       _Pragma("unroll") for (int j = 0; j < 2; ++j) asm volatile("" ::"v"(bfx_[j][ks]));                     \

@@ -1,7 +1,7 @@
 #!/bin/bash
 # Diagnostic: libmyrtle_vision_hip variants with parts of gemm_nt_8phase_kernel removed (results are WRONG by
 # construction): 8 = no epilogue, 16 = no main loop; 32 = whole kernel with per-workgroup
-# time stamps (tools/diag/p8_timeline.py; MODES=32 tools/ablate_gemm8.sh); main loop only: 64 = no fragment reads, 128 = no DMA, 256 = no MFMAs.   build here: tools/ablate_gemm8.sh ; GPU box: tools/ablate_gemm8.sh run
+# time stamps (tools/diag/p8_timeline.py; MODES=32 tools/ablate_gemm8.sh); main loop only, bits may be combined: 64 = no fragment reads, 128 = no DMA, 256 = no MFMAs (320 = the DMA stream and its barriers alone).   build here: tools/ablate_gemm8.sh ; GPU box: tools/ablate_gemm8.sh run
 set -e
 cd "$(dirname "$0")/.."
 CS=myrtle-vision_amd/csrc
