@@ -35,8 +35,10 @@ from myrtle_vision.utils.utils import (cleanup_distributed, get_batch_sizes, ini
 
 
 class ShardSampler(Sampler):
-    """torch DistributedSampler semantics (classification/train.py:116,200): per-epoch seeded permutation, padded
-    to a multiple of the world size, rank r takes indices[r::world]."""
+    """Index for index what ``torch.utils.data.DistributedSampler(dataset)`` yields (classification/train.py:116,200:
+    default arguments, so shuffle, seed 0, no drop_last): ``randperm(n)`` from a generator seeded ``seed + epoch``, padded
+    to a multiple of the world size by repeating the head of the list, rank r takes ``indices[r::world]``
+    (``tests/test_host_cpu.py::test_shard_sampler_is_torch_distributed_sampler``)."""
 
     def __init__(self, n, rank, world, seed=0):
         self.n, self.rank, self.world, self.seed, self.epoch = n, rank, world, seed, 0
@@ -48,7 +50,9 @@ class ShardSampler(Sampler):
     def __iter__(self):
         g = torch.Generator().manual_seed(self.seed + self.epoch)
         idx = torch.randperm(self.n, generator=g).tolist()
-        idx += idx[: self.num_samples * self.world - len(idx)]
+        pad = self.num_samples * self.world - len(idx)
+        if pad > 0:
+            idx += (idx * -(-pad // len(idx)))[:pad]
         return iter(idx[self.rank::self.world])
 
     def __len__(self):
@@ -235,7 +239,7 @@ def train_worker(rank, num_gpus, config, task="classification"):
     plan_t, plan_v = _device_plan(data_config, "transform_ops_train", use_dev), _device_plan(data_config, "transform_ops_val", use_dev)
     trainset = mk("train", "train_files", "transform_ops_train", plan_t)
     valset = mk("eval", "valid_files", "transform_ops_val", plan_v)
-    sampler = ShardSampler(len(trainset), rank, world, seed=train_config["seed"]) if num_gpus > 1 else None
+    sampler = ShardSampler(len(trainset), rank, world) if num_gpus > 1 else None     # seed 0: the reference's default
     train_loader = BatchFeed(trainset, plan_t, task, device, collate, shuffle=(sampler is None), sampler=sampler,
                              batch_size=batch_size, drop_last=train_config["drop_last_batch"])
     val_loader = BatchFeed(valset, plan_v, task, device, collate, batch_size=batch_size,

@@ -60,3 +60,24 @@ def summarize(t: torch.Tensor, head: int = 16):
     w = torch.linspace(-1.0, 1.0, f.numel(), dtype=torch.float64)
     stats = torch.stack([f.sum(), f.norm(), f.abs().max(), (f * w).sum()])
     return torch.cat([stats, f[:head]]).float()
+
+
+def timm_source_shapes(cfg: dict):
+    """Key ORDER and shapes of a timm 0.5.4 ``VisionTransformer.state_dict()`` (cls_token, pos_embed, conv patch
+    embedding, blocks, final norm, head) at the width ``cfg`` names -- the INPUT of the reference's
+    ``rename_timm_state_dict`` (utils/models.py:154-223); values are ``det_param("timm:" + key, shape)``."""
+    D, M, P = cfg["embed_dim"], cfg["mlp_dim"], cfg["patch_size"]
+    n = (cfg["image_size"] // P) ** 2 + 1
+    shapes = {"cls_token": (1, 1, D), "pos_embed": (1, n, D),
+              "patch_embed.proj.weight": (D, 3, P, P), "patch_embed.proj.bias": (D,)}
+    for i in range(cfg["depth"]):
+        b = f"blocks.{i}."
+        shapes.update({b + "norm1.weight": (D,), b + "norm1.bias": (D,),
+                       b + "attn.qkv.weight": (3 * D, D), b + "attn.qkv.bias": (3 * D,),
+                       b + "attn.proj.weight": (D, D), b + "attn.proj.bias": (D,),
+                       b + "norm2.weight": (D,), b + "norm2.bias": (D,),
+                       b + "mlp.fc1.weight": (M, D), b + "mlp.fc1.bias": (M,),
+                       b + "mlp.fc2.weight": (D, M), b + "mlp.fc2.bias": (D,)})
+    shapes.update({"norm.weight": (D,), "norm.bias": (D,),
+                   "head.weight": (cfg["num_classes"], D), "head.bias": (cfg["num_classes"],)})
+    return shapes

@@ -32,7 +32,7 @@ sys.path.insert(0, "/root/reference/src")
 warnings.filterwarnings("ignore")
 
 from oracle import quant_oracle  # noqa: E402
-from oracle.detinit import det_images, det_labels, det_param, summarize  # noqa: E402
+from oracle.detinit import det_images, det_labels, det_param, summarize, timm_source_shapes  # noqa: E402
 
 SITES = []
 
@@ -100,6 +100,8 @@ CASES = {
     # round 3: logits-only fixtures over enough images for a top-1 agreement RATE (eval-mode forward, no backward)
     "base_cls_b32": (dict(decoder="classification", image_size=224, num_classes=1000, **BASE), 32, None, "logits_only"),
     "tiny_cls_b64": (dict(decoder="classification", image_size=224, num_classes=45, **TINY), 64, None, "logits_only"),
+    # round 4: BASELINE config 4 at its own shape -- ViT-B width, 256^2 inputs (257 tokens, bicubic pos-emb resize, seg tail)
+    "base_seg_256": (dict(decoder="segmentation", image_size=256, num_classes=17, **BASE), 1, None, False),
 }
 
 
@@ -201,9 +203,78 @@ def run_case(name, kwargs, batch, q_format, convert):
     return out, meta
 
 
+# ---------------------------------------------------------------- round 4: the reference's timm renaming (row f4)
+TIMM_CFG = dict(embed_dim=64, depth=2, heads=1, mlp_dim=128, patch_size=16, image_size=224, num_classes=10)
+
+
+def gen_timm_rename(here):
+    """Run the REFERENCE's ``rename_timm_state_dict`` (utils/models.py:154-223, rule table :157-188) on a deterministic
+    timm-keyed state dict.  ``timm.create_model`` needs the network; an in-memory ``timm`` module whose ``create_model``
+    returns that state dict stands in for it (as does a one-name ``torchvision.models``: utils/models.py:6 imports
+    ``resnet50`` for the distillation teacher only).  The renaming itself -- rule table, head filter, conv->linear
+    permutation -- is the reference's code, unmodified."""
+    calls = []
+
+    class _TimmViT:
+        def __init__(self, sd):
+            self._sd = sd
+
+        def state_dict(self):
+            return self._sd
+
+    def create_model(name, pretrained=False, num_classes=None, **kw):
+        calls.append([name, bool(pretrained), num_classes])
+        return _TimmViT({k: det_param("timm:" + k, s) for k, s in timm_source_shapes(TIMM_CFG).items()})
+
+    t = types.ModuleType("timm")
+    t.create_model = create_model
+    sys.modules["timm"] = t
+    tv, tvm = types.ModuleType("torchvision"), types.ModuleType("torchvision.models")
+    tvm.resnet50 = lambda *a, **k: (_ for _ in ()).throw(RuntimeError("distillation teacher is out of scope"))
+    tv.models = tvm
+    sys.modules.setdefault("torchvision", tv)
+    sys.modules.setdefault("torchvision.models", tvm)
+    from myrtle_vision.utils import models as ref_models
+    assert "/root/reference/" in ref_models.__file__
+
+    vit_config = {"embed_dim": TIMM_CFG["embed_dim"], "patch_size": TIMM_CFG["patch_size"]}
+    out = ref_models.rename_timm_state_dict("vit_nano_patch16_224", vit_config, TIMM_CFG["num_classes"])
+    src = timm_source_shapes(TIMM_CFG)
+    meta = {"cfg": TIMM_CFG, "create_model_calls": calls, "timm_keys": list(src.keys()),
+            "renamed_keys": list(out.keys()),                       # ORDER of the returned dict
+            "shapes": {k: list(v.shape) for k, v in out.items()},
+            "torch": torch.__version__}
+    # which timm key each output came from: values are unique per key, so match on content
+    origin = {}
+    for nk, v in out.items():
+        for ok, s in src.items():
+            w = det_param("timm:" + ok, s)
+            if w.numel() == v.numel() and torch.equal(w.flatten().sort().values, v.flatten().sort().values):
+                origin[nk] = ok
+        assert nk in origin, nk
+    meta["origin"] = origin
+    meta["dropped"] = [k for k in src if k not in origin.values()]
+    # the reference loads the result with strict=False and asserts no unexpected keys (segmentation/train.py:164-175)
+    vit = ViT(patch_size=16, q_format="FP32", decoder="classification", image_size=TIMM_CFG["image_size"],
+              num_classes=TIMM_CFG["num_classes"], dim=TIMM_CFG["embed_dim"], depth=TIMM_CFG["depth"],
+              heads=TIMM_CFG["heads"], mlp_dim=TIMM_CFG["mlp_dim"])
+    res = vit.load_state_dict(out, strict=False)
+    assert res.unexpected_keys == []
+    meta["missing_keys_after_load"] = list(res.missing_keys)
+    arrays = {"patch_to_embedding.weight": out["patch_to_embedding.weight"].contiguous().numpy()}
+    for k, v in out.items():
+        arrays["sum:" + k] = summarize(v).numpy()
+    np.savez_compressed(os.path.join(here, "timm_rename.npz"), **arrays)
+    with open(os.path.join(here, "timm_rename.json"), "w") as f:
+        json.dump(meta, f, indent=1, sort_keys=True)
+    print(f"timm_rename: {len(out)} renamed keys, dropped {meta['dropped']}, missing after load {meta['missing_keys_after_load']}")
+
+
 def main():
     only = set(sys.argv[1:])
     here = os.path.dirname(os.path.abspath(__file__))
+    if not only or "timm_rename" in only:
+        gen_timm_rename(here)
     for name, (kwargs, batch, qf, conv) in CASES.items():
         if only and name not in only:
             continue

@@ -282,6 +282,54 @@ def test_rename_timm_state_dict_rules():
         rename_timm_state_dict("vit_base_patch16_224", {"embed_dim": D, "patch_size": 16}, 10)
 
 
+def test_rename_timm_matches_reference_fixture(tmp_path):
+    """Row f4 pinned: ``tests/golden/timm_rename.*`` is what the REFERENCE's ``rename_timm_state_dict`` (utils/models.py:154-223,
+    run by ``gen_golden.py`` on a formula-defined timm-keyed state dict) returned -- key order, which timm key each output
+    came from, the dropped classifier head, the conv -> linear permutation of the patch embedding, every value."""
+    from myrtle_vision.models.vit import ViT
+    from myrtle_vision.utils.models import rename_timm_state_dict
+    from oracle.detinit import det_param, summarize, timm_source_shapes
+    arrays, meta = load_golden("timm_rename")
+    cfg = meta["cfg"]
+    src = {k: det_param("timm:" + k, s) for k, s in timm_source_shapes(cfg).items()}
+    assert list(src) == meta["timm_keys"]
+    path = str(tmp_path / "vit_nano_patch16_224.pth")
+    torch.save(src, path)
+    for source in (path, src):                                         # a local file (what engine.train_worker passes) or a dict
+        out = rename_timm_state_dict(source, {"embed_dim": cfg["embed_dim"], "patch_size": cfg["patch_size"]}, cfg["num_classes"])
+        assert list(out) == meta["renamed_keys"]                       # same keys, same ORDER
+        assert not set(meta["dropped"]) & set(out)
+        assert {k: list(v.shape) for k, v in out.items()} == meta["shapes"]
+        assert np.array_equal(out["patch_to_embedding.weight"].numpy(), arrays["patch_to_embedding.weight"])
+        for k, v in out.items():
+            assert np.array_equal(summarize(v).numpy(), arrays["sum:" + k]), k
+            if k != "patch_to_embedding.weight":
+                assert torch.equal(v, src[meta["origin"][k]]), k
+    vit = ViT(patch_size=cfg["patch_size"], q_format="FP32", decoder="classification", image_size=cfg["image_size"],
+              num_classes=cfg["num_classes"], dim=cfg["embed_dim"], depth=cfg["depth"], heads=cfg["heads"], mlp_dim=cfg["mlp_dim"])
+    res = vit.load_state_dict(out, strict=False)                       # segmentation/train.py:164-175
+    assert res.unexpected_keys == [] and list(res.missing_keys) == meta["missing_keys_after_load"]
+
+
+@pytest.mark.parametrize("n,world", [(10, 2), (11, 2), (1000, 8), (1003, 8), (7, 4), (3, 8), (1, 2), (64, 1)])
+def test_shard_sampler_is_torch_distributed_sampler(n, world):
+    """``engine.ShardSampler`` yields exactly ``DistributedSampler(dataset)``'s indices (classification/train.py:116: default
+    arguments -> seed 0), for every rank and epoch, including the wrap-around padding and n < world."""
+    from torch.utils.data import DistributedSampler
+    from myrtle_vision.engine import ShardSampler
+    ds = list(range(n))
+    for epoch in (0, 1, 5):
+        seen = []
+        for rank in range(world):
+            ref = DistributedSampler(ds, num_replicas=world, rank=rank)
+            ours = ShardSampler(n, rank, world)
+            ref.set_epoch(epoch)
+            ours.set_epoch(epoch)
+            assert list(ours) == list(ref) and len(ours) == len(ref)
+            seen += list(ours)
+        assert set(seen) == set(range(n))
+
+
 def test_get_models_reads_reference_config_schema(tmp_path):
     from myrtle_vision.utils.models import get_models
     cfg = json.load(open(os.path.join(ROOT, "classification", "train_configs", "vit_tiny.json")))

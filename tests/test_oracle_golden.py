@@ -10,7 +10,7 @@ from oracle.vit_oracle import ViTConfig, loss_and_grads, vit_forward
 
 from conftest import load_golden
 
-FP32_CASES = ["micro_cls", "micro_cls_256", "micro_seg", "micro_seg_256", "tiny_cls", "base_cls", "base_seg"]
+FP32_CASES = ["micro_cls", "micro_cls_256", "micro_seg", "micro_seg_256", "tiny_cls", "base_cls", "base_seg", "base_seg_256"]
 
 
 def _setup(name):

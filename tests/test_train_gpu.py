@@ -55,6 +55,45 @@ def test_train_loop_writes_reloadable_checkpoints(tmp_path, task, capsys):
     assert 0.0 <= res["accuracy"] <= 1.0
 
 
+def test_train_starts_from_local_timm_backbone(tmp_path, capsys):
+    """Row f4 end to end (segmentation/train.py:98,163-175; classification configs carry the same key): ``pretrained_backbone``
+    = a LOCAL timm-format state dict.  The loop must start from exactly the renamed weights -- the iteration-0 checkpoint it
+    writes before the first optimizer step holds them bit for bit, the decoder head (which the reference drops) stays at its
+    random init, and the first forward equals a model that received the renamed dict through ``load_state_dict`` directly."""
+    from myrtle_vision.engine import train_worker
+    from myrtle_vision.models.vit import ViT
+    from myrtle_vision.utils.models import rename_timm_state_dict
+    from oracle.detinit import det_images, det_param, timm_source_shapes
+    cfg = _config(tmp_path, "classification")
+    v = cfg["vit_config"]
+    shape_cfg = dict(embed_dim=v["embed_dim"], mlp_dim=v["mlp_dim"], patch_size=v["patch_size"], image_size=v["image_size"],
+                     depth=v["depth"], num_classes=1000)                   # a timm checkpoint carries its own 1000-class head
+    src = {k: det_param("timm:" + k, s) for k, s in timm_source_shapes(shape_cfg).items()}
+    path = str(tmp_path / "vit_tiny_patch16_224.pth")
+    torch.save(src, path)
+    cfg["train_config"]["pretrained_backbone"] = path
+    train_worker(0, 1, copy.deepcopy(cfg), "classification")
+    assert "WARNING: pretrained_backbone" not in capsys.readouterr().out
+    ck = torch.load(os.path.join(cfg["train_config"]["output_directory"], "vit_000000"), map_location="cpu", weights_only=False)
+    renamed = rename_timm_state_dict(path, v, 45)
+    assert len(renamed) == 4 + 12 * v["depth"]
+    for k, w in renamed.items():
+        assert torch.equal(ck["model"][k], w), k
+    assert not torch.equal(ck["model"]["decoder.linear.weight"][:, :8], src["head.weight"][:45, :8])
+    # the first forward: checkpointed start state == renamed dict loaded directly (+ the loop's random decoder)
+    kw = dict(patch_size=v["patch_size"], q_format="FP32", decoder="classification", image_size=v["image_size"], num_classes=45,
+              dim=v["embed_dim"], depth=v["depth"], heads=v["heads"], mlp_dim=v["mlp_dim"])
+    a, b = ViT(**kw), ViT(**kw)
+    a.load_state_dict(ck["model"])
+    res = b.load_state_dict(renamed, strict=False)
+    assert res.unexpected_keys == []
+    b.load_state_dict({k: ck["model"][k] for k in res.missing_keys}, strict=False)
+    a, b = a.cuda().eval(), b.cuda().eval()
+    img = det_images("timm_backbone", 4, v["image_size"]).cuda()
+    with torch.no_grad():
+        assert torch.equal(a(img), b(img))
+
+
 def test_quantized_evaluation_path(tmp_path):
     from myrtle_vision.engine import evaluate, train_worker
     cfg = _config(tmp_path, "classification")

@@ -18,7 +18,7 @@ pytestmark = pytest.mark.gpu
 from conftest import load_golden  # noqa: E402
 from oracle.detinit import det_images, det_labels, det_param, summarize  # noqa: E402
 
-CASES = ["micro_cls", "micro_cls_256", "micro_seg", "micro_seg_256", "tiny_cls", "base_cls", "base_seg"]
+CASES = ["micro_cls", "micro_cls_256", "micro_seg", "micro_seg_256", "tiny_cls", "base_cls", "base_seg", "base_seg_256"]
 BF16_LOGITS, BF16_GRAD = 1.5e-2, 2e-2
 
 
