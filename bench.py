@@ -292,6 +292,7 @@ def main():
         args.no_kernel_timer = True
     for _ in range(args.warmup):
         loss = step()
+    reducer.exposed_ms(reset=True)                            # drop the warm-up steps' spans (lazy RCCL / communicator setup)
     timer = None if args.no_kernel_timer else ops.KernelTimer(sample_every=args.timer_every)
     if world > 1 or force_dist:
         dist.barrier()

@@ -2299,7 +2299,8 @@ extern "C" int mv_gemm_nt_bf16_ksplit(const void* A, int lda, const void* B, int
   MV_REQUIRE(K % (128 * splits) == 0 && N % 4 == 0, MV_ERR_UNSUPPORTED);
   MV_REQUIRE(lda % 8 == 0 && ldb % 8 == 0 && lda >= K && ldb >= K, MV_ERR_ALIGN);
   MV_REQUIRE(mv_aligned16(A) && mv_aligned16(B) && mv_aligned16(slabs), MV_ERR_ALIGN);
-  MV_REQUIRE((long)M * lda < (1L << 32) && (long)N * ldb < (1L << 32), MV_ERR_UNSUPPORTED);   // 32-bit staging offsets
+  // buffer-descriptor DMA: BYTE offsets and the descriptor's extent are 32-bit (as in p8_ok / launch_nt)
+  MV_REQUIRE((long)M * lda < (1L << 31) && (long)N * ldb < (1L << 31), MV_ERR_UNSUPPORTED);
   const int a8 = MV_ONCE_PER_DEVICE(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_nt_8phase_kernel<MV_EPI_NONE, float, NT_BF16, true>),
                                             hipFuncAttributeMaxDynamicSharedMemorySize, P8_SMEM) == hipSuccess ? 0 : -1);
   if (a8) return MV_ERR_LAUNCH;

@@ -169,7 +169,7 @@ class PreparedWeight:
     """bf16 copies of one nn.Linear weight [N_out, K_in]: ``w`` [N_out, pad8(K_in)] for the forward product and
     ``wt`` [K_in, pad8(N_out)] (transposed) for the input-gradient product; pads are zero."""
 
-    __slots__ = ("w", "wt", "ldw", "ldt", "n_out", "k_in", "version", "ptr", "ref", "epoch")
+    __slots__ = ("w", "wt", "ldw", "ldt", "n_out", "k_in", "version", "ptr", "ref", "epoch", "owner")
 
 
 class _WeightPrepItem(ctypes.Structure):          # mv_weight_prep_item (include/myrtle_vision_hip.h)
@@ -178,57 +178,93 @@ class _WeightPrepItem(ctypes.Structure):          # mv_weight_prep_item (include
                 ("first_block", ctypes.c_int)]
 
 
-# Cache epoch: the prepared copies of a weight are valid while (its _version, the epoch) are unchanged.  The epoch moves when
-# (a) ``invalidate_weight_caches()`` is called -- ParamArena.bump_versions() after a raw-pointer write (the AdamW kernel), a
-# replayed HIP graph (utils.graph) -- or (b) ANY registered arena buffer is written through torch (its ``_version`` counts
-# in-place ops on the flat tensor: loading into the arena, an EMA, a custom collective), which a parameter's own version
-# counter never sees.  One integer compare per lookup; nothing is refreshed until a weight is used again.
+# Cache epoch: the prepared copies of a weight are valid while (its _version, its owner's epoch) are unchanged.  A weight's
+# OWNER is the registered parameter arena whose flat buffer holds it (None for a free-standing parameter).  An owner's epoch
+# moves when (a) ``invalidate_weight_caches(flat)`` names it -- ParamArena.bump_versions() after a raw-pointer write (the AdamW
+# kernel), a replayed HIP graph (utils.graph) -- (b) ITS flat buffer is written through torch (its ``_version`` counts in-place
+# ops on the flat tensor: loading into the arena, an EMA, a custom collective), which a parameter's own version counter never
+# sees, or (c) ``invalidate_weight_caches()`` without an argument (everything).  Epochs only ever grow: an arena that dies folds
+# its last version into its generation, so a value can never repeat, and one model's optimizer step does not make another
+# (frozen, EMA, evaluation) model's copies stale.  One integer compare per lookup; nothing is refreshed until a weight is used.
 _generation = [0]
-_arena_refs = []
+
+
+class _Owner:
+    """One registered arena: weak reference to the flat tensor, its address range, a generation counter."""
+    __slots__ = ("ref", "lo", "hi", "gen", "last")
+
+    def __init__(self, flat):
+        self.ref, self.lo, self.gen, self.last = weakref.ref(flat), flat.data_ptr(), 0, flat._version
+        self.hi = self.lo + flat.numel() * flat.element_size()
+
+    def epoch(self) -> int:
+        t = self.ref()
+        if t is not None:
+            self.last = t._version
+        return self.gen + self.last
+
+
+_owners = []
 
 
 def register_arena(flat: torch.Tensor):
-    _arena_refs.append(weakref.ref(flat))
+    for o in _owners:
+        if o.ref() is None:
+            _prep_table.pop(id(o), None)
+    _owners[:] = [o for o in _owners if o.ref() is not None]
+    _owners.append(_Owner(flat))
 
 
-def invalidate_weight_caches():
-    _generation[0] += 1
+def _owner_of(weight):
+    ptr = weight.data_ptr()
+    for o in reversed(_owners):                     # the newest registration wins if an address range was recycled
+        if o.lo <= ptr < o.hi and o.ref() is not None:
+            return o
+    return None
 
 
-def cache_epoch() -> int:
-    e = _generation[0]
-    dead = False
-    for r in _arena_refs:
-        t = r()
-        if t is None:
-            dead = True
-        else:
-            e += t._version
-    if dead:
-        _arena_refs[:] = [r for r in _arena_refs if r() is not None]
-    return e
+def invalidate_weight_caches(flat=None):
+    """Move the epoch of the arena ``flat`` (every prepared copy of ITS parameters becomes stale), or of everything."""
+    if flat is None:
+        _generation[0] += 1
+        return
+    ptr = flat.data_ptr()
+    for o in _owners:
+        if o.lo == ptr and o.ref() is flat:
+            o.gen += 1
+            return
+    _generation[0] += 1                             # not registered: be safe
+
+
+def cache_epoch(owner=None) -> int:
+    return _generation[0] + (owner.epoch() if owner is not None else 0)
 
 
 _prepared = {}   # id(parameter) -> PreparedWeight (identity-keyed: tensors define == elementwise); entries die with the tensor
-_prep_table = {}  # the last batch's item table on the device: key (ids, pointers) -> (uint8 tensor, count, total_blocks)
+_prep_table = {}  # per owner: id(owner) -> (key (ids, pointers), uint8 item table on the device, count, total_blocks)
+_capture_keep = None   # utils.graph: while a step is being captured, every device table / weight copy the capture reads is
+#                        appended here, and the GraphedTrainStep keeps the list for as long as its graph exists
 
 
-def _refresh_stale(device):
-    """After an optimizer step EVERY prepared weight is stale: refresh them all in one launch (mv_weight_prep_batch)
-    instead of one ~7 us launch per nn.Linear at its first use."""
+def _refresh_stale(device, owner, only=None):
+    """After an optimizer step EVERY prepared weight of that optimizer's arena is stale: refresh them all in one launch
+    (mv_weight_prep_batch) instead of one ~7 us launch per nn.Linear at its first use.  Only weights of ``owner`` are
+    touched (``only``: a single weight, for free-standing parameters inside a graph capture)."""
     stale = []
-    epoch = cache_epoch()
     for pw in list(_prepared.values()):                      # a finalizer may pop entries while we look
         w = pw.ref() if pw.ref is not None else None
-        if w is None or pw.w.device != device or not w.is_contiguous():
+        if w is None or pw.owner is not owner or pw.w.device != device or not w.is_contiguous():
             continue
-        if pw.version != w._version or pw.ptr != w.data_ptr() or pw.epoch != epoch:
+        if only is not None and w is not only:
+            continue
+        if pw.version != w._version or pw.ptr != w.data_ptr() or pw.epoch != cache_epoch(owner):
             stale.append((pw, w))
     if not stale:
         return
+    epoch = cache_epoch(owner)
     key = tuple((id(w), w.data_ptr(), pw.w.data_ptr()) for pw, w in stale)
-    ent = _prep_table.get(key)
-    if ent is None:
+    ent = _prep_table.get(id(owner))
+    if ent is None or ent[0] != key:
         items = (_WeightPrepItem * len(stale))()
         first = 0
         for it, (pw, w) in zip(items, stale):
@@ -237,30 +273,34 @@ def _refresh_stale(device):
             it.tiles_x, it.first_block = (max(pw.k_in, pw.ldw) + 63) // 64, first
             first += it.tiles_x * ((max(pw.n_out, pw.ldt) + 63) // 64)
         table = torch.frombuffer(bytearray(bytes(items)), dtype=torch.uint8).to(device)
-        _prep_table.clear()
-        ent = _prep_table[key] = (table, len(stale), first)
-    table, count, total = ent
+        ent = _prep_table[id(owner)] = (key, table, len(stale), first)
+    _, table, count, total = ent
+    if _capture_keep is not None:                            # the graph replays this launch: it owns what the launch reads
+        _capture_keep.append((table, [(pw.w, pw.wt) for pw, _ in stale]))
     check(lib().mv_weight_prep_batch(_p(table), count, total, _s()), "weight_prep_batch", count=count)
     for pw, w in stale:
         pw.version, pw.ptr, pw.epoch = w._version, w.data_ptr(), epoch
 
 
 def prepared_weight(weight: torch.Tensor) -> PreparedWeight:
-    """Cached bf16 / transposed-bf16 copies, refreshed when the parameter changed (``_version`` or storage)."""
+    """Cached bf16 / transposed-bf16 copies, refreshed when the parameter changed (``_version``, storage, owner epoch)."""
     key = id(weight)
     pw = _prepared.get(key)
-    epoch = cache_epoch()
-    if pw is not None and pw.version == weight._version and pw.ptr == weight.data_ptr() and pw.epoch == epoch:
+    if pw is not None and pw.version == weight._version and pw.ptr == weight.data_ptr() and pw.epoch == cache_epoch(pw.owner):
         return pw
     require_cuda(weight)
     n_out, k_in = weight.shape
+    owner = _owner_of(weight)
+    if pw is not None and pw.owner is not owner:
+        pw.owner, pw.epoch = owner, -1                      # the parameter moved into (or out of) an arena
     if pw is not None and pw.n_out == n_out and pw.k_in == k_in and pw.w.device == weight.device and weight.is_contiguous():
-        _refresh_stale(weight.device)                       # this weight and every other stale one
-        if pw.version == weight._version and pw.ptr == weight.data_ptr() and pw.epoch == epoch:
+        # this weight and every other stale one of the same arena (a free-standing weight inside a capture: itself only)
+        _refresh_stale(weight.device, owner, only=weight if (owner is None and _capture_keep is not None) else None)
+        if pw.version == weight._version and pw.ptr == weight.data_ptr() and pw.epoch == cache_epoch(owner):
             return pw
     if pw is None or pw.n_out != n_out or pw.k_in != k_in or pw.w.device != weight.device:
         pw = PreparedWeight()
-        pw.n_out, pw.k_in = n_out, k_in
+        pw.n_out, pw.k_in, pw.owner = n_out, k_in, owner
         pw.ldw, pw.ldt = pad8(k_in), pad8(n_out)
         pw.w = torch.empty(n_out, pw.ldw, dtype=torch.bfloat16, device=weight.device)
         pw.wt = torch.empty(k_in, pw.ldt, dtype=torch.bfloat16, device=weight.device)
@@ -271,9 +311,11 @@ def prepared_weight(weight: torch.Tensor) -> PreparedWeight:
     wd = weight.detach()
     if not wd.is_contiguous():
         wd = wd.contiguous()
+    if _capture_keep is not None:
+        _capture_keep.append((wd, [(pw.w, pw.wt)]))
     check(lib().mv_weight_prep(_p(wd), _p(pw.w), pw.ldw, _p(pw.wt), pw.ldt, n_out, k_in, _s()), "weight_prep",
           R=n_out, C=k_in)
-    pw.version, pw.ptr, pw.epoch = weight._version, weight.data_ptr(), epoch
+    pw.version, pw.ptr, pw.epoch = weight._version, weight.data_ptr(), cache_epoch(owner)
     return pw
 
 
@@ -402,7 +444,7 @@ def split_weight(weight: torch.Tensor, which: str) -> torch.Tensor:
     transposed weight, dx = dy W); refreshed when the parameter changed."""
     key = id(weight)
     sw = _split_weights.get(key)
-    epoch = cache_epoch()
+    epoch = cache_epoch(_owner_of(weight))
     if sw is None or sw.version != weight._version or sw.ptr != weight.data_ptr() or sw.epoch != epoch:
         if sw is None:
             weakref.finalize(weight, _split_weights.pop, key, None)

@@ -119,9 +119,8 @@ class GradAllReducer:
                     self._launch(b)
             for h in self.handles:
                 h.wait()                                      # the compute stream waits for the collective's stream
-            if self.stage is not None:
-                for lo, hi, _, _ in self.ranges:
-                    _convert(self.stage[lo:hi], self.arena.flat_grad[lo:hi])
+            if self.stage is not None:                        # the buckets tile [0, total): widen back in one launch
+                _convert(self.stage, self.arena.flat_grad)
             if span is not None:
                 span[1].record()
                 self._spans.append(span)

@@ -14,8 +14,9 @@ What makes the step capturable here:
 * dropout must be off (its mask seed is a host draw per call: a replay would repeat one mask) -- checked.
 Single process only: the RCCL exchange is not captured (world size 1); a multi-GPU run keeps the eager step.
 
-After every replay the weight caches' epoch moves (``ops.invalidate_weight_caches``): the graph refreshed its own bf16
+After every replay the epoch of THIS optimizer's arena moves (``ParamArena.bump_versions``): the graph refreshed its bf16
 weight copies BEFORE the optimizer step it contains, so an eager forward afterwards (validation) must prepare them again.
+The graph keeps alive every device table and weight copy its captured preparation launches read or write.
 """
 import torch
 
@@ -56,8 +57,16 @@ class GraphedTrainStep:
         self.graph = torch.cuda.CUDAGraph()
         optimizer.zero_grad()
         optimizer.arena.bump_versions()                 # the capture must CONTAIN the weight preparation: every copy stale
-        with torch.cuda.graph(self.graph):
-            self.loss = self._eager_step(advance=False)
+        # The graph OWNS what it captured: the device table of the batched weight preparation and the bf16 copies it writes
+        # (ops._capture_keep).  The preparation inside the capture covers THIS optimizer's arena only (ops._refresh_stale is
+        # per owner), so other models may come and go between replays without the graph reading a recycled table.
+        self._keep = []
+        ops._capture_keep = self._keep
+        try:
+            with torch.cuda.graph(self.graph):
+                self.loss = self._eager_step(advance=False)
+        finally:
+            ops._capture_keep = None
         self.warmup_steps = warmup
 
     def _eager_step(self, advance=True):
@@ -72,5 +81,5 @@ class GraphedTrainStep:
         self.labels.copy_(labels, non_blocking=True)
         self.optimizer.advance()                        # step count, lr, bias corrections -> device (three floats per group)
         self.graph.replay()
-        ops.invalidate_weight_caches()                  # parameters changed behind the host-side caches' back
+        self.optimizer.arena.bump_versions()            # parameters changed behind the host-side caches' back (this arena only)
         return self.loss

@@ -43,11 +43,12 @@ class ParamArena:
         no_decay = [(n, p) for n, p in named if (p.ndim <= 1 or n.endswith(".bias"))]
         self.names: List[str] = [n for n, _ in decay + no_decay]
         self.params: List[torch.nn.Parameter] = [p for _, p in decay + no_decay]
-        # each tensor starts on a 16-byte boundary so kernels can use vector access on any slice
+        # each tensor starts on a 32-byte boundary: kernels can use 16-byte vector access on any slice of the fp32 arena AND
+        # of its bf16 staging copy (the half-width gradient exchange casts bucket slices, utils/ddp.py)
         offs, total = [], 0
         for _, p in decay + no_decay:
             offs.append(total)
-            total += (p.numel() + 3) & ~3
+            total += (p.numel() + 7) & ~7
         self.n_decay = offs[len(decay)] if no_decay and decay else (total if decay else 0)
         self.offsets, self.total = offs, total
         self.flat_param = torch.zeros(total, dtype=torch.float32, device=dev)
@@ -92,7 +93,7 @@ class ParamArena:
         """The AdamW kernel writes through raw pointers: tell autograd / the bf16 weight cache the data changed."""
         for p in self.params:
             torch.autograd.graph.increment_version(p)
-        ops.invalidate_weight_caches()
+        ops.invalidate_weight_caches(self.flat_param)
 
 
 class AdamW:

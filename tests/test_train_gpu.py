@@ -298,6 +298,74 @@ def test_graphed_step_equals_eager_step(task):
         assert torch.equal(vit_g(batches[0][0]), vit_e(batches[0][0]))
 
 
+def test_graph_owns_its_weight_tables_while_other_models_come_and_go():
+    """the captured step contains a batched weight-preparation launch that reads a device TABLE of
+    pointers.  The graph must own that table and prepare ITS arena's weights only: other models are created, used (which
+    rebuilds the preparation tables of THEIR owners) and freed between replays, the allocator is pushed to recycle their
+    memory, and the replays must still equal the eager steps bit for bit.  Also: one model's optimizer step does not make
+    another model's prepared copies stale, and epochs never repeat after an arena dies."""
+    import gc
+    from myrtle_vision.hip import ops
+    from myrtle_vision.hip.functional import cross_entropy
+    from myrtle_vision.models.vit import ViT
+    from myrtle_vision.utils.graph import GraphedTrainStep
+    from myrtle_vision.utils.optim import AdamW, ParamArena
+    from myrtle_vision.utils.utils import seed_everything
+    kw = dict(decoder="classification", num_classes=7, image_size=224, patch_size=16, dim=128, depth=2, heads=2, mlp_dim=256)
+    loss_fn = lambda m, x, y: cross_entropy(m(x), y)
+    g = torch.Generator().manual_seed(3)
+    batches = [(torch.randn(4, 3, 224, 224, generator=g).cuda(), torch.randint(0, 7, (4,), generator=g).cuda()) for _ in range(5)]
+
+    def build(seed=21, with_opt=True):
+        seed_everything(seed)
+        vit = ViT(precision="bf16", q_format="FP32", **kw).cuda().train()
+        opt = AdamW(ParamArena(vit.named_parameters(), skip=vit.unused_parameter_names()), lr=1e-3, weight_decay=0.05) if with_opt else None
+        return vit, opt
+
+    vit_e, opt_e = build()
+    for i in [0, 0, 0, 1, 2, 3, 4]:
+        opt_e.zero_grad()
+        loss_fn(vit_e, *batches[i]).backward()
+        opt_e.step()
+    want = opt_e.arena.flat_param.clone()
+    del vit_e, opt_e
+
+    vit_g, opt_g = build()
+    graphed = GraphedTrainStep(vit_g, opt_g, loss_fn, *batches[0], warmup=3)
+    assert graphed._keep, "the capture recorded no preparation launch to own"
+    epochs_seen = []
+    for i in (1, 2, 3, 4):
+        # another model with its own arena: trains a step (its table replaces nothing of the graph's), then dies
+        other, opt_o = build(seed=100 + i)
+        opt_o.zero_grad()
+        loss_fn(other, *batches[0]).backward()
+        opt_o.step()
+        with torch.no_grad():
+            other.eval()(batches[0][0])
+        # a free-standing evaluation model (no arena): its prepared copies must survive the graph's replays untouched
+        frozen, _ = build(seed=7, with_opt=False)
+        frozen.eval()
+        with torch.no_grad():
+            y0 = frozen(batches[0][0]).clone()
+        w = frozen.transformer.layers[0][0].fn.fn.to_qkv.weight
+        pw_before = ops.prepared_weight(w)
+        stamp = (pw_before.version, pw_before.ptr, pw_before.epoch)
+        graphed(*batches[i])
+        torch.cuda.synchronize()
+        pw_after = ops.prepared_weight(w)
+        assert pw_after is pw_before and (pw_after.version, pw_after.ptr, pw_after.epoch) == stamp    # not re-prepared
+        with torch.no_grad():
+            assert torch.equal(frozen(batches[0][0]), y0)
+        epochs_seen.append(ops.cache_epoch(ops._owner_of(vit_g.transformer.layers[0][0].fn.fn.to_qkv.weight)))
+        del other, opt_o, frozen, w, pw_before, pw_after
+        gc.collect()
+        torch.cuda.empty_cache()
+        junk = [torch.full((1 << 20,), float(i), device="cuda") for _ in range(8)]    # recycle whatever was freed
+        del junk
+    assert epochs_seen == sorted(set(epochs_seen)), epochs_seen                      # strictly increasing: never repeats
+    assert torch.equal(opt_g.arena.flat_param, want)
+
+
 def test_direct_arena_write_refreshes_weight_copies():
     """a torch-side in-place write to ``arena.flat_param`` (an EMA, loading into the arena) is seen by the bf16
     weight caches without any bump_versions() call -- the arena buffer's own version counter is part of the cache epoch."""
