@@ -43,45 +43,73 @@ VIT_B = dict(decoder="classification", image_size=224, patch_size=16, num_classe
              mlp_dim=3072, dropout=0.0, emb_dropout=0.0)
 
 
+def _lib_digest16():
+    """First 16 hex digits of the source digest the loaded library was built from (myrtle_vision/hip/build.py)."""
+    try:
+        with open(os.path.join(ROOT, "myrtle-vision_amd", "lib", "build.sha256")) as f:
+            return f.read().strip()[:16]
+    except OSError:
+        return None
+
+
 def _latest_profile(suffix):
-    """Newest committed profiles/rNN_<suffix> (rounds sort lexicographically), parsed, or None."""
+    """Newest committed profiles/rNN_<suffix> (rounds sort lexicographically) -> (parsed, file name, refusal reason or None).
+    A counter summary is quoted only for the library it was measured on: its ``lib_source_digest16`` (or its evidence set's
+    ``<tag>_stamp.json``) must equal the digest of the library this process loaded -- a kernel change without a refreshed
+    evidence set reports ``null`` and says why instead of stale counters."""
     import glob
     # rNN_<suffix> or rNN_<tag>_<suffix> (tools/evidence.sh names its outputs <tag>_<suffix>, e.g. r03_b_pmc_traffic.json)
     files = sorted(glob.glob(os.path.join(ROOT, "profiles", f"r[0-9][0-9]_*{suffix}")))
     if not files:
-        return None
+        return None, None, "no committed counter summary"
+    name = os.path.basename(files[-1])
     try:
         with open(files[-1]) as f:
-            return json.load(f), os.path.basename(files[-1])
-    except (OSError, ValueError):
-        return None
+            d = json.load(f)
+    except (OSError, ValueError) as e:
+        return None, name, f"unreadable: {e}"
+    measured = d.get("lib_source_digest16")
+    if measured is None:
+        try:
+            with open(files[-1][:-len(suffix)] + "stamp.json") as f:
+                measured = json.load(f).get("lib_source_digest16")
+        except (OSError, ValueError):
+            measured = None
+    loaded = _lib_digest16()
+    if measured is None or loaded is None or measured != loaded:
+        return None, name, (f"profiles/{name} was measured on library source digest {measured}, this process loaded {loaded}: "
+                            "counters not quoted (re-run tools/evidence.sh on this tree)")
+    return d, name, None
 
 
 def pmc_traffic(kernel_family):
     """HBM-side bytes per launch of the dominant kernel family, from the committed rocprofv3 PMC passes
     (FETCH_SIZE and WRITE_SIZE in separate runs, FETCH_SIZE doubled per the gfx950 correction of
     MI355X_MICROARCH.md section HBM; tools/pmc_traffic.py -> profiles/rNN_pmc_traffic.json).  Counters cannot be read from
-    inside this process, so this is the last measured value for the same command, or None if none has been committed."""
-    got = _latest_profile("pmc_traffic.json")
+    inside this process, so this is the last measured value for the same command ON THE SAME LIBRARY, else None + the reason."""
+    d, name, why = _latest_profile("pmc_traffic.json")
+    if d is None:
+        return None, {"refused": why}
     try:
-        d, name = got
-        return round(d["kernels"][kernel_family]["hbm_bytes_per_launch"]), {"source": f"profiles/{name}", "commit": d.get("commit")}
-    except (TypeError, KeyError, ValueError):
-        return None, None
+        return round(d["kernels"][kernel_family]["hbm_bytes_per_launch"]), {"source": f"profiles/{name}", "commit": d.get("commit"),
+                                                                             "lib_source_digest16": _lib_digest16()}
+    except (TypeError, KeyError, ValueError) as e:
+        return None, {"refused": f"profiles/{name}: {e!r}"}
 
 
 def pmc_mfma_util():
     """MFMA utilisation (matrix-pipe busy cycles / SIMD-cycles) from the committed SQ counter pass
     (tools/pmc_mfma_util.py -> profiles/rNN_mfma_util.json): the dominant kernel family and the attention + MLP blocks."""
-    got = _latest_profile("mfma_util.json")
+    d, name, why = _latest_profile("mfma_util.json")
+    if d is None:
+        return {"refused": why}
     try:
-        d, name = got
         return {"gemm_nt": round(d["kernels"]["gemm_nt"]["mfma_util"], 4), "gemm_tn": round(d["kernels"]["gemm_tn"]["mfma_util"], 4),
                 "attention": round(d["kernels"]["attention"]["mfma_util"], 4),
                 "attention_mlp_block": round(d["block"]["mfma_util"], 4), "source": f"profiles/{name}",
-                "commit": d.get("commit")}
-    except (TypeError, KeyError, ValueError):
-        return None
+                "commit": d.get("commit"), "lib_source_digest16": _lib_digest16()}
+    except (TypeError, KeyError, ValueError) as e:
+        return {"refused": f"profiles/{name}: {e!r}"}
 
 
 def cpu_baseline(seconds_budget=25.0):
@@ -132,11 +160,28 @@ def self_launch(n_gpus):
     return subprocess.run(cmd, env=env).returncode
 
 
+def set_host_threads(local_world):
+    """N ranks on one node share its host cores: each rank's intra-op pool is its share of the affinity mask (torch's default
+    -- every visible cpu per process -- oversubscribes an 8-rank launch N-fold; torchrun would pin it to 1 instead, which
+    starves rank 0's cpu_baseline leg at N = 1).  The HIP path itself needs one host thread per rank."""
+    try:
+        ncores = len(os.sched_getaffinity(0))
+    except AttributeError:
+        ncores = os.cpu_count() or 1
+    n = max(1, min(16, ncores // max(local_world, 1)))
+    if local_world > 1 or "OMP_NUM_THREADS" not in os.environ:
+        torch.set_num_threads(n)
+    return n
+
+
 def dry_run(args, rank, world):
     """``--dry-run``: the launch / rendezvous / barrier / max-over-ranks / JSON plumbing with NO compute (a sleep stands in
     for the step), runnable without a GPU (gloo): what the CPU test of the multi-process path exercises.  Its JSON line
     says so and carries no throughput."""
     backend = os.environ.get("MV_DIST_BACKEND", "gloo")
+    if args.dry_run_fail_rank is not None and rank == args.dry_run_fail_rank:
+        # rehearsal of a rank that dies before the rendezvous completes: the launcher must fail the command, not hang
+        raise SystemExit(f"rank {rank}: --dry-run-fail-rank")
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("gloo" if backend != "nccl" or not torch.cuda.is_available() else "nccl", rank=rank,
@@ -155,7 +200,8 @@ def dry_run(args, rank, world):
                           "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1e3 * float(t) / args.steps, 3),
                           "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.precision,
                           "data": "dry-run: no compute, launch and collective plumbing only",
-                          "config": {"workload": "dry-run", "global_batch": args.batch * world, "parallelism": f"dp{world}"}}))
+                          "config": {"workload": "dry-run", "global_batch": args.batch * world, "parallelism": f"dp{world}",
+                                     "host_threads_per_rank": torch.get_num_threads()}}))
     if world > 1:
         dist.destroy_process_group()
 
@@ -190,12 +236,15 @@ def main():
                          "the event timer is off in this mode, so the line carries no per-kernel roofline section")
     ap.add_argument("--dry-run", action="store_true",
                     help="no compute: only the multi-process launch, rendezvous, barriers and the JSON line (CPU test)")
+    ap.add_argument("--dry-run-fail-rank", type=int, default=None,
+                    help="--dry-run only: this rank exits non-zero before the rendezvous (the launcher must fail, not hang)")
     args = ap.parse_args()
 
     if args.batch is None:
         args.batch = 1024 if args.workload == "infer-int8" else 256
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         raise SystemExit(self_launch(args.gpus))         # one fresh process per GPU; this one never initialises a GPU
+    set_host_threads(int(os.environ.get("LOCAL_WORLD_SIZE", os.environ.get("WORLD_SIZE", "1"))))
     if args.dry_run:
         return dry_run(args, int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1")))
 
@@ -333,8 +382,14 @@ def main():
             "data": "synthetic",
             "config": {"workload": WORKLOAD[args.workload] + ("" if not args.no_optimizer else " [optimizer step OFF]")
                        + (f" [q_format {args.q_format}]" if args.q_format else "")
-                       + (" [attention core: fused bf16 kernel]" if args.int8_bf16_attention else ""),
+                       + (" [attention core: fused bf16 kernel]" if args.int8_bf16_attention else "")
+                       + (" [activations saved for backward in bf16; gelu'(h) as an 8-bit code]"
+                          if args.precision == "bf16" and args.workload != "infer-int8" and not args.q_format else ""),
                        "step_launch": "one HIP graph replay per step" if args.graph else "eager (one launch per kernel)",
+                       # what the bf16 mode stores between forward and backward (hip/functional.py): not a precision claim
+                       **({"saved_activations": "bf16, except gelu'(h): an 8-bit code on a fixed grid of step 0.005 holding 0 and 1 "
+                                                "exactly (|error| <= 0.0025), written by fc1's epilogue and multiplied into dX of fc2"}
+                          if args.precision == "bf16" and args.workload != "infer-int8" and not args.q_format else {}),
                        "per_gpu_batch": args.batch, "global_batch": args.batch * world,
                        "parallelism": f"dp{world}", "final_loss": round(final_loss, 4)},
         }

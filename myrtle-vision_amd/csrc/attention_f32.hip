@@ -455,11 +455,7 @@ int launch_attn_f32(const float* qkv, void* out, int B, int N, int H, float scal
   const int attr = MV_ONCE_PER_DEVICE(hipFuncSetAttribute(reinterpret_cast<const void*>(attn_fwd_f32_kernel<NT, Q8>),
                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) == hipSuccess ? 0 : -1);
   if (attr) return MV_ERR_LAUNCH;
-  static const int n_cu = [] {
-    int dev = 0, n = 0;
-    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) n = 0;
-    return n > 0 ? n : 256;
-  }();
+  const int n_cu = mv_cu_count();                         // of the current device (one cached value per device)
   const int items = B * H;
   attn_fwd_f32_kernel<NT, Q8><<<items < n_cu ? items : n_cu, 512, lds, s>>>(qkv, (float*)out, N, H, scale, q_inv, q_zp, lse,
                                                                              items);

@@ -25,6 +25,21 @@
     return s_ == 1 ? 0 : -1;                                                                                   \
   }())
 
+// Compute units of the CURRENT device (persistent-kernel grid sizes), remembered per device like the attributes above.
+inline int mv_cu_count() {
+  static std::atomic<int> n_[32] = {};
+  int d = 0;
+  const bool have = hipGetDevice(&d) == hipSuccess && d >= 0 && d < 32;
+  if (have) {
+    const int c = n_[d].load(std::memory_order_acquire);
+    if (c > 0) return c;
+  }
+  int n = 0;
+  if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, have ? d : 0) != hipSuccess || n <= 0) n = 256;
+  if (have) n_[d].store(n, std::memory_order_release);
+  return n;
+}
+
 typedef __bf16 bf16_t;
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
 typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;

@@ -517,6 +517,36 @@ def test_bench_self_launches_two_ranks_and_prints_one_json_line():
     assert r.returncode != 0
 
 
+def test_bench_eight_ranks_dry_run_and_a_dying_rank_fails_the_command():
+    """The shape of the driver's first real 8-GPU run, rehearsed on the CPU: ``bench.py --gpus 8`` -> eight fresh children
+    (never a re-exec of a process that touched a GPU), one rendezvous on 127.0.0.1, ONE JSON line from rank 0 with n_gpus 8 and
+    each rank's host-thread share; and when ONE rank exits non-zero before the rendezvous the command fails promptly instead
+    of hanging the other seven in their first barrier."""
+    import json
+    import subprocess
+    import sys
+    import time
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT", "MASTER_ADDR",
+                                                             "LOCAL_WORLD_SIZE", "OMP_NUM_THREADS")}
+    env["MV_DIST_BACKEND"] = "gloo"
+    bench = os.path.join(ROOT, "bench.py")
+    r = subprocess.run([sys.executable, bench, "--gpus", "8", "--steps", "2", "--warmup", "1", "--dry-run"],
+                       env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 8 and out["config"]["parallelism"] == "dp8" and out["config"]["global_batch"] == 8 * 256
+    ncores = len(os.sched_getaffinity(0))
+    assert out["config"]["host_threads_per_rank"] == max(1, min(16, ncores // 8))
+    t0 = time.time()
+    r = subprocess.run([sys.executable, bench, "--gpus", "8", "--steps", "2", "--dry-run", "--dry-run-fail-rank", "5"],
+                       env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode != 0
+    assert not [ln for ln in r.stdout.splitlines() if ln.startswith("{")]          # no throughput line from a broken job
+    assert time.time() - t0 < 300
+
+
 @pytest.mark.parametrize("fmt,outputs", [("FP16_32", False), ("TF32", False), ("FP16_16", True)])
 def test_prepared_modules_actually_hold_their_quantisers(fmt, outputs):
     """Regression (round 2): quantisers assigned to a class-swapped module live in nn.Module._modules, which a class-level

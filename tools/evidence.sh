@@ -18,6 +18,7 @@ TAG=${1:-r03_x}
 R=$PWD; O=$R/gpurun_out/evidence_$TAG; mkdir -p $O
 export MV_COMMIT=${COMMIT:-unknown}
 DIGEST=$(cat $R/myrtle-vision_amd/lib/build.sha256 2>/dev/null | cut -c1-16)
+export MV_LIB_DIGEST=$DIGEST      # stamped into the PMC summaries: bench.py quotes them only for the library they were measured on
 python3 - > $O/${TAG}_stamp.json <<PY
 import json, time
 print(json.dumps({"commit": "$MV_COMMIT", "lib_source_digest16": "$DIGEST", "utc": time.strftime("%Y-%m-%dT%H:%M:%SZ", time.gmtime()),

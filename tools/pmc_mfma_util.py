@@ -42,7 +42,8 @@ def main():
                 f["sq_busy"] += d.get("SQ_BUSY_CYCLES", 0.0)
     out = {"source": "rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE over bench.py "
                      "--steps 2 --warmup 1 --no-cpu-baseline (tools/pmc_mfma_util.py); util = MFMA busy cycles / (GRBM_GUI_ACTIVE/8 "
-                     "x 1024 SIMDs)", "commit": os.environ.get("MV_COMMIT"), "kernels": {}}
+                     "x 1024 SIMDs)", "commit": os.environ.get("MV_COMMIT"),
+           "lib_source_digest16": os.environ.get("MV_LIB_DIGEST"), "kernels": {}}
     for k, f in fam.items():
         if f["launches"]:
             out["kernels"][k] = {"launches": f["launches"], "cycles_per_launch": f["cycles"] / f["launches"],

@@ -33,7 +33,8 @@ def main():
     res = {"source": "rocprofv3 --kernel-trace --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) over "
                      "bench.py --steps 2 --warmup 1 --no-cpu-baseline; FETCH_SIZE doubled per the gfx950 correction "
                      "(tools/pmc_traffic.py)",
-           "commit": os.environ.get("MV_COMMIT"), "kernels": {}}
+           "commit": os.environ.get("MV_COMMIT"),
+           "lib_source_digest16": os.environ.get("MV_LIB_DIGEST"), "kernels": {}}
     for fam in FAMILIES:
         if fam in fetch and fam in write:
             nf, f = fetch[fam]
