@@ -196,6 +196,18 @@ int mv_gemm_nt_bf16_ksplit(const void* A, int lda, const void* B, int ldb, float
  * are.  M, N multiples of 8, rows a multiple of 32; workspace as mv_gemm_tn_workspace_bytes(M, N, 6 * rows). */
 int mv_gemm_tn_bf16_x6(const void* A6, const void* B6, float* C, int ldc, int M, int N, int rows, float* workspace,
                        size_t workspace_bytes, mv_stream_t stream);
+/* "bf16x3": the fp32 products of nn.Linear (vit.py:48-51,72-74,86) to 2^-16 relative -- inside BASELINE's 1e-3 end to end -- at
+ * half the matrix-core work of bf16x6 (``precision="bf16x3"``).  Each operand as TWO bf16 pieces p0 = bf16(x), p1 = bf16(x - p0),
+ * three segments in the order role 0: p0 p0 p1, role 1: p0 p1 p0 (the first three of mv_split3_bf16's six), so a bf16 product
+ * over the 3 * K contraction is a0 b0 + a0 b1 + a1 b0.  Same argument meaning as mv_split3_bf16 / mv_split3_bf16_ex (the _ex
+ * form writes [rows, 3 * cols]; workspace as mv_split3_ex_workspace_bytes) / mv_gemm_tn_bf16_x6 (A3 [rows, 3 M], B3 [rows, 3 N],
+ * workspace as mv_gemm_tn_workspace_bytes(M, N, 3 * rows)). */
+int mv_split2_bf16(const float* x, long ldx, void* out, long ldo, long seg, long rows, int cols, int role,
+                   mv_stream_t stream);
+int mv_split2_bf16_ex(const float* x, long ldx, const float* h, long ldh, int op, void* out, long rows, int cols,
+                      float* colsum, float* workspace, size_t workspace_bytes, mv_stream_t stream);
+int mv_gemm_tn_bf16_x3(const void* A3, const void* B3, float* C, int ldc, int M, int N, int rows, float* workspace,
+                       size_t workspace_bytes, mv_stream_t stream);
 /* weight prep for the MFMA path: w fp32 [R, C] -> w_bf16 [R, ldw] and wt_bf16 [C, ldt] (transposed), pads zeroed;
  * either output may be NULL */
 int mv_weight_prep(const float* w, void* w_bf16, int ldw, void* wt_bf16, int ldt, int R, int C, mv_stream_t stream);

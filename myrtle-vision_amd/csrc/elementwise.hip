@@ -850,7 +850,9 @@ extern "C" int mv_cast(const void* src, int src_dtype, void* dst, int dst_dtype,
 // f32 MFMA's.  The kernel writes all six segments of one operand, `seg` elements apart: seg = cols with ldo = 6 * cols puts them
 // side by side along K (NT operands), seg = rows * ldo stacks them along the rows (TN operands, contraction over rows).
 // ---------------------------------------------------------------------------------------------------------------------
-template <int ROLE>
+// NSEG = 3 ("bf16x3", mv_split2_bf16*): TWO pieces, the first three segments only -- A' = [a0 | a0 | a1], B' = [b0 | b1 | b0] -- i.e.
+// the pairings (0,0) (0,1) (1,0): 2^-16 relative per product (the dropped a1 b1 and the third pieces) at half the MFMA work.
+template <int ROLE, int NSEG = 6>
 __global__ __launch_bounds__(256) void split3_kernel(const float* __restrict__ x, long ldx, bf16_t* __restrict__ out, long ldo,
                                                      long seg, long rows, int cols4) {
   const long total = rows * cols4;
@@ -873,7 +875,7 @@ __global__ __launch_bounds__(256) void split3_kernel(const float* __restrict__ x
     constexpr int order[2][6] = {{0, 0, 1, 0, 1, 2}, {0, 1, 0, 2, 1, 0}};
     bf16_t* o = out + r * ldo + c;
 #pragma unroll
-    for (int s = 0; s < 6; ++s) *reinterpret_cast<bf16x4*>(o + s * seg) = p[order[ROLE][s]];
+    for (int s = 0; s < NSEG; ++s) *reinterpret_cast<bf16x4*>(o + s * seg) = p[order[ROLE][s]];
   }
 }
 
@@ -882,7 +884,7 @@ __global__ __launch_bounds__(256) void split3_kernel(const float* __restrict__ x
 // the fp32 activation itself is never stored); OP 2: v = x * gelu'(h) (fc2's dX times the activation derivative).
 // A thread owns 4 columns and walks the rows of its row part (coalesced: the block's threads cover consecutive columns), so
 // the column sums of v accumulate in registers; partial[part][cols] is reduced by mv_reduce_rows_kernel (fixed order).
-template <int OP>
+template <int OP, int NSEG = 6>
 __global__ __launch_bounds__(256) void split3_ex_kernel(const float* __restrict__ x, long ldx, const float* __restrict__ h,
                                                         long ldh, bf16_t* __restrict__ out, long ldo, long seg, long rows,
                                                         int cols4, int rows_per_part, float* __restrict__ partial) {
@@ -917,7 +919,7 @@ __global__ __launch_bounds__(256) void split3_ex_kernel(const float* __restrict_
     constexpr int order[6] = {0, 0, 1, 0, 1, 2};
     bf16_t* o = out + r * ldo + c;
 #pragma unroll
-    for (int sg = 0; sg < 6; ++sg) *reinterpret_cast<bf16x4*>(o + sg * seg) = p[order[sg]];
+    for (int sg = 0; sg < NSEG; ++sg) *reinterpret_cast<bf16x4*>(o + sg * seg) = p[order[sg]];
   }
   if (partial) *reinterpret_cast<float4*>(partial + (long)blockIdx.y * (cols4 * 4) + c) = make_float4(cs[0], cs[1], cs[2], cs[3]);
 }
@@ -929,8 +931,10 @@ inline int split3_parts(long rows) {
 
 extern "C" size_t mv_split3_ex_workspace_bytes(long rows, int cols) { return (size_t)split3_parts(rows) * cols * sizeof(float) + 256; }
 
-extern "C" int mv_split3_bf16_ex(const float* x, long ldx, const float* h, long ldh, int op, void* out, long rows, int cols,
-                                 float* colsum, float* workspace, size_t workspace_bytes, mv_stream_t stream) {
+namespace {
+template <int NSEG>
+int launch_split_ex(const float* x, long ldx, const float* h, long ldh, int op, void* out, long rows, int cols, float* colsum,
+                    float* workspace, size_t workspace_bytes, mv_stream_t stream) {
   MV_REQUIRE(rows >= 0 && cols >= 0 && op >= 0 && op <= 2 && (op != 2 || h), MV_ERR_SHAPE);
   if (rows == 0 || cols == 0) return MV_OK;
   MV_REQUIRE(cols % 4 == 0 && ldx % 4 == 0 && ldx >= cols && (op != 2 || (ldh % 4 == 0 && ldh >= cols)), MV_ERR_ALIGN);
@@ -940,13 +944,13 @@ extern "C" int mv_split3_bf16_ex(const float* x, long ldx, const float* h, long 
   const int rpp = (int)((rows + parts - 1) / parts);
   dim3 grid(mv_cdiv(cols / 4, 256), mv_cdiv(rows, rpp));
   float* partial = colsum ? workspace : nullptr;
-  const long ldo = 6L * cols, seg = cols;
+  const long ldo = (long)NSEG * cols, seg = cols;
   if (op == 0)
-    split3_ex_kernel<0><<<grid, 256, 0, S_>>>(x, ldx, h, ldh, (bf16_t*)out, ldo, seg, rows, cols / 4, rpp, partial);
+    split3_ex_kernel<0, NSEG><<<grid, 256, 0, S_>>>(x, ldx, h, ldh, (bf16_t*)out, ldo, seg, rows, cols / 4, rpp, partial);
   else if (op == 1)
-    split3_ex_kernel<1><<<grid, 256, 0, S_>>>(x, ldx, h, ldh, (bf16_t*)out, ldo, seg, rows, cols / 4, rpp, partial);
+    split3_ex_kernel<1, NSEG><<<grid, 256, 0, S_>>>(x, ldx, h, ldh, (bf16_t*)out, ldo, seg, rows, cols / 4, rpp, partial);
   else
-    split3_ex_kernel<2><<<grid, 256, 0, S_>>>(x, ldx, h, ldh, (bf16_t*)out, ldo, seg, rows, cols / 4, rpp, partial);
+    split3_ex_kernel<2, NSEG><<<grid, 256, 0, S_>>>(x, ldx, h, ldh, (bf16_t*)out, ldo, seg, rows, cols / 4, rpp, partial);
   MV_CHECK_LAUNCH();
   if (colsum) {
     mv_reduce_rows_kernel<<<mv_reduce_rows_grid(cols), 1024, 0, S_>>>(workspace, (int)grid.y, cols, (long)cols, colsum, colsum,
@@ -956,19 +960,41 @@ extern "C" int mv_split3_bf16_ex(const float* x, long ldx, const float* h, long 
   return MV_OK;
 }
 
-extern "C" int mv_split3_bf16(const float* x, long ldx, void* out, long ldo, long seg, long rows, int cols, int role,
-                              mv_stream_t stream) {
+template <int NSEG>
+int launch_split(const float* x, long ldx, void* out, long ldo, long seg, long rows, int cols, int role, mv_stream_t stream) {
   MV_REQUIRE(rows >= 0 && cols >= 0 && (role == 0 || role == 1), MV_ERR_SHAPE);
   if (rows == 0 || cols == 0) return MV_OK;
   MV_REQUIRE(cols % 4 == 0 && ldx % 4 == 0 && ldo % 4 == 0 && seg % 4 == 0 && ldx >= cols && ldo >= cols, MV_ERR_ALIGN);
   MV_REQUIRE(mv_aligned16(x) && mv_aligned16(out), MV_ERR_ALIGN);
   const int grid = ew_grid(rows * (cols / 4));
   if (role == 0)
-    split3_kernel<0><<<grid, 256, 0, S_>>>(x, ldx, (bf16_t*)out, ldo, seg, rows, cols / 4);
+    split3_kernel<0, NSEG><<<grid, 256, 0, S_>>>(x, ldx, (bf16_t*)out, ldo, seg, rows, cols / 4);
   else
-    split3_kernel<1><<<grid, 256, 0, S_>>>(x, ldx, (bf16_t*)out, ldo, seg, rows, cols / 4);
+    split3_kernel<1, NSEG><<<grid, 256, 0, S_>>>(x, ldx, (bf16_t*)out, ldo, seg, rows, cols / 4);
   MV_CHECK_LAUNCH();
   return MV_OK;
+}
+}  // namespace
+
+extern "C" int mv_split3_bf16_ex(const float* x, long ldx, const float* h, long ldh, int op, void* out, long rows, int cols,
+                                 float* colsum, float* workspace, size_t workspace_bytes, mv_stream_t stream) {
+  return launch_split_ex<6>(x, ldx, h, ldh, op, out, rows, cols, colsum, workspace, workspace_bytes, stream);
+}
+
+extern "C" int mv_split3_bf16(const float* x, long ldx, void* out, long ldo, long seg, long rows, int cols, int role,
+                              mv_stream_t stream) {
+  return launch_split<6>(x, ldx, out, ldo, seg, rows, cols, role, stream);
+}
+
+// bf16x3: the two-piece splits ([rows, 3 cols] side by side for the _ex form; three segments `seg` apart for the plain one)
+extern "C" int mv_split2_bf16_ex(const float* x, long ldx, const float* h, long ldh, int op, void* out, long rows, int cols,
+                                 float* colsum, float* workspace, size_t workspace_bytes, mv_stream_t stream) {
+  return launch_split_ex<3>(x, ldx, h, ldh, op, out, rows, cols, colsum, workspace, workspace_bytes, stream);
+}
+
+extern "C" int mv_split2_bf16(const float* x, long ldx, void* out, long ldo, long seg, long rows, int cols, int role,
+                              mv_stream_t stream) {
+  return launch_split<3>(x, ldx, out, ldo, seg, rows, cols, role, stream);
 }
 
 extern "C" int mv_weight_prep(const float* w, void* w_bf16, int ldw, void* wt_bf16, int ldt, int R, int C,

@@ -2318,15 +2318,18 @@ extern "C" int mv_gemm_nt_bf16_ksplit(const void* A, int lda, const void* B, int
 // 0 / 2 / 5); C[M, N] = sum over the six pairings (0,0) (0,1) (1,0) (0,2) (1,1) (2,0) of piece_i(dY)^T piece_j(X).  The ring
 // kernel walks 6 * rows contraction rows through the segment table -- the SAME splits the dX and forward products use, no
 // stacked copies.
-extern "C" int mv_gemm_tn_bf16_x6(const void* A6, const void* B6, float* C, int ldc, int M, int N, int rows, float* workspace,
-                                  size_t workspace_bytes, mv_stream_t stream) {
+namespace {
+// NSEG = 6: the bf16x6 pairings over three pieces per operand; NSEG = 3: the bf16x3 pairings (0,0) (0,1) (1,0) over TWO pieces per
+// operand in the [p0 p0 p1] layout of mv_split2_bf16 (p0 at column block 0, p1 at block 2).
+template <int NSEG>
+int launch_tn_segments(const void* A, const void* B, float* C, int ldc, int M, int N, int rows, float* workspace,
+                       size_t workspace_bytes, hipStream_t s) {
   MV_REQUIRE(M > 0 && N > 0 && rows > 0, MV_ERR_SHAPE);
   MV_REQUIRE(M % 8 == 0 && N % 8 == 0 && rows % BKR == 0, MV_ERR_UNSUPPORTED);
-  MV_REQUIRE((long)rows * 6 * M * 2 < (1L << 32) && (long)rows * 6 * N * 2 < (1L << 32), MV_ERR_UNSUPPORTED);   // 32-bit byte offsets of the DMA
-  MV_REQUIRE(mv_aligned16(A6) && mv_aligned16(B6) && mv_aligned16(C) && mv_aligned16(workspace), MV_ERR_ALIGN);
-  const int Kc = 6 * rows;
+  MV_REQUIRE((long)rows * NSEG * M * 2 < (1L << 32) && (long)rows * NSEG * N * 2 < (1L << 32), MV_ERR_UNSUPPORTED);   // 32-bit byte offsets of the DMA
+  MV_REQUIRE(mv_aligned16(A) && mv_aligned16(B) && mv_aligned16(C) && mv_aligned16(workspace), MV_ERR_ALIGN);
+  const int Kc = NSEG * rows;
   MV_REQUIRE(workspace_bytes >= mv_gemm_tn_workspace_bytes(M, N, Kc), MV_ERR_WORKSPACE);
-  hipStream_t s = (hipStream_t)stream;
   const TnPlan pl = tn_plan256(M, N, Kc);
   const int tiles_mn = pl.tiles_m * pl.tiles_n;
   const bool direct = pl.splits == 1;
@@ -2338,11 +2341,12 @@ extern "C" int mv_gemm_tn_bf16_x6(const void* A6, const void* B6, float* C, int 
   seg.tiles = rows / BKR;
   const int pa[6] = {0, 0, 1, 0, 1, 2}, pb[6] = {0, 1, 0, 2, 1, 0}, block[3] = {0, 2, 5};
   for (int i = 0; i < 6; ++i) {
-    seg.a[i] = block[pa[i]] * M;
-    seg.b[i] = block[pb[i]] * N;
+    const int j = i < NSEG ? i : NSEG - 1;                 // entries past the last segment are never issued; keep them valid
+    seg.a[i] = block[pa[j]] * M;
+    seg.b[i] = block[pb[j]] * N;
   }
   gemm_tn_ring_kernel<4, true><<<tiles_mn * pl.splits, 512, 4 * RSTAGE_BYTES, s>>>(
-      (const bf16_t*)A6, 6 * M, (const bf16_t*)B6, 6 * N, direct ? C : workspace, direct ? (long)ldc : (long)N,
+      (const bf16_t*)A, NSEG * M, (const bf16_t*)B, NSEG * N, direct ? C : workspace, direct ? (long)ldc : (long)N,
       direct ? 0 : slab_stride, M, N, Kc, pl.tiles_n, tiles_mn, pl.steps_per_split, seg);
   MV_CHECK_LAUNCH();
   if (!direct) {
@@ -2352,6 +2356,19 @@ extern "C" int mv_gemm_tn_bf16_x6(const void* A6, const void* B6, float* C, int 
     MV_CHECK_LAUNCH();
   }
   return MV_OK;
+}
+}  // namespace
+
+extern "C" int mv_gemm_tn_bf16_x6(const void* A6, const void* B6, float* C, int ldc, int M, int N, int rows, float* workspace,
+                                  size_t workspace_bytes, mv_stream_t stream) {
+  return launch_tn_segments<6>(A6, B6, C, ldc, M, N, rows, workspace, workspace_bytes, (hipStream_t)stream);
+}
+
+// dW of an fp32 nn.Linear as a bf16x3 product: A3 = split2(dY) [rows, 3 M], B3 = split2(X) [rows, 3 N] (mv_split2_bf16, role 0);
+// C[M, N] = p0(dY)^T p0(X) + p0(dY)^T p1(X) + p1(dY)^T p0(X): 2^-16-relative products at half the work of bf16x6.
+extern "C" int mv_gemm_tn_bf16_x3(const void* A3, const void* B3, float* C, int ldc, int M, int N, int rows, float* workspace,
+                                  size_t workspace_bytes, mv_stream_t stream) {
+  return launch_tn_segments<3>(A3, B3, C, ldc, M, N, rows, workspace, workspace_bytes, (hipStream_t)stream);
 }
 
 namespace {

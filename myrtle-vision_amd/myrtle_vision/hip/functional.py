@@ -34,11 +34,25 @@ def _c(t):
 
 def _scoped(backward):
     """Run one backward function inside ``ops.split_scope()``: its dX and dW products share the bf16x6 split of dY (fp32
-    mode; a no-op for the bf16 path)."""
+    mode; a no-op for the bf16 path) -- and with the segment count its forward ran under (``_fwd``: 6 = bf16x6, 3 = bf16x3;
+    backward runs on autograd's worker threads, which do not see the caller's thread-local scope)."""
     @functools.wraps(backward)
-    def run(*args, **kwargs):
-        with ops.split_scope():
-            return backward(*args, **kwargs)
+    def run(ctx, *args, **kwargs):
+        with ops.split_scope(), ops.segments(getattr(ctx, "mv_segments", 6)):
+            return backward(ctx, *args, **kwargs)
+    return run
+
+
+def _fwd(forward):
+    """Forward of an autograd function that may hold fp32 Linear products: remember the segment count of the calling scope."""
+    @functools.wraps(forward)
+    def run(ctx, *args, **kwargs):
+        # fused functions receive the model's precision as their last argument and follow it; granular ones (one reference
+        # module each, no precision argument) follow the scope their caller opened (ViT.forward)
+        prec = args[-1] if args and isinstance(args[-1], str) else None
+        ctx.mv_segments = ops.prec_segments(prec) if prec is not None else ops.current_segments()
+        with ops.segments(ctx.mv_segments):
+            return forward(ctx, *args, **kwargs)
     return run
 
 
@@ -49,6 +63,7 @@ class _LayerNorm(Function):
     """nn.LayerNorm over the last dim (vit.py:37).  Input fp32 (any leading shape), output ``out_dtype``."""
 
     @staticmethod
+    @_fwd
     def forward(ctx, x, gamma, beta, out_dtype, eps):
         ops.require_cuda(x, gamma, beta)
         x = _c(x.float())
@@ -79,6 +94,7 @@ class _Linear(Function):
     """nn.Linear: y = x W^T + b (vit.py:72,74,48,51,220,333).  x dtype selects the kernel family."""
 
     @staticmethod
+    @_fwd
     def forward(ctx, x, weight, bias, out_dtype):
         ops.require_cuda(x, weight, bias)
         K = x.shape[-1]
@@ -132,6 +148,7 @@ class _LinearQatF16(Function):
     (dY is not quantised, so those products stay on the f32 MFMA)."""
 
     @staticmethod
+    @_fwd
     def forward(ctx, x, weight, bias):
         ops.require_cuda(x, weight, bias)
         K, N = x.shape[-1], weight.shape[0]
@@ -169,6 +186,7 @@ def linear_qat_f16(x, weight, bias):
 
 class _Gelu(Function):
     @staticmethod
+    @_fwd
     def forward(ctx, x):
         ops.require_cuda(x)
         x = _c(x)
@@ -191,6 +209,7 @@ def gelu(x):
 
 class _Cast(Function):
     @staticmethod
+    @_fwd
     def forward(ctx, x, dtype):
         ctx.src_dtype = x.dtype
         return ops.cast(_c(x), dtype)
@@ -209,6 +228,7 @@ class _Add(Function):
     """FloatFunctional.add of the residual (vit.py:27) in the unfused path."""
 
     @staticmethod
+    @_fwd
     def forward(ctx, a, b):
         ops.require_cuda(a, b)
         return ops.add_f32(_c(a.float()), _c(b.float()))
@@ -228,6 +248,7 @@ class _Dropout(Function):
     CPU generator in forward -- reproducible under ``seed_everything`` -- and regenerated in backward, never stored."""
 
     @staticmethod
+    @_fwd
     def forward(ctx, x, p):
         ops.require_cuda(x)
         seed, offset = (int(v) for v in torch.randint(0, 2 ** 62, (2,), dtype=torch.int64).tolist())
@@ -255,6 +276,7 @@ class _AttentionFused(Function):
     """softmax(q k^T * scale) v on the fused MFMA kernel.  qkv bf16 [B, N, 3*H*64] -> [B, N, H*64]."""
 
     @staticmethod
+    @_fwd
     def forward(ctx, qkv, heads, scale):
         B, N, three_d = qkv.shape
         qkv = _c(qkv)
@@ -278,6 +300,7 @@ class _AttentionProbs(Function):
     """Materialised fp32 path, part 1: probs = softmax(q k^T * scale)  [B, H, N, N] (vit.py:92-93)."""
 
     @staticmethod
+    @_fwd
     def forward(ctx, qkv, heads, scale):
         B, N, three_d = qkv.shape
         dh = three_d // (3 * heads)
@@ -312,6 +335,7 @@ class _AttentionPV(Function):
     """Materialised fp32 path, part 2: out = (probs @ v).transpose(1,2).reshape(B,N,C) (vit.py:96)."""
 
     @staticmethod
+    @_fwd
     def forward(ctx, probs, qkv, heads):
         B, N, three_d = qkv.shape
         dh = three_d // (3 * heads)
@@ -390,6 +414,7 @@ class _PatchEmbed(Function):
     """patchify + patch_to_embedding + cls token + positional embedding (vit.py:271-311) -> fp32 [B, T, D]."""
 
     @staticmethod
+    @_fwd
     def forward(ctx, img, weight, bias, cls_token, pos, patch, prec):
         ops.require_cuda(img, weight, bias, cls_token, pos)
         adt = ops.act_dtype(prec)
@@ -492,6 +517,7 @@ class _AttnBlock(Function):
     """x + to_out(attention(to_qkv(LN(x))))  ==  Residual(PreNorm(dim, Attention)) (vit.py:131-141, 84-99)."""
 
     @staticmethod
+    @_fwd
     def forward(ctx, x, g, b, wqkv, bqkv, wo, bo, heads, scale, prec):
         adt = ops.act_dtype(prec)
         B, T, D = x.shape
@@ -623,6 +649,7 @@ class _MlpBlock(Function):
     """x + fc2(gelu(fc1(LN(x))))  ==  Residual(PreNorm(dim, FeedForward)) (vit.py:142-151, 44-56)."""
 
     @staticmethod
+    @_fwd
     def forward(ctx, x, g, b, w1, b1, w2, b2, prec):
         adt = ops.act_dtype(prec)
         B, T, D = x.shape
@@ -720,6 +747,7 @@ class _ClsHead(Function):
     """ClassificationDecoder: linear(norm(x[:, 0])) (vit.py:335-342) -> fp32 logits [B, num_classes]."""
 
     @staticmethod
+    @_fwd
     def forward(ctx, x, g, b, w, bias, prec):
         adt = ops.act_dtype(prec)
         B, T, D = x.shape
@@ -795,6 +823,7 @@ class _UpsampleBilinear(Function):
     LayerNorm / Linear); the fused heads below call the same kernels."""
 
     @staticmethod
+    @_fwd
     def forward(ctx, small, grid, size):
         ops.require_cuda(small)
         B, hw, C = small.shape
@@ -819,6 +848,7 @@ class _SegHead(Function):
     """SegmentationDecoder: upsample(rearrange(linear(norm(x[:, 1:])))) (vit.py:359-374) -> fp32 [B, C, S, S]."""
 
     @staticmethod
+    @_fwd
     def forward(ctx, x, g, b, w, bias, grid, size, prec):
         B, T, D = x.shape
         C = w.shape[0]
@@ -854,6 +884,7 @@ class _SegHeadLoss(Function):
     never written (vit.py:355-374 + segmentation/train.py:188,261-265).  -> (loss, pixel accuracy, pred uint8 [B,S,S])."""
 
     @staticmethod
+    @_fwd
     def forward(ctx, x, g, b, w, bias, labels, grid, size, prec):
         B, T, D = x.shape
         C = w.shape[0]
@@ -894,6 +925,7 @@ class _CrossEntropy(Function):
     """nn.CrossEntropyLoss() (mean) with the gradient produced in the same pass (classification/train.py:170,250)."""
 
     @staticmethod
+    @_fwd
     def forward(ctx, logits, labels):
         ops.require_cuda(logits, labels)
         loss, dl, _ = ops.cross_entropy(logits.float(), labels, want_grad=True)
@@ -924,6 +956,7 @@ class CrossEntropyLoss(torch.nn.Module):
 # ------------------------------------------------------------------------------------------------------------
 class _FakeQuant(Function):
     @staticmethod
+    @_fwd
     def forward(ctx, x, kind, a, b):
         dtype = x.dtype
         if kind == "float":

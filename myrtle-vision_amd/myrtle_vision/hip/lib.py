@@ -60,6 +60,9 @@ SIGNATURES = {
     "mv_split3_ex_workspace_bytes": ("li", _Z),
     "mv_split3_bf16_ex": ("plpl" "ip" "li" "ppz" "p", _I),
     "mv_gemm_tn_bf16_x6": ("ppp" "iiii" "pz" "p", _I),
+    "mv_split2_bf16": ("plpll" "lii" "p", _I),
+    "mv_split2_bf16_ex": ("plpl" "ip" "li" "ppz" "p", _I),
+    "mv_gemm_tn_bf16_x3": ("ppp" "iiii" "pz" "p", _I),
     "mv_weight_prep": ("ppipi" "ii" "p", _I),
     "mv_weight_prep_batch": ("pii" "p", _I),
     "mv_colsum": ("pil" "pi" "li" "pz" "p", _I),

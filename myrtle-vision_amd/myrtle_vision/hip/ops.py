@@ -6,7 +6,10 @@ streams.  CPU tensors are rejected: there is no CPU compute path in this package
 
 Precision: ``"bf16"`` = bf16 activations and weights on MFMA with fp32 accumulation and an fp32 residual stream
 (the benchmark configuration); ``"fp32"`` = every contraction to fp32 accuracy (parity mode: bf16x6 Linear products, f32-MFMA
-attention; MV_F32_GEMM=mfma puts every product on the bit-exact fmaf-chain kernels).
+attention; MV_F32_GEMM=mfma puts every product on the bit-exact fmaf-chain kernels); ``"bf16x3"`` = the fp32 mode's data flow with
+every nn.Linear product to 2^-16 relative instead of 2^-25 (two bf16 pieces per operand, three pairings: half the matrix-core work
+of bf16x6; attention core, LayerNorm, GELU, softmax and the residual stream exactly as in ``"fp32"``) -- the cheapest arithmetic
+inside BASELINE's 1e-3 end to end.
 """
 import ctypes
 import os
@@ -28,9 +31,9 @@ _DT = {torch.float32: MV_F32, torch.bfloat16: MV_BF16}
 def act_dtype(prec: str):
     if prec == "bf16":
         return torch.bfloat16
-    if prec == "fp32":
+    if prec in ("fp32", "bf16x3"):
         return torch.float32
-    raise ValueError(f"unknown precision {prec!r} (expected 'bf16' or 'fp32')")
+    raise ValueError(f"unknown precision {prec!r} (expected 'bf16', 'bf16x3' or 'fp32')")
 
 
 def require_cuda(*tensors):
@@ -370,26 +373,61 @@ def pad32(n: int) -> int:
     return (n + 31) & ~31
 
 
+# How many SEGMENTS a split operand has: 6 = bf16x6 (three pieces per operand, six pairings: fp32-accurate, ``precision="fp32"``),
+# 3 = bf16x3 (two pieces, the pairings a0 b0 + a0 b1 + a1 b0: 2^-16 relative per product, half the matrix-core work,
+# ``precision="bf16x3"``).  The count is a property of the running model, carried per THREAD (forward runs on the caller's thread,
+# backward on autograd's workers): ``with segments(prec_segments(prec))`` in the forward of every autograd function that holds a
+# Linear product, which records it for its backward (functional._scoped).
+_seg_tls = threading.local()
+
+
+def prec_segments(prec: str) -> int:
+    return 3 if prec == "bf16x3" else 6
+
+
+def current_segments() -> int:
+    return getattr(_seg_tls, "n", 6)
+
+
+class segments:
+    def __init__(self, n: int):
+        if n not in (3, 6):
+            raise ValueError(f"segments {n}: 3 (bf16x3) or 6 (bf16x6)")
+        self.n = n
+
+    def __enter__(self):
+        self.prev = getattr(_seg_tls, "n", 6)
+        _seg_tls.n = self.n
+        return self
+
+    def __exit__(self, *exc):
+        _seg_tls.n = self.prev
+        return False
+
+
 def _split_buffer(rows, cols, device):
-    """[rows, 6 * cols] bf16 whose STORAGE runs on to the next multiple of 32 rows, zero-filled: the dW product walks its
-    contraction (the rows) in stages of 32, and zero rows add nothing -- any token count takes the bf16x6 path."""
-    full = torch.empty(pad32(rows), 6 * cols, dtype=torch.bfloat16, device=device)
+    """[rows, nseg * cols] bf16 whose STORAGE runs on to the next multiple of 32 rows, zero-filled: the dW product walks its
+    contraction (the rows) in stages of 32, and zero rows add nothing -- any token count takes the bf16x6 / bf16x3 path."""
+    full = torch.empty(pad32(rows), current_segments() * cols, dtype=torch.bfloat16, device=device)
     if full.shape[0] != rows:
         full[rows:].zero_()
     return full[:rows]
 
 
 def split3(x, rows, cols, ldx, role, stack=False):
-    """fp32 [rows, cols] (row stride ldx) -> its six bf16 segments: [rows, 6 * cols] side by side, or stacked
-    [6 * rows, cols] (``stack``).  role 0 = left operand of the product, 1 = right operand."""
+    """fp32 [rows, cols] (row stride ldx) -> its bf16 segments (six, or three in a ``segments(3)`` scope): [rows, nseg * cols]
+    side by side, or stacked [nseg * rows, cols] (``stack``).  role 0 = left operand of the product, 1 = right operand."""
     require_cuda(x)
+    nseg = current_segments()
     if stack:
-        out = torch.empty(6 * rows, cols, dtype=torch.bfloat16, device=x.device)
+        out = torch.empty(nseg * rows, cols, dtype=torch.bfloat16, device=x.device)
         ldo, seg = cols, rows * cols
     else:
         out = _split_buffer(rows, cols, x.device)
-        ldo, seg = 6 * cols, cols
-    check(lib().mv_split3_bf16(_p(x), ldx, _p(out), ldo, seg, rows, cols, role, _s()), "split3_bf16", rows=rows, cols=cols)
+        ldo, seg = nseg * cols, cols
+    fn = lib().mv_split3_bf16 if nseg == 6 else lib().mv_split2_bf16
+    check(fn(_p(x), ldx, _p(out), ldo, seg, rows, cols, role, _s()), "split3_bf16" if nseg == 6 else "split2_bf16", rows=rows,
+          cols=cols)
     return out
 
 
@@ -420,13 +458,14 @@ def split_act(x, rows, cols, ldx, colsum_out=None):
            (lambda: split_ex(x, rows, cols, ldx=ldx, colsum_out=colsum_out))
     if memo is None:
         return make()
+    key = (rows, cols, ldx, x.data_ptr(), current_segments())
     for ent in memo:
-        if ent[1] == (rows, cols, ldx, x.data_ptr()):        # ent[0] keeps that storage alive: the address cannot be reused
+        if ent[1] == key:                                    # ent[0] keeps that storage alive: the address cannot be reused
             if colsum_out is not None:
                 colsum(x, rows, cols, ldx, colsum_out)
             return ent[2]
     out = make()
-    memo.append((x, (rows, cols, ldx, x.data_ptr()), out))
+    memo.append((x, key, out))
     if len(memo) > 2:
         memo.pop(0)
     return out
@@ -440,8 +479,8 @@ _split_weights = {}
 
 
 def split_weight(weight: torch.Tensor, which: str) -> torch.Tensor:
-    """Cached right-operand splits of an nn.Linear weight [N, K]: 'fwd' -> [N, 6K] (y = x W^T), 'dx' -> [K, 6N] (the
-    transposed weight, dx = dy W); refreshed when the parameter changed."""
+    """Cached right-operand splits of an nn.Linear weight [N, K]: 'fwd' -> [N, nseg K] (y = x W^T), 'dx' -> [K, nseg N] (the
+    transposed weight, dx = dy W); refreshed when the parameter changed.  One cache entry per segment count."""
     key = id(weight)
     sw = _split_weights.get(key)
     epoch = cache_epoch(_owner_of(weight))
@@ -449,15 +488,16 @@ def split_weight(weight: torch.Tensor, which: str) -> torch.Tensor:
         if sw is None:
             weakref.finalize(weight, _split_weights.pop, key, None)
         sw = _split_weights[key] = _SplitWeight()
-        sw.version, sw.ptr, sw.fwd, sw.dx, sw.epoch = weight._version, weight.data_ptr(), None, None, epoch
+        sw.version, sw.ptr, sw.fwd, sw.dx, sw.epoch = weight._version, weight.data_ptr(), {}, {}, epoch
     n_out, k_in = weight.shape
+    nseg = current_segments()
     if which == "fwd":
-        if sw.fwd is None:
-            sw.fwd = split3(weight.detach().contiguous(), n_out, k_in, k_in, 1)
-        return sw.fwd
-    if sw.dx is None:
-        sw.dx = split3(weight.detach().t().contiguous(), k_in, n_out, n_out, 1)
-    return sw.dx
+        if nseg not in sw.fwd:
+            sw.fwd[nseg] = split3(weight.detach().contiguous(), n_out, k_in, k_in, 1)
+        return sw.fwd[nseg]
+    if nseg not in sw.dx:
+        sw.dx[nseg] = split3(weight.detach().t().contiguous(), k_in, n_out, n_out, 1)
+    return sw.dx[nseg]
 
 
 def _x6_nt_ok(M, N, Kc):
@@ -482,7 +522,8 @@ def split_ex(x, rows, cols, *, ldx=None, op=0, h=None, ldh=None, colsum_out=None
     require_cuda(x)
     out = _split_buffer(rows, cols, x.device)
     ws = workspace(lib().mv_split3_ex_workspace_bytes(rows, cols), x.device) if colsum_out is not None else None
-    check(lib().mv_split3_bf16_ex(_p(x), cols if ldx is None else ldx, _p(h), cols if ldh is None else ldh, op, _p(out), rows,
+    fn = lib().mv_split3_bf16_ex if current_segments() == 6 else lib().mv_split2_bf16_ex
+    check(fn(_p(x), cols if ldx is None else ldx, _p(h), cols if ldh is None else ldh, op, _p(out), rows,
                                   cols, _p(colsum_out), _p(ws), ws.numel() if ws is not None else 0, _s()),
           "split3_bf16_ex", rows=rows, cols=cols, mode=op)
     return out
@@ -502,14 +543,19 @@ def tn_x6(dy6, x6, M, weight):
     """dW[N, K] = dY^T X from the two splits, into the weight's gradient slot."""
     N, K = weight.shape
     dw = grad_out(weight, (N, K), dy6.device)
-    Mp = pad32(M)                                  # the splits' storage is zero-padded to whole stages (_split_buffer)
-    ws = workspace(lib().mv_gemm_tn_workspace_bytes(N, K, 6 * Mp), dy6.device)
-    t0 = _timer.begin() if _timer is not None else None
-    check(lib().mv_gemm_tn_bf16_x6(_p(dy6), _p(x6), _p(dw), K, N, K, Mp, _p(ws), ws.numel(), _s()),
-          "gemm_tn_bf16_x6", M=N, N=K, rows=Mp)
-    if t0 is not None:
-        _timer.end("gemm_tn_bf16x6", t0, 2.0 * M * N * K, shape=f"dw N{N} K{K}")
+    _tn_segments(dy6, x6, dw, M, N, K)
     return dw
+
+
+def _tn_segments(dy6, x6, dw, M, N, K):
+    nseg = current_segments()
+    Mp = pad32(M)                                  # the splits' storage is zero-padded to whole stages (_split_buffer)
+    ws = workspace(lib().mv_gemm_tn_workspace_bytes(N, K, nseg * Mp), dy6.device)
+    t0 = _timer.begin() if _timer is not None else None
+    fn = lib().mv_gemm_tn_bf16_x6 if nseg == 6 else lib().mv_gemm_tn_bf16_x3
+    check(fn(_p(dy6), _p(x6), _p(dw), K, N, K, Mp, _p(ws), ws.numel(), _s()), f"gemm_tn_bf16_x{nseg}", M=N, N=K, rows=Mp)
+    if t0 is not None:
+        _timer.end(f"gemm_tn_bf16x{nseg}", t0, 2.0 * M * N * K, shape=f"dw N{N} K{K}")
 
 
 def _x6_ksplits(M, N):
@@ -521,21 +567,25 @@ def _x6_ksplits(M, N):
 
 
 def _nt_x6(a6, b6, out, ldc, M, N, Kc, bias, epi, aux=None, ld_aux=0, aux_i=0, tag="fwd"):
+    nseg = current_segments()
+    Kx = nseg * Kc
     t0 = _timer.begin() if _timer is not None else None
     S = _x6_ksplits(M, N) if epi in (EPI_NONE, EPI_RESIDUAL) and ldc == N and (aux is None or ld_aux == N) else 1
+    if S > 1 and Kx % (128 * S) != 0:
+        S = 1
     if S > 1:
         slabs = workspace(S * M * N * 4, out.device)
-        check(lib().mv_gemm_nt_bf16_ksplit(_p(a6), 6 * Kc, _p(b6), 6 * Kc, _p(slabs), M, N, 6 * Kc, S, _p(bias), _s()),
-              "gemm_nt_bf16_ksplit(x6)", M=M, N=N, K=6 * Kc, S=S)
+        check(lib().mv_gemm_nt_bf16_ksplit(_p(a6), Kx, _p(b6), Kx, _p(slabs), M, N, Kx, S, _p(bias), _s()),
+              f"gemm_nt_bf16_ksplit(x{nseg})", M=M, N=N, K=Kx, S=S)
         check(lib().mv_sum_slabs_add(_p(slabs), M * N, S, _p(aux) if epi == EPI_RESIDUAL else None, _p(out), M * N, _s()),
               "sum_slabs_add", n=M * N)
         if t0 is not None:
-            _timer.end("gemm_nt_bf16x6", t0, 2.0 * M * N * Kc, shape=f"{tag} N{N} K{Kc} epi{epi} S{S}")
+            _timer.end(f"gemm_nt_bf16x{nseg}", t0, 2.0 * M * N * Kc, shape=f"{tag} N{N} K{Kc} epi{epi} S{S}")
         return
-    check(lib().mv_gemm_nt_bf16(_p(a6), 6 * Kc, _p(b6), 6 * Kc, _p(out), ldc, MV_F32, M, N, 6 * Kc, _p(bias), epi, _p(aux),
-                                ld_aux, aux_i, None, 0, _s()), "gemm_nt_bf16(x6)", M=M, N=N, K=6 * Kc, epi=epi)
+    check(lib().mv_gemm_nt_bf16(_p(a6), Kx, _p(b6), Kx, _p(out), ldc, MV_F32, M, N, Kx, _p(bias), epi, _p(aux),
+                                ld_aux, aux_i, None, 0, _s()), f"gemm_nt_bf16(x{nseg})", M=M, N=N, K=Kx, epi=epi)
     if t0 is not None:
-        _timer.end("gemm_nt_bf16x6", t0, 2.0 * M * N * Kc, shape=f"{tag} N{N} K{Kc} epi{epi}")
+        _timer.end(f"gemm_nt_bf16x{nseg}", t0, 2.0 * M * N * Kc, shape=f"{tag} N{N} K{Kc} epi{epi}")
 
 
 # ------------------------------------------------------------------------------------------------------------
@@ -617,13 +667,7 @@ def linear_dw(dy, x, M, N, K, *, ld_dy=None, ldx=None, want_bias=True, weight=No
             _timer.end("gemm_tn_bf16(+reduce+colsum)", t0, 2.0 * M * N * K, shape=f"dw N{N} K{K} bias{int(want_bias)}")
     elif _x6_tn_ok(M, N, K) and dy.dtype == torch.float32 and x.dtype == torch.float32:
         a6, b6 = split_act(dy, M, N, ld_dy, colsum_out=db if want_bias else None), split_act(x, M, K, ldx)
-        Mp = pad32(M)
-        ws = workspace(lib().mv_gemm_tn_workspace_bytes(N, K, 6 * Mp), x.device)
-        t0 = _timer.begin() if _timer is not None else None
-        check(lib().mv_gemm_tn_bf16_x6(_p(a6), _p(b6), _p(dw), K, N, K, Mp, _p(ws), ws.numel(), _s()),
-              "gemm_tn_bf16_x6", M=N, N=K, rows=Mp)
-        if t0 is not None:
-            _timer.end("gemm_tn_bf16x6", t0, 2.0 * M * N * K, shape=f"dw N{N} K{K}")
+        _tn_segments(a6, b6, dw, M, N, K)
     else:
         S = f32_dw_splits(M, N, K)
         if S == 1:

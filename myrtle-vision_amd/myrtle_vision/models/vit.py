@@ -5,9 +5,10 @@ SegmentationDecoder, DetectionDecoder``), constructor kwargs, attribute names (h
 checkpoint wire format), the ``attn_output`` hook point, ``.convert()`` and ``.quantizer`` as the reference; the
 arithmetic runs in the HIP kernels of ``csrc/`` through ``myrtle_vision.hip.functional``.
 
-One extension: ``ViT(..., precision="bf16" | "fp32")`` (default: env ``MYRTLE_VISION_PRECISION`` or ``"bf16"``).
+One extension: ``ViT(..., precision="bf16" | "bf16x3" | "fp32")`` (default: env ``MYRTLE_VISION_PRECISION`` or ``"bf16"``).
 ``bf16`` is the benchmark configuration (MFMA, fp32 accumulate, fp32 residual stream); ``fp32`` is the
-parity mode (fp32-accurate arithmetic: the one held to 1e-3 / bit-exact argmax against the reference).  Any fake-quantised ``q_format`` runs in ``fp32`` (its values are fp32 by definition,
+parity mode (fp32-accurate arithmetic: the one held to 1e-3 / bit-exact argmax against the reference); ``bf16x3`` is the fast mode
+inside that same tolerance (fp32 data flow, every nn.Linear product from two bf16 pieces per operand: 2^-16 relative).  Any fake-quantised ``q_format`` runs in ``fp32`` (its values are fp32 by definition,
 utils/quantize.py:84).
 
 There is no CPU compute path: ``forward`` on CPU tensors raises.
@@ -50,7 +51,8 @@ class Linear(nn.Linear, _HipModule):
         ops.require_cuda(x, self.weight)
         if x.dtype != self.act_dtype:
             x = F.cast(x, self.act_dtype)
-        return F.linear(x, self.weight, self.bias)
+        with ops.segments(ops.prec_segments(self.precision)):          # bf16x3 / bf16x6 (only fp32 inputs look at it)
+            return F.linear(x, self.weight, self.bias)
 
 
 class LayerNorm(nn.LayerNorm, _HipModule):
@@ -447,10 +449,11 @@ class ViT(nn.Module):
                 and self.pos_embedding_cat.plain())
 
     def forward(self, img: torch.Tensor):
-        x = self._backbone(img)
-        with self.cm_mlp_head:
-            output = self.decoder(x)
-        output = self.dequant_output(output)
+        with ops.segments(ops.prec_segments(self.precision)):
+            x = self._backbone(img)
+            with self.cm_mlp_head:
+                output = self.decoder(x)
+            output = self.dequant_output(output)
         return output
 
     def segmentation_loss(self, img: torch.Tensor, labels: torch.Tensor):
@@ -460,11 +463,12 @@ class ViT(nn.Module):
         separate HIP kernels (same numbers, more HBM traffic) for shapes the fused kernels do not cover."""
         if not isinstance(self.decoder, SegmentationDecoder):
             raise ValueError("segmentation_loss needs decoder='segmentation'")
-        x = self._backbone(img)
-        with self.cm_mlp_head:
-            if self.decoder.loss_fusable(labels):
-                return self.decoder.loss(x, labels)
-            logits = self.dequant_output(self.decoder(x))
+        with ops.segments(ops.prec_segments(self.precision)):
+            x = self._backbone(img)
+            with self.cm_mlp_head:
+                if self.decoder.loss_fusable(labels):
+                    return self.decoder.loss(x, labels)
+                logits = self.dequant_output(self.decoder(x))
         loss = F.cross_entropy(logits, labels)
         pred = logits.detach().argmax(dim=1)
         return loss, (pred == labels).float().mean(), pred.to(torch.uint8)

@@ -474,6 +474,48 @@ def test_gemm_f32_bf16x6_is_fp32_accurate(ops, M, N, K):
     assert relerr(o, x.double() @ w.double().t() + b.double()) < 4e-6
 
 
+@pytest.mark.parametrize("M,N,K", [(394, 192, 192), (1600, 768, 768), (1600, 3072, 768), (1024, 768, 3072), (4096, 2304, 768)])
+def test_gemm_f32_bf16x3_is_2e16_accurate(ops, M, N, K):
+    """The bf16x3 products (``ops.segments(3)``: two bf16 pieces per operand, pairings a0 b0 + a0 b1 + a1 b0 in ONE bf16 MFMA
+    product over 3 K) against fp64: forward (+bias, +residual, +GELU), dX (+GELU'), dW / db.  Error model: a piece is an 8-bit
+    significand, so the dropped terms (a1 b1, the third pieces) are <= 2^-16 |a||b| per product -- 256x below a plain bf16 product
+    -- and they add up like rounding noise over the contraction.  Bounds: 2e-5 of max|C| (a plain bf16 product of these
+    operands measures ~3e-3), and the pieces themselves are exact: p0 + p1 == x to 2^-17 |x|."""
+    x, w, b = torch.randn(M, K, generator=g(1)).cuda(), torch.randn(N, K, generator=g(2)).cuda(), torch.randn(N, generator=g(3)).cuda()
+    dy, res = torch.randn(M, N, generator=g(4)).cuda(), torch.randn(M, N, generator=g(5)).cuda()
+    with ops.segments(3):
+        s2 = ops.split3(x, M, K, K, 0)
+        assert s2.shape == (M, 3 * K)
+        p0, p0b, p1 = s2[:, :K].float(), s2[:, K:2 * K].float(), s2[:, 2 * K:].float()
+        assert torch.equal(p0, p0b) and torch.equal(p0, x.bfloat16().float())
+        assert float(((p0 + p1) - x).abs().max() / x.abs().max()) < 2.0 ** -16
+        r2 = ops.split3(x, M, K, K, 1)                                  # right-operand order: p0 p1 p0
+        assert torch.equal(r2[:, :K], s2[:, :K]) and torch.equal(r2[:, K:2 * K], s2[:, 2 * K:]) and torch.equal(r2[:, 2 * K:], s2[:, :K])
+        outs = []
+        o = torch.empty(M, N, device="cuda"); ops.linear_fwd(x, M, K, w, b, o, N); outs.append(o)
+        o = torch.empty(M, N, device="cuda"); ops.linear_fwd(x, M, K, w, b, o, N, epi=ops.EPI_RESIDUAL, aux=res, ld_aux=N); outs.append(o)
+        o, h = torch.empty(M, N, device="cuda"), torch.empty(M, N, device="cuda")
+        ops.linear_fwd(x, M, K, w, b, o, N, epi=ops.EPI_GELU, out2=h, ld_out2=N); outs += [o, h]
+        o = torch.empty(M, K, device="cuda"); ops.linear_dx(dy, M, N, w, o, K); outs.append(o)
+        o = torch.empty(M, K, device="cuda"); ops.linear_dx(dy, M, N, w, o, K, epi=ops.EPI_DGELU, aux=x, ld_aux=K); outs.append(o)
+        with ops.split_scope():
+            dw, db = ops.linear_dw(dy, x, M, N, K); outs += [dw, db]
+    y64 = x.double() @ w.double().t() + b.double()
+    gelu = torch.nn.functional.gelu
+    dx64 = dy.double() @ w.double()
+    xd = x.double().requires_grad_(True)
+    (dgelu,) = torch.autograd.grad(gelu(xd).sum(), xd)
+    ref64 = [y64, y64 + res.double(), gelu(y64), y64, dx64, dx64 * dgelu, dy.double().t() @ x.double(), dy.double().sum(0)]
+    worst = 0.0
+    for i, (a, r) in enumerate(zip(outs, ref64)):
+        e = relerr(a, r)
+        worst = max(worst, e)
+        assert e < 2e-5, (i, e)
+    # the scope is per call: outside it the same calls are bf16x6 again (and far tighter)
+    o = torch.empty(M, N, device="cuda"); ops.linear_fwd(x, M, K, w, b, o, N)
+    assert relerr(o, y64) < 2e-6 and worst > relerr(o, y64)
+
+
 def test_attention_materialised_fp32_mfma_equals_fma(ops):
     from myrtle_vision.hip.lib import lib
     B, N, H, dh = 2, 197, 3, 64
