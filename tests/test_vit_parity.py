@@ -100,8 +100,13 @@ def check_case(name, precision, tol_logits, tol_grad, q_format=None):
         s_got, s_want = summarize(lg).numpy(), arrays["logits_summary"]
         # bf16 and fake-quantised paths: norms only (their rounding errors are correlated, and a plain sum over 1.7 M logits
         # compared against the l2 scale amplifies them 1000-fold: measured 3.7e-4 of the sum itself for FP16_32)
-        idx = slice(0, 4) if precision in EXACT and q_format is None else slice(1, 3)
+        # (bf16x3: its 2^-16 product errors are correlated across the 256 pixels one source logit is upsampled to, so the plain sum
+        # over 1.1 M logits is held to 1e-3 of ITSELF (measured 6e-6) and the norms to 1e-3 of the l2 scale)
+        idx = slice(0, 4) if precision == "fp32" and q_format is None else slice(1, 3)
         assert np.abs(s_got[idx] - s_want[idx]).max() / s_want[1] < tol_logits
+        if precision == "bf16x3":
+            assert abs(s_got[0] - s_want[0]) < tol_logits * max(abs(s_want[0]), s_want[1])
+            assert abs(s_got[3] - s_want[3]) < tol_logits * max(abs(s_want[3]), s_want[1])
     assert abs(float(loss) - float(arrays["loss"])) < tol_logits * max(1.0, abs(float(arrays["loss"])))
     unused = []
     worst = 0.0
