@@ -65,9 +65,11 @@ int mv_version(void);
 const char* mv_error_string(int code);
 /* number of bytes of workspace mv_gemm_tn_bf16 / mv_layernorm_bwd want for these sizes */
 size_t mv_gemm_tn_workspace_bytes(int M, int N, int Kc);
-/* Tuning / test hook (no reference counterpart): force a kernel variant for the following mv_gemm_nt_bf16 (0 auto | 128 | 256 | 2564 ring | 2568
- * 8-phase | 2569 persistent 8-phase | 2567 automatic dispatch with the 8-phase epilogue's aux prefetch off | 2565 automatic dispatch with global_load_lds instead of buffer_load ... lds staging in the 8-phase kernel) and mv_gemm_tn_bf16 (0 auto | 128 | 256 ring) calls of this process; a forced variant that cannot run a
- * shape (alignment of K) falls back to the automatic choice.  Results are identical up to fp32 summation order. */
+/* Tuning / test hook (no reference counterpart): force a kernel variant for the following mv_gemm_nt_bf16 (0 auto | 128 | 2564 ring |
+ * 2568 8-phase | 25680 8-phase without the half-item tail | 3000 / 3002 automatic dispatch with the 8-phase kernel's column bands
+ * off / on | 3100 / 3102 the same with the 8-phase kernel forced) and mv_gemm_tn_bf16 (0 auto | 128 | 256 ring) calls of this
+ * process; a forced variant that cannot run a shape (alignment of K) falls back to the automatic choice.  Results are identical up
+ * to fp32 summation order (bands on / off: bit for bit). */
 int mv_gemm_force_variant(int nt_variant, int tn_variant);
 size_t mv_layernorm_bwd_workspace_bytes(int rows, int dim);
 

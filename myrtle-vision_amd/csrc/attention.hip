@@ -20,10 +20,6 @@
 
 #include <atomic>
 
-#ifndef MV_ATTN_ABLATE
-#define MV_ATTN_ABLATE 0   // diagnostic builds only (tools/ablate_attn.sh): bits 1-16 remove phases of attn_bwd4_kernel, 32 / 64 the passes
-                           // of attn_bwd2p_kernel, 128-2048 phases of attn_fwd_kernel (S products, exp, PV products, K/V staging, stores)
-#endif
 
 namespace {
 
@@ -133,7 +129,7 @@ __global__ __launch_bounds__(256, (NKT <= 18 ? 2 : 1)) void attn_fwd_kernel(cons
   const int b = blockIdx.x / H, h = blockIdx.x % H;
   const long D = (long)H * 64;
   const bf16_t* base = qkv + (long)b * N * 3 * D + h * 64;
-  if (!(MV_ATTN_ABLATE & 1024)) stage_kv_dma(base, D, N, sK, NP, sV, NP, wave, 4, lane);
+  stage_kv_dma(base, D, N, sK, NP, sV, NP, wave, 4, lane);
   const int nqt = (N + 15) >> 4;
   // Q fragments straight from global memory, one 16-query tile ahead: the next tile's loads are in flight while this
   // one computes (rows >= N clamped: those outputs are not stored)
@@ -162,7 +158,7 @@ __global__ __launch_bounds__(256, (NKT <= 18 ? 2 : 1)) void attn_fwd_kernel(cons
 #pragma unroll
     for (int kp = 0; kp < NKT; kp += 2) {
       f32x4 acc[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
-      if (!(MV_ATTN_ABLATE & 128)) {
+      {
         const bf16x8 ka0 = row_frag128(sK, kp * 16, L.rf[0]), kb0 = row_frag128(sK, (kp + 1) * 16, L.rf[0]);
         const bf16x8 ka1 = row_frag128(sK, kp * 16, L.rf[1]), kb1 = row_frag128(sK, (kp + 1) * 16, L.rf[1]);
         acc[0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ka0, qf[0], acc[0], 0, 0, 0);
@@ -192,7 +188,7 @@ __global__ __launch_bounds__(256, (NKT <= 18 ? 2 : 1)) void attn_fwd_kernel(cons
     for (int kt = 0; kt < NKT; ++kt)
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        const float p = (MV_ATTN_ABLATE & 256) ? st[kt][r] : __builtin_amdgcn_exp2f(st[kt][r] - mx);
+        const float p = __builtin_amdgcn_exp2f(st[kt][r] - mx);
         st[kt][r] = p;
         sum += p;
       }
@@ -207,7 +203,6 @@ __global__ __launch_bounds__(256, (NKT <= 18 ? 2 : 1)) void attn_fwd_kernel(cons
       const bf16x8 pf = pack8(st[2 * u], st[2 * u + 1]);
 #pragma unroll
       for (int dt = 0; dt < 4; ++dt) {
-        if (MV_ATTN_ABLATE & 512) continue;
         o[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(tr_frag128(sV, 32 * u, L.tr[dt]), pf, o[dt], 0, 0, 0);
       }
     }
@@ -216,7 +211,7 @@ __global__ __launch_bounds__(256, (NKT <= 18 ? 2 : 1)) void attn_fwd_kernel(cons
 #pragma unroll
       for (int dt = 0; dt < 4; ++dt) o[dt] *= inv;
       const u32x4 w0 = pair16(o[0], o[1]), w1 = pair16(o[2], o[3]);
-      if (qrow < N && (!(MV_ATTN_ABLATE & 2048) || sum == 1234.5f)) {
+      if (qrow < N) {
         bf16_t* orow = out + ((long)b * N + qrow) * D + h * 64;
         *reinterpret_cast<u32x4*>(orow + pair16_off(0, g)) = w0;
         *reinterpret_cast<u32x4*>(orow + pair16_off(2, g)) = w1;
@@ -729,18 +724,6 @@ __global__ __launch_bounds__(512, 1) void attn_bwd_kernel(const bf16_t* __restri
 // phases between barriers have nothing to overlap with.  This variant keeps the same mathematics and fragment maps but
 // fits two workgroups on a CU: single-buffered Q/dO pair and dS^T (two barriers per query pair instead of one), V
 // trimmed to the 13 real key tiles -> 79,616 B.  Wave w owns key tiles w, w+4, w+8, w+12 (128 accumulator VGPRs).
-#ifdef MV_ATTN_TRACE
-// diagnostic build (tools/diag/attn_timeline.py): per-workgroup time stamps (100 MHz s_memrealtime), wave 0 only
-__device__ unsigned long long g_attn_trace[16 * 4096];
-extern "C" int mv_debug_attn_trace(void* dst) {
-  return hipMemcpyFromSymbol(dst, HIP_SYMBOL(g_attn_trace), sizeof(g_attn_trace)) == hipSuccess ? 0 : -1;
-}
-#define ATTN_STAMP(v_) v_ = __builtin_amdgcn_s_memrealtime();
-#define ATTN_ACC(acc_, from_, to_) acc_ += (to_) - (from_);
-#else
-#define ATTN_STAMP(v_)
-#define ATTN_ACC(acc_, from_, to_)
-#endif
 template <int NW>   // waves per workgroup: 4 (256 registers per lane) or 2 (one wave per SIMD: 512)
 __global__ __launch_bounds__(64 * NW, NW / 2) void attn_bwd4_kernel(const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ out,
                                                            const bf16_t* __restrict__ dout, const float* __restrict__ lse,
@@ -765,14 +748,7 @@ __global__ __launch_bounds__(64 * NW, NW / 2) void attn_bwd4_kernel(const bf16_t
   bf16_t* dbase = dqkv + (long)b * N * 3 * D + h * 64;
   const u32x4 zero4 = {0u, 0u, 0u, 0u};
   const float c2 = scale * LOG2E;
-  unsigned long long ts0 = 0, ts1 = 0, ts2 = 0, ta = 0, tb = 0, tc = 0, td = 0, a_s = 0, a_b1 = 0, a_q = 0, a_b2 = 0;
-  ATTN_STAMP(ts0)
 
-#ifdef MV_ATTN_STAGGER
-  // diagnostic: the second workgroup of every CU's first round starts late, so the two resident workgroups run out of phase
-  if (blockIdx.x >= 256 && blockIdx.x < 512)
-    for (int i = 0; i < MV_ATTN_STAGGER; ++i) __builtin_amdgcn_s_sleep(127);
-#endif
   // K, V by DMA (the serialized register path was 112 of this kernel's 313 us: stage_kv_dma)
   stage_kv_dma(base, D, N, sK, NPK, sV, NPV, wave, NW, lane);
   // dS^T rows no wave ever writes must read as zero in the dQ phase.  Two waves (192 < N): the 14 key tiles are all written (the
@@ -781,7 +757,7 @@ __global__ __launch_bounds__(64 * NW, NW / 2) void attn_bwd4_kernel(const bf16_t
     for (int idx = tid; idx < NPK * 4; idx += NT) reinterpret_cast<u32x4*>(sDS)[idx] = zero4;
   for (int row = tid; row < NPK; row += NT) {
     float l2 = INFINITY;
-    if (row < N && !(MV_ATTN_ABLATE & 8)) l2 = lse[((long)b * H + h) * N + row] * LOG2E;
+    if (row < N) l2 = lse[((long)b * H + h) * N + row] * LOG2E;
     sLse[row] = l2;
   }
 
@@ -819,7 +795,7 @@ __global__ __launch_bounds__(64 * NW, NW / 2) void attn_bwd4_kernel(const bf16_t
     dl += __shfl_xor(dl, 1);
     dl += __shfl_xor(dl, 2);
     dl += __shfl_xor(dl, 4);
-    if ((tid & 7) == 0) sDelta[32 * u + (tid >> 3) + (NT / 8) * j] = (MV_ATTN_ABLATE & 8) ? 0.f : dl;
+    if ((tid & 7) == 0) sDelta[32 * u + (tid >> 3) + (NT / 8) * j] = dl;
   };
 
   f32x4 adk[KPW][4], adv[KPW][4];
@@ -844,20 +820,18 @@ __global__ __launch_bounds__(64 * NW, NW / 2) void attn_bwd4_kernel(const bf16_t
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // this wave's K/V DMA pieces have landed
   __syncthreads();
-  ATTN_STAMP(ts1)
 
   const char* sQ = sPair;
   const char* sDO = sPair + 4096;
   const int nkt_valid = (N + 15) >> 4;
   f32x4 dqs0 = {0.f, 0.f, 0.f, 0.f}, dqs1 = {0.f, 0.f, 0.f, 0.f};   // running column sums of this wave's two dQ tiles
   for (int u = 0; u < NQP; ++u) {
-    ATTN_STAMP(ta)
     u32x4 nx[PE], nxo[PE / 2];
 #pragma unroll
     for (int e = 0; e < PE; ++e) nx[e] = zero4;
 #pragma unroll
     for (int j = 0; j < PE / 2; ++j) nxo[j] = zero4;
-    if (u + 1 < NQP && !(MV_ATTN_ABLATE & 4)) {
+    if (u + 1 < NQP) {
 #pragma unroll
       for (int e = 0; e < PE; ++e) nx[e] = load_pair(u + 1, e);
 #pragma unroll
@@ -969,7 +943,7 @@ __global__ __launch_bounds__(64 * NW, NW / 2) void attn_bwd4_kernel(const bf16_t
         }
         stage_c(KPW - 1);
       }
-    } else if (32 * u < N && !(MV_ATTN_ABLATE & 16)) {
+    } else if (32 * u < N) {
       // The query pair's TRANSPOSED fragments (operands of the dV / dK products) do not depend on the key tile: read them
       // once per pair (8 fragments, 32 VGPRs) instead of once per key tile.  (Hoisting the row fragments as well spills.)
       bf16x8 dotr[4], qtr[4];
@@ -1006,10 +980,10 @@ __global__ __launch_bounds__(64 * NW, NW / 2) void attn_bwd4_kernel(const bf16_t
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
             const int ql = 32 * u + 16 * t + 4 * g + r;
-            float p = (MV_ATTN_ABLATE & 2) ? s[t][r] : __builtin_amdgcn_exp2f(s[t][r] * c2 - sLse[ql]);
-            p = ((MV_ATTN_ABLATE & 2) || key < N) ? p : 0.f;
+            float p = __builtin_amdgcn_exp2f(s[t][r] * c2 - sLse[ql]);
+            p = key < N ? p : 0.f;
             pp[t][r] = p;
-            ds[t][r] = (MV_ATTN_ABLATE & 2) ? dp[t][r] : p * (dp[t][r] - sDelta[ql]) * scale;
+            ds[t][r] = p * (dp[t][r] - sDelta[ql]) * scale;
           }
         const bf16x8 pf = pack8(pp[0], pp[1]);
         const bf16x8 dsf = pack8(ds[0], ds[1]);
@@ -1022,10 +996,8 @@ __global__ __launch_bounds__(64 * NW, NW / 2) void attn_bwd4_kernel(const bf16_t
         for (int t = 0; t < 2; ++t) *reinterpret_cast<bf16x4*>(sDS + swds4(key, t, g)) = pack4(ds[t]);
       }
     }
-    ATTN_STAMP(tb)
     __syncthreads();                                   // S-phase done everywhere: dS^T complete, Q/dO pair no longer read
-    ATTN_STAMP(tc)
-    if (u + 1 < NQP && !(MV_ATTN_ABLATE & 4)) {
+    if (u + 1 < NQP) {
 #pragma unroll
       for (int e = 0; e < PE; ++e) store_pair(e, nx[e]);
 #pragma unroll
@@ -1033,7 +1005,7 @@ __global__ __launch_bounds__(64 * NW, NW / 2) void attn_bwd4_kernel(const bf16_t
     }
     // dQ^T[d][q] = sum_key K^T[d][key] dS^T[key][q]: 2 q-tiles x 4 d-tiles = 8 output tiles.  Four waves: two each (one q-tile,
     // a d-tile pair); two waves: four each (both q-tiles of d-tile pair `wave`: the K^T fragments serve both)
-    if (32 * u < N && !(MV_ATTN_ABLATE & 1)) {
+    if (32 * u < N) {
       constexpr int QT = NW == 4 ? 1 : 2;
       const int t0 = NW == 4 ? wave >> 1 : 0, dh = NW == 4 ? (wave & 1) : wave;
       const int trk0 = dh ? L.tr[2] : L.tr[0], trk1 = dh ? L.tr[3] : L.tr[1];
@@ -1085,17 +1057,8 @@ __global__ __launch_bounds__(64 * NW, NW / 2) void attn_bwd4_kernel(const bf16_t
         dqs1 += dq[tq][1];
       }
     }
-    ATTN_STAMP(td)
     __syncthreads();                                   // dS^T reads done; next Q/dO pair visible
-#ifdef MV_ATTN_TRACE
-    {
-      unsigned long long te;
-      ATTN_STAMP(te)
-      ATTN_ACC(a_s, ta, tb) ATTN_ACC(a_b1, tb, tc) ATTN_ACC(a_q, tc, td) ATTN_ACC(a_b2, td, te)
-    }
-#endif
   }
-  ATTN_STAMP(ts2)
 
   if constexpr (NW == 2) {                                   // dS^T came without the softmax scale
 #pragma unroll
@@ -1151,21 +1114,6 @@ __global__ __launch_bounds__(64 * NW, NW / 2) void attn_bwd4_kernel(const bf16_t
     __syncthreads();
     attn_colsum_store<NW>(red, colsum + (long)b * 3 * D + h * 64, D, tid);
   }
-#ifdef MV_ATTN_TRACE
-  {
-    unsigned long long ts3, ts4;
-    ATTN_STAMP(ts3)
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    ATTN_STAMP(ts4)
-    if (tid == 0 && blockIdx.x < 4096) {
-      unsigned long long* tr = g_attn_trace + 16 * blockIdx.x;
-      tr[0] = ts0; tr[1] = ts1; tr[2] = ts2; tr[3] = ts3; tr[4] = ts4;
-      tr[5] = a_s; tr[6] = a_b1; tr[7] = a_q; tr[8] = a_b2;
-      tr[9] = __builtin_amdgcn_s_getreg(0xF804);
-      tr[10] = __builtin_amdgcn_s_getreg(0xF814);
-    }
-  }
-#endif
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1236,7 +1184,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd2p_kernel(const bf16_t* __rest
   f32x4 dqs[4];
 #pragma unroll
   for (int dt = 0; dt < 4; ++dt) dqs[dt] = (f32x4){0.f, 0.f, 0.f, 0.f};
-  for (int task = wave; task < NP32 && !(MV_ATTN_ABLATE & 32); task += 4) {
+  for (int task = wave; task < NP32; task += 4) {
     if (32 * task >= N) break;
     bf16x8 qf[2][2], dof[2][2];
     float dl[2], l2[2];
@@ -1349,7 +1297,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd2p_kernel(const bf16_t* __rest
       }
   }
   const int nkt_valid = (N + 15) >> 4;
-  for (int task = wave; task < NP32 && !(MV_ATTN_ABLATE & 64); task += 4) {
+  for (int task = wave; task < NP32; task += 4) {
     if (32 * task >= N) break;
     bf16x8 kf[2][2], vf[2][2];
 #pragma unroll

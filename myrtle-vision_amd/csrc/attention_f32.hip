@@ -29,9 +29,6 @@ namespace {
 constexpr int AF_DH = 64;
 __device__ __forceinline__ int vt_sw(int d) { return (0xF0 >> (((d >> 2) & 3) * 2)) & 3; }   // {0, 0, 3, 3}[(d >> 2) & 3]
 constexpr float AF_LOG2E = 1.4426950408889634f, AF_LN2 = 0.6931471805599453f;
-#ifndef MV_AF_ABLATE
-#define MV_AF_ABLATE 0   // diagnostic builds only: 1 no S products, 2 no softmax, 4 no PV products, 8 no staging, 16 no output
-#endif
 
 // NT = key/query tiles of 16 (13: N <= 208, i.e. 197 tokens; 17: N <= 272, i.e. 257 tokens)
 // Q8 = true: the result goes straight into to_out's quint8 quantiser and leaves as int8 codes q - 128 ([B, N, H*64] int8)
@@ -67,8 +64,8 @@ __global__ __launch_bounds__(512) void attn_fwd_f32_kernel(const float* __restri
       const int vkey = i % NK, vj = i / NK;
       kst[it] = (f32x4){0.f, 0.f, 0.f, 0.f};
       vst[it] = (f32x4){0.f, 0.f, 0.f, 0.f};
-      if (i < NK * 16 && kkey < N && !(MV_AF_ABLATE & 8)) kst[it] = *reinterpret_cast<const f32x4*>(kb + kkey * row + 4 * kj);
-      if (i < NK * 16 && vkey < N && !(MV_AF_ABLATE & 8)) vst[it] = *reinterpret_cast<const f32x4*>(vb + vkey * row + 4 * vj);
+      if (i < NK * 16 && kkey < N) kst[it] = *reinterpret_cast<const f32x4*>(kb + kkey * row + 4 * kj);
+      if (i < NK * 16 && vkey < N) vst[it] = *reinterpret_cast<const f32x4*>(vb + vkey * row + 4 * vj);
     }
   };
   auto write_lds = [&]() {
@@ -130,7 +127,6 @@ __global__ __launch_bounds__(512) void attn_fwd_f32_kernel(const float* __restri
       for (int c = 0; c < 4; ++c)
 #pragma unroll
         for (int kk = 0; kk < 4; ++kk) {
-          if (MV_AF_ABLATE & 1) continue;
           acc[T] = __builtin_amdgcn_mfma_f32_16x16x4f32(kf[c][kk], qf[c][kk], acc[T], 0, 0, 0);
         }
 #pragma unroll
@@ -186,7 +182,6 @@ __global__ __launch_bounds__(512) void attn_fwd_f32_kernel(const float* __restri
       for (int r = 0; r < 4; ++r)
 #pragma unroll
         for (int dt = 0; dt < 4; ++dt) {
-          if (MV_AF_ABLATE & 4) continue;
           o[dt] = __builtin_amdgcn_mfma_f32_16x16x4f32(vf[dt][r], acc[T][r], o[dt], 0, 0, 0);
         }
 #pragma unroll

@@ -33,9 +33,6 @@
 #include <atomic>
 #include <type_traits>
 
-#ifndef MV_ABLATE
-#define MV_ABLATE 0   // diagnostic builds only (tools/ablate_gemm.sh); 0 in the product
-#endif
 namespace {
 
 constexpr int BM = 128, BN = 128, BK = 64;
@@ -67,8 +64,7 @@ struct EpiArgs {
   // contraction slice t / ks_tiles (ks_len elements long) and writes slab t / ks_tiles (ks_slab elements apart)
   int ks_tiles, ks_len;
   long ks_slab;
-  int no_prefetch;      // A/B switch (mv_gemm_force_variant 2567): the 8-phase epilogue loads each quadrant's aux tile itself
-  int glds_dma;         // A/B switch (2565): the 8-phase kernel stages its slots with global_load_lds (round 2) instead of buffer_load ... lds
+  int band;             // 8-phase kernel: > 0 = an XCD walks column BANDS of this many tile columns (its B slice stays in its L2)
 };
 
 // 16-byte output store of the NT epilogues
@@ -725,107 +721,9 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_glds_kernel(const bf16_t* __re
   nt_epilogue<EPI, CT>(acc, C, ldc, M, N, m0, n0, wm, wn, lane, ep);
 }
 
-// ------------------------------------------------------------------------------------------------
-// NT kernel, 256x256 tile, direct-to-LDS staging (K % 64 == 0, large N)
-// ------------------------------------------------------------------------------------------------
-// The 128x128 kernel is bound by (bytes in flight) / (DMA latency): one 32 KiB stage per workgroup in flight against
-// ~1.5 us of loaded latency (measured: 3,170 cycles per K-step vs 512 cycles of MFMA per wave, MFMA pipe 32 % busy).
-// LDS is the in-flight buffer, so the lever is FLOPs per staged byte: a 256x256 tile does 2x the MFMA work of the
-// 128x128 tile per byte brought into LDS and per byte read out of it (per wave 128x64 = 8x4 MFMA tiles: 12 fragment
-// reads feed 32 MFMAs instead of 8 feeding 16).  8 waves (2 per SIMD, one workgroup per CU), 2 x 64 KiB stages.
+// 256 x 256 tiles (the ring and 8-phase kernels).  The first kernel of this tile size (two 64 KiB stages) is retired:
+// csrc/diag/gemm_nt_glds256.inc.
 constexpr int BM2 = 256, BN2 = 256;
-constexpr int STAGE2_BYTES = (BM2 + BN2) * BK * 2;  // 64 KiB
-constexpr int SMEM2_BYTES = 2 * STAGE2_BYTES;       // 128 KiB
-
-template <int EPI, typename CT>
-__global__ __launch_bounds__(512, 2) void gemm_nt_glds256_kernel(const bf16_t* __restrict__ A, int lda,
-                                                                 const bf16_t* __restrict__ B, int ldb, CT* __restrict__ C,
-                                                                 int ldc, int M, int N, int K, int tiles_n, EpiArgs ep) {
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int wm = wave >> 2, wn = wave & 3;           // wave tile: rows [128 wm, +128), cols [64 wn, +64)
-  const int t = xcd_remap(blockIdx.x, gridDim.x);
-  const int m0 = (t / tiles_n) * BM2, n0 = (t % tiles_n) * BN2;
-
-  // wave w stages rows [32w, 32w+32) of both 256-row tiles: 4 + 4 wave-instructions per K-step
-  const bf16_t* pa[4];
-  const bf16_t* pb[4];
-#pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    const int row = 32 * wave + 8 * i + (lane >> 3);
-    const int ch = (lane & 7) ^ (((row >> 1) & 3) << 1);
-    const int ar = m0 + row < M ? m0 + row : M - 1, br = n0 + row < N ? n0 + row : N - 1;
-    pa[i] = A + (long)ar * lda + ch * 8;
-    pb[i] = B + (long)br * ldb + ch * 8;
-  }
-  char* const wave_lds = smem + 32 * wave * 128;
-#define NT2_ISSUE(stage_, kt_)                                                         \
-  {                                                                                    \
-    char* la_ = wave_lds + (stage_) * STAGE2_BYTES;                                    \
-    char* lb_ = la_ + BM2 * BK * 2;                                                    \
-    const int ko_ = (kt_) * BK;                                                        \
-    glds16(pa[0] + ko_, la_);          glds16(pa[1] + ko_, la_ + 1024);                \
-    glds16(pa[2] + ko_, la_ + 2048);   glds16(pa[3] + ko_, la_ + 3072);                \
-    glds16(pb[0] + ko_, lb_);          glds16(pb[1] + ko_, lb_ + 1024);                \
-    glds16(pb[2] + ko_, lb_ + 2048);   glds16(pb[3] + ko_, lb_ + 3072);                \
-  }
-
-  f32x4 acc[8][4];
-#pragma unroll
-  for (int i = 0; i < 8; ++i)
-#pragma unroll
-    for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
-
-  const int nk = K / BK;
-  const int frow = lane & 15, fch = lane >> 4;
-  NT2_ISSUE(0, 0)
-  for (int kt = 0; kt < nk; ++kt) {
-    const int cur = kt & 1;
-#if MV_ABLATE == 1
-    if (false) {
-#else
-    if (kt + 1 < nk) {
-#endif
-      NT2_ISSUE(cur ^ 1, kt + 1)
-      asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-    } else {
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    }
-    __builtin_amdgcn_s_barrier();
-    asm volatile("" ::: "memory");
-    const char* sa = smem + cur * STAGE2_BYTES + wm * 128 * 128;
-    const char* sb = smem + cur * STAGE2_BYTES + BM2 * BK * 2 + wn * 64 * 128;
-#if MV_ABLATE != 2
-#pragma unroll
-#else
-#pragma unroll
-    for (int ks = 0; ks < 0; ++ks) {}
-    if (false)
-#endif
-    for (int ks = 0; ks < 2; ++ks) {
-      bf16x8 bfr[4];
-#pragma unroll
-      for (int j = 0; j < 4; ++j) bfr[j] = *reinterpret_cast<const bf16x8*>(sb + sw128(j * 16 + frow, 4 * ks + fch));
-#pragma unroll
-      for (int i = 0; i < 8; ++i) {
-        const bf16x8 af = *reinterpret_cast<const bf16x8*>(sa + sw128(i * 16 + frow, 4 * ks + fch));
-#pragma unroll
-        for (int j = 0; j < 4; ++j)
-          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[j], af, acc[i][j], 0, 0, 0);
-      }
-    }
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
-  }
-#undef NT2_ISSUE
-  // epilogue in two 64-row halves of the wave tile (keeps the hoisted aux vectors within the register budget);
-  // nt_epilogue addresses a 128x128 region with a 2x2 wave grid, so present this wave as quadrant (h, wn & 1) of the
-  // region whose origin is (m0 + 128 wm, n0 + 128 (wn >> 1))
-#pragma unroll
-  for (int h = 0; h < 2; ++h)
-    nt_epilogue<EPI, CT>(*reinterpret_cast<f32x4(*)[4][4]>(&acc[4 * h]), C, ldc, M, N, m0 + 128 * wm, n0 + 128 * (wn >> 1), h,
-                         wn & 1, lane, ep);
-}
 
 // ------------------------------------------------------------------------------------------------
 // NT kernel, 256x256 tile, LDS RING of S stages of BK = 32 (K % 32 == 0)
@@ -994,17 +892,7 @@ typedef __attribute__((ext_vector_type(4))) int i32x4;
 constexpr int NT_BF16 = 0, NT_I8 = 1, NT_F16 = 2;
 typedef __attribute__((ext_vector_type(8))) _Float16 f16x8;
 
-#if MV_ABLATE == 32
-// diagnostic build (tools/diag/p8_timeline.py): per-workgroup time stamps (100 MHz s_memrealtime) and hardware ids
-__device__ unsigned long long g_p8_trace[8 * 4096];
-extern "C" int mv_debug_p8_trace(void* dst) {
-  return hipMemcpyFromSymbol(dst, HIP_SYMBOL(g_p8_trace), sizeof(g_p8_trace)) == hipSuccess ? 0 : -1;
-}
-#define P8_STAMP(v_) v_ = __builtin_amdgcn_s_memrealtime();
-#else
-#define P8_STAMP(v_)
-#endif
-template <int EPI, typename CT, int OPK = NT_BF16, bool KSPLIT = false, bool BUFDMA = true>
+template <int EPI, typename CT, int OPK = NT_BF16, bool KSPLIT = false>
 __global__ __launch_bounds__(512, 2) void gemm_nt_8phase_kernel(const bf16_t* __restrict__ A, int lda,
                                                                 const bf16_t* __restrict__ B, int ldb, CT* __restrict__ C,
                                                                 int ldc, int M, int N, int K, int tiles_n, EpiArgs ep,
@@ -1023,14 +911,22 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_8phase_kernel(const bf16_t* __
   int t, half = -1;
   if (bid < full_tiles) {
     t = xcd_remap(bid, full_tiles);
+    if (!KSPLIT && ep.band > 0) {
+      // Column bands (tiles_n % band == 0, dispatch): the whole tile rows of the full region are enumerated band by band, row-major
+      // inside a band, and an XCD owns a contiguous run of THAT order -- one or two bands per XCD for the whole launch, so its
+      // slice of B (band x K x 512 B; 1.2 MB for three tile columns at K = 768) stays in its 4 MiB L2 while it walks down A.
+      const int rows = full_tiles / tiles_n, per_band = rows * ep.band;
+      if (t < rows * tiles_n) {
+        const int b = t / per_band, r = t - b * per_band, rm = r / ep.band;
+        t = rm * tiles_n + b * ep.band + (r - rm * ep.band);
+      }
+    }
   } else {
     const int idx = bid - full_tiles;
     t = full_tiles + (idx >> 1);
     half = idx & 1;
   }
   const bool is_half_rt = half >= 0;             // wave-uniform
-  unsigned long long ts0 = 0, ts1 = 0, ts2 = 0;
-  P8_STAMP(ts0)
   if constexpr (KSPLIT) {                        // K = the slice length; the bias rides on slice 0 only
     const int ks = t / ep.ks_tiles;
     t -= ks * ep.ks_tiles;
@@ -1066,30 +962,23 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_8phase_kernel(const bf16_t* __
   }
   // the wave's staging destination as a provably wave-uniform value: the DMA's LDS base goes to M0 by scalar arithmetic
   char* const wave_lds = smem + __builtin_amdgcn_readfirstlane(wave) * 2048;
-  // BUFDMA (round 3, default): the pieces are buffer_load_dwordx4 ... offen lds -- a wave-uniform descriptor (4 SGPRs) + the lane's
+  // The pieces are buffer_load_dwordx4 ... offen lds -- a wave-uniform descriptor (4 SGPRs) + the lane's
   // 32-bit byte offset (constant over the K loop) + the K-tile's byte offset in an SGPR -- instead of global_load_lds_dwordx4 with
   // a 64-bit per-lane address: no address arithmetic per piece, 16 fewer address VGPRs (the kernel's 10 spilled VGPRs are gone),
-  // and a cheaper request: +3...9 % on every ViT-B shape, 38.40 -> 37.67 ms in the step (NT_VARIANTS=2565,0 tools/ab_step.py;
-  // force 2565 = the global_load_lds form).  The descriptor's extent is the whole operand (rows are clamped, never beyond it).
+  // and a cheaper request: +3...9 % on every ViT-B shape, 38.40 -> 37.67 ms in the step (round 3, in-process A/B against the
+  // global_load_lds form, since removed).  The descriptor's extent is the whole operand (rows are clamped, never beyond it).
   const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(A), (short)0, (int)((unsigned)M * (unsigned)lda * 2u), 0x00020000);
   const __amdgpu_buffer_rsrc_t rsB = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(B), (short)0, (int)((unsigned)N * (unsigned)ldb * 2u), 0x00020000);
-  constexpr bool buf_dma = BUFDMA;
 #define P8_STAGE(buf_, slot_, kt_)                                                      \
-  if (!(MV_ABLATE >= 64 && (MV_ABLATE & 128))) {                                                               \
+  {                                                                                     \
     char* l_ = wave_lds + ((buf_) * 4 + (slot_)) * P8_SLOT;                             \
-    if constexpr (buf_dma) {                                                            \
-      const int so_ = (kt_) * 128;                                                      \
-      if ((slot_) == P8_AQ0 || (slot_) == P8_AQ1) {                                     \
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, LDS_PTR(void, l_), 16, (int)(ps[slot_][0] * 2u), so_, 0, 0);        \
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, LDS_PTR(void, l_ + 1024), 16, (int)(ps[slot_][1] * 2u), so_, 0, 0); \
-      } else {                                                                          \
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsB, LDS_PTR(void, l_), 16, (int)(ps[slot_][0] * 2u), so_, 0, 0);        \
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsB, LDS_PTR(void, l_ + 1024), 16, (int)(ps[slot_][1] * 2u), so_, 0, 0); \
-      }                                                                                 \
+    const int so_ = (kt_) * 128;                                                        \
+    if ((slot_) == P8_AQ0 || (slot_) == P8_AQ1) {                                       \
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, LDS_PTR(void, l_), 16, (int)(ps[slot_][0] * 2u), so_, 0, 0);        \
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, LDS_PTR(void, l_ + 1024), 16, (int)(ps[slot_][1] * 2u), so_, 0, 0); \
     } else {                                                                            \
-      const bf16_t* g_ = (((slot_) == P8_AQ0 || (slot_) == P8_AQ1) ? A : B) + (kt_) * 64; \
-      glds16(g_ + ps[slot_][0], l_);                                                    \
-      glds16(g_ + ps[slot_][1], l_ + 1024);                                             \
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsB, LDS_PTR(void, l_), 16, (int)(ps[slot_][0] * 2u), so_, 0, 0);        \
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsB, LDS_PTR(void, l_ + 1024), 16, (int)(ps[slot_][1] * 2u), so_, 0, 0); \
     }                                                                                   \
   }
 
@@ -1107,17 +996,8 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_8phase_kernel(const bf16_t* __
   const char* const a_rd = smem + 64 * wm * 128;
   const char* const b_rd = smem + 32 * wn * 128;
   bf16x8 af[4][2], bf0[2][2], bf1[2][2];
-#if MV_ABLATE >= 64 && (MV_ABLATE & 64)
-  {                                              // diagnostic (no fragment reads): the MFMAs run on whatever these hold
-    const bf16x8 seed = *reinterpret_cast<const bf16x8*>(A + 8 * lane);
-#pragma unroll
-    for (int i = 0; i < 4; ++i) af[i][0] = af[i][1] = seed;
-#pragma unroll
-    for (int j = 0; j < 2; ++j) bf0[j][0] = bf0[j][1] = bf1[j][0] = bf1[j][1] = seed;
-  }
-#endif
 #define P8_READ_A(buf_, slot_)                                                                               \
-  if (!(MV_ABLATE >= 64 && (MV_ABLATE & 64))) {                                                                                     \
+  {                                                                                                          \
     const char* s_ = a_rd + ((buf_) * 4 + (slot_)) * P8_SLOT;                                                \
     _Pragma("unroll") for (int i = 0; i < 4; ++i) {                                                          \
       af[i][0] = *reinterpret_cast<const bf16x8*>(s_ + i * 2048 + rf0);                                      \
@@ -1125,7 +1005,7 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_8phase_kernel(const bf16_t* __
     }                                                                                                        \
   }
 #define P8_READ_B(dst_, buf_, slot_)                                                                         \
-  if (!(MV_ABLATE >= 64 && (MV_ABLATE & 64))) {                                                                                     \
+  {                                                                                                          \
     const char* s_ = b_rd + ((buf_) * 4 + (slot_)) * P8_SLOT;                                                \
     _Pragma("unroll") for (int j = 0; j < 2; ++j) {                                                          \
       dst_[j][0] = *reinterpret_cast<const bf16x8*>(s_ + j * 2048 + rf0);                                    \
@@ -1133,12 +1013,7 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_8phase_kernel(const bf16_t* __
     }                                                                                                        \
   }
 #define P8_MFMA(mb_, nb_, bfx_)                                                                              \
-  if (MV_ABLATE >= 64 && (MV_ABLATE & 256)) { /* diagnostic (no MFMAs): the fragments are still "used", so their reads stay */   \
-    _Pragma("unroll") for (int ks = 0; ks < 2; ++ks) {                                                       \
-      _Pragma("unroll") for (int i = 0; i < 4; ++i) asm volatile("" ::"v"(af[i][ks]));                       \
-      _Pragma("unroll") for (int j = 0; j < 2; ++j) asm volatile("" ::"v"(bfx_[j][ks]));                     \
-    }                                                                                                        \
-  } else {                                                                                                   \
+  {                                                                                                          \
     __builtin_amdgcn_s_setprio(1);                                                                           \
     _Pragma("unroll") for (int ks = 0; ks < 2; ++ks)                                                         \
       _Pragma("unroll") for (int i = 0; i < 4; ++i)                                                          \
@@ -1230,11 +1105,7 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_8phase_kernel(const bf16_t* __
   if (lazy) { P8_WAIT(10) } else { P8_WAIT(6) }           // B_q0, A_q0 of K-tile 0 landed | the whole K-tile 0
   P8_BAR()
   if (__builtin_amdgcn_readfirstlane(wave) >= 4) P8_BAR()      // waves 4-7 run one barrier behind
-  P8_STAMP(ts1)
   int kt = 0;
-#if MV_ABLATE == 16
-  kt = nk - 2;                                   // diagnostic: only the peeled last iteration runs
-#endif
   for (; kt < nk - 2; kt += 2) {
     // phases 1-4: compute buffer 0 (K-tile kt); stage A_q1[kt+1] -> buffer 1, then B_q0/A_q0/B_q1[kt+2] -> buffer 0
     P8_KTILE(0, 1, 1, kt + 1, 0, kt + 2, P8_WAIT(10), P8_WAIT(10), P8_WAIT(10), P8_WAIT(6), 1)
@@ -1245,7 +1116,6 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_8phase_kernel(const bf16_t* __
   P8_KTILE(0, 0, 1, kt + 1, 0, 0, P8_WAIT(10), P8_WAIT(8), P8_WAIT(4), P8_WAIT(0), 1)
   P8_KTILE(1, 0, 0, 0, 0, 0, P8_WAIT(2), P8_WAIT(0), , , 0)
   if (__builtin_amdgcn_readfirstlane(wave) < 4) P8_BAR()
-  P8_STAMP(ts2)
 #undef P8_WAIT
 #undef P8_KTILE
 #undef P8_LGKM0
@@ -1277,17 +1147,6 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_8phase_kernel(const bf16_t* __
       }
     }
   }
-#if MV_ABLATE == 8
-  {                                              // diagnostic: no epilogue; one conditional store keeps the accumulators alive
-    float keep = 0.f;
-#pragma unroll
-    for (int i = 0; i < 8; ++i)
-#pragma unroll
-      for (int j = 0; j < 4; ++j) keep += acc[i][j][0] + acc[i][j][1] + acc[i][j][2] + acc[i][j][3];
-    if (keep == 12345.678f) C[0] = (CT)keep;
-    return;
-  }
-#endif
   constexpr bool park = epi_is_dgelu(EPI) || EPI == MV_EPI_RESIDUAL;
   f32x4* const parked = reinterpret_cast<f32x4*>(smem) + wave * 16 * 64 + lane;
   if (park && !is_half) {
@@ -1299,7 +1158,7 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_8phase_kernel(const bf16_t* __
   // both quadrant-rows' aux tiles are requested now; the second one lands under the first one's arithmetic and stores
   constexpr bool can_pre = (EPI == MV_EPI_RESIDUAL || EPI == MV_EPI_MUL8) && !KSPLIT;
   if constexpr (can_pre) {
-    if (!is_half && !ep.no_prefetch && nt_epi_prefetch_ok<EPI>(M, N, m0 + 128 * wm, n0 + 128 * (wn >> 1), ldc, ep)) {
+    if (!is_half && nt_epi_prefetch_ok<EPI>(M, N, m0 + 128 * wm, n0 + 128 * (wn >> 1), ldc, ep)) {
       EpiPre<EPI> pre0, pre1;
       nt_epi_prefetch<EPI>(pre0, m0 + 128 * wm, n0 + 128 * (wn >> 1), 0, wn & 1, lane, ep);
       nt_epi_prefetch<EPI>(pre1, m0 + 128 * wm, n0 + 128 * (wn >> 1), 1, wn & 1, lane, ep);
@@ -1333,288 +1192,6 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_8phase_kernel(const bf16_t* __
   };
   if (is_half_rt) body(std::true_type{});
   else body(std::false_type{});
-#if MV_ABLATE == 32
-  {
-    unsigned long long ts3, ts4;
-    P8_STAMP(ts3)                                  // all stores issued
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    P8_STAMP(ts4)                                  // ... and acknowledged
-    if (tid == 0 && blockIdx.x < 4096) {
-      unsigned long long* tr = g_p8_trace + 8 * blockIdx.x;
-      tr[0] = ts0; tr[1] = ts1; tr[2] = ts2; tr[3] = ts3; tr[4] = ts4;
-      tr[5] = __builtin_amdgcn_s_getreg(0xF804);   // HW_ID
-      tr[6] = __builtin_amdgcn_s_getreg(0xF814);   // XCC_ID
-      tr[7] = ((unsigned long long)(is_half_rt ? 1 : 0) << 32) | (unsigned)t;
-    }
-  }
-#endif
-}
-
-// ------------------------------------------------------------------------------------------------
-// NT 8-phase kernel, PERSISTENT: one workgroup per CU walks whole interior tiles; stores drain under the next tile
-// ------------------------------------------------------------------------------------------------
-// Ablation of gemm_nt_8phase_kernel (tools/ablate_gemm8.sh): with the epilogue removed it sustains 1.18-1.27 PFLOP/s on
-// EVERY ViT-B shape, K = 768 included; the epilogue is purely additive (qkv: 149 us of main loop + 80 us of output
-// write, all 256 CUs bursting at once while HBM idles during the main loops) = 32-49 % of the K = 768 GEMMs.  Here a
-// workgroup stays on its CU and walks items blockIdx.x, + gridDim.x, ...: when a tile's main loop ends it first issues
-// the NEXT tile's whole prologue, then this tile's epilogue stores, and goes straight on -- the stores drain while the
-// next tile computes.  What makes that legal with an IN-ORDER vmcnt:
-//   * every DMA is issued through inline asm, so hipcc never waits on them and sees only the stores;
-//   * the next tile's prologue is ALL of K-tiles 0 and 1 (16 pieces) + its bias row (1 piece, into LDS: the epilogue
-//     issues no global load), issued BEFORE the S >= 16 epilogue stores of the current tile;
-//   * in a tile's first iteration the waits step over those stores: K-tile 0 landed = vmcnt(8 + 16), K-tile 1 landed
-//     (phase 4) = vmcnt(6 + 16); from phase 8 on the counts are the usual vmcnt(6).  S = 16 is a lower bound of the
-//     stores actually issued (16 or 32): an underestimate only waits longer.  A workgroup's first tile (no stores before
-//     it) uses vmcnt(8) / vmcnt(6).
-// Register discipline (a first version spilled 50 VGPRs through 47-68 spilled SGPRs, and every scratch reload is a
-// vector-memory load the compiler guards with vmcnt(0) -- it ran 35 % slower): the DMA takes ONE SGPR for the wave's LDS
-// base plus an immediate (s_add_u32 m0, base, imm inside the statement), one running SGPR pointer pair per operand that
-// advances by two K-tiles per iteration, the relative K-tile (1, 2, 3) in the instruction's offset: field, and the 8
-// lane-constant byte offsets in VGPRs.
-// Restricted to what makes the store count exact: whole tiles with M % 256 == N % 256 == 0 (every tile interior),
-// K >= 256, epilogues NONE / GELU / GELU_GRAD.  Half items of a tail round run in a second launch of
-// gemm_nt_8phase_kernel.  Phase schedule, slot organisation and wave stagger are those of gemm_nt_8phase_kernel.
-// Measured (same box, alternating runs): in isolation, also with buffer sets rotated beyond the Infinity Cache, the
-// persistent kernel is +3...21 % per GEMM (qkv 818 -> 992 TFLOP/s); inside the ViT-B training step the event-timed NT
-// time does not drop (20.77 vs 20.59 ms) while the unchanged TN kernel and everything else run 2-4 % slower -- the
-// step LOSES 1.7 % (6 584 vs 6 702 img/s): the chip is power-managed and the saving comes back as lower clocks.  So it
-// is selectable (mv_gemm_force_variant 2569) and tested, but not the automatic choice.
-constexpr int PP_AUTO_FORCE = -1;                  // 0: pick the persistent kernel automatically where eligible; -1: only when forced (2569)
-constexpr int PP_BIAS = 24 * 1024;                 // 8 waves x (2 parities + 1 dummy target) x 1 KiB
-constexpr int PP_SMEM = P8_SMEM + PP_BIAS;
-
-// hidden LDS-DMA, 16 B per lane: global address = SGPR pair + 32-bit lane byte offset; LDS destination = SGPR base +
-// immediate.  Two hardware facts found the hard way: (1) the instruction's offset: field is added to the LDS address as
-// well as to the global address, so it is not used (the relative K-tile is added to the SGPR base instead); (2) M0
-// written directly by s_add_u32 gave garbage destinations, so the sum goes through a scratch SGPR and s_mov_b32.  M0 is
-// saved and restored inside the statement; s_add_u32 clobbers SCC.
-#define PP_DMA(sbase_, voff_, ldsbase_, ldsimm_)                                                                 \
-  {                                                                                                              \
-    unsigned keep_, dst_;                                                                                        \
-    asm volatile("s_mov_b32 %0, m0\n\ts_add_u32 %1, %4, %5\n\ts_mov_b32 m0, %1\n\ts_nop 0\n\t"                  \
-                 "global_load_lds_dwordx4 %2, %3\n\ts_mov_b32 m0, %0"                                            \
-                 : "=&s"(keep_), "=&s"(dst_)                                                                     \
-                 : "v"(voff_), "s"(sbase_), "s"(ldsbase_), "i"(ldsimm_)                                          \
-                 : "memory", "scc");                                                                             \
-  }
-
-template <int EPI, typename CT>
-__global__ __launch_bounds__(512, 2) void gemm_nt_8phase_persistent_kernel(const bf16_t* __restrict__ A, int lda,
-                                                                           const bf16_t* __restrict__ B, int ldb,
-                                                                           CT* __restrict__ C, int ldc, int M, int N, int K,
-                                                                           int tiles_n, EpiArgs ep, int n_items) {
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int wm = wave >> 2, wn = wave & 3;
-  const int nk = K >> 6;                         // even, >= 4 (dispatch)
-
-  // this lane's staging offsets inside a tile, in BYTES from the tile's first A / B row at the current K-tile
-  unsigned pa00, pa01, pa10, pa11, pb00, pb01, pb10, pb11;     // p{a,b}{q}{i}
-  {
-    const int r0 = 16 * wave + (lane >> 3), r1 = r0 + 8;
-    const int c0 = (lane & 7) ^ (((r0 >> 1) & 3) << 1), c1 = (lane & 7) ^ (((r1 >> 1) & 3) << 1);
-    const int ra = 128 * (wave >> 2) + 16 * (wave & 3) + (lane >> 3), rb = 64 * (wave >> 1) + 16 * (wave & 1) + (lane >> 3);
-    pa00 = 2u * ((unsigned)ra * (unsigned)lda + c0 * 8);
-    pa01 = 2u * ((unsigned)(ra + 8) * (unsigned)lda + c1 * 8);
-    pa10 = 2u * ((unsigned)(ra + 64) * (unsigned)lda + c0 * 8);
-    pa11 = 2u * ((unsigned)(ra + 72) * (unsigned)lda + c1 * 8);
-    pb00 = 2u * ((unsigned)rb * (unsigned)ldb + c0 * 8);
-    pb01 = 2u * ((unsigned)(rb + 8) * (unsigned)ldb + c1 * 8);
-    pb10 = 2u * ((unsigned)(rb + 32) * (unsigned)ldb + c0 * 8);
-    pb11 = 2u * ((unsigned)(rb + 40) * (unsigned)ldb + c1 * 8);
-  }
-  const unsigned lane16 = 16u * lane;
-  const unsigned lds_w = (unsigned)__builtin_amdgcn_readfirstlane((unsigned)(size_t)(smem + wave * 2048));          // staging base
-  const unsigned lds_b = (unsigned)__builtin_amdgcn_readfirstlane((unsigned)(size_t)(smem + P8_SMEM + wave * 1024)); // bias areas
-  char* const bias_lds = smem + P8_SMEM + wave * 1024;          // + parity * 8192; + 16384: dummy target
-  const bool has_bias = ep.bias != nullptr;
-  if (!has_bias) {                               // no bias: both parities hold zeros for good
-    reinterpret_cast<float4*>(bias_lds)[lane] = make_float4(0.f, 0.f, 0.f, 0.f);
-    reinterpret_cast<float4*>(bias_lds + 8192)[lane] = make_float4(0.f, 0.f, 0.f, 0.f);
-  }
-// stage one slot of buffer buf_ from K-tile (current + REL_): 2 pieces per wave
-#define PP_STAGE(buf_, slot_, REL_)                                                                              \
-  {                                                                                                              \
-    if ((slot_) == P8_AQ0) { PP_DMA(a_cur + (REL_) * 128, pa00, lds_w, ((buf_) * 4 + (slot_)) * P8_SLOT)          \
-                             PP_DMA(a_cur + (REL_) * 128, pa01, lds_w, ((buf_) * 4 + (slot_)) * P8_SLOT + 1024) } \
-    if ((slot_) == P8_AQ1) { PP_DMA(a_cur + (REL_) * 128, pa10, lds_w, ((buf_) * 4 + (slot_)) * P8_SLOT)          \
-                             PP_DMA(a_cur + (REL_) * 128, pa11, lds_w, ((buf_) * 4 + (slot_)) * P8_SLOT + 1024) } \
-    if ((slot_) == P8_BQ0) { PP_DMA(b_cur + (REL_) * 128, pb00, lds_w, ((buf_) * 4 + (slot_)) * P8_SLOT)          \
-                             PP_DMA(b_cur + (REL_) * 128, pb01, lds_w, ((buf_) * 4 + (slot_)) * P8_SLOT + 1024) } \
-    if ((slot_) == P8_BQ1) { PP_DMA(b_cur + (REL_) * 128, pb10, lds_w, ((buf_) * 4 + (slot_)) * P8_SLOT)          \
-                             PP_DMA(b_cur + (REL_) * 128, pb11, lds_w, ((buf_) * 4 + (slot_)) * P8_SLOT + 1024) } \
-  }
-// the whole prologue of a tile (a_cur / b_cur at its K-tile 0): bias row (1 piece; without a bias a harmless read of A into
-// the dummy area, so that the count is always 17 and the parity areas keep their zeros), then K-tiles 0 and 1
-#define PP_PROLOGUE(bias_src_, bias_dst_)                                                                        \
-  {                                                                                                              \
-    PP_DMA(bias_src_, lane16, bias_dst_, 0)                                                                      \
-    PP_STAGE(0, P8_BQ0, 0) PP_STAGE(0, P8_AQ0, 0) PP_STAGE(0, P8_BQ1, 0) PP_STAGE(0, P8_AQ1, 0)                  \
-    PP_STAGE(1, P8_BQ0, 1) PP_STAGE(1, P8_AQ0, 1) PP_STAGE(1, P8_BQ1, 1) PP_STAGE(1, P8_AQ1, 1)                  \
-  }
-
-  const int fr = (((lane & 15) >> 1) & 3) << 1;
-  const int rf0 = (lane & 15) * 128 + (((lane >> 4) ^ fr) << 4);
-  const int rf1 = (lane & 15) * 128 + (((4 + (lane >> 4)) ^ fr) << 4);
-  const char* const a_rd = smem + 64 * wm * 128;
-  const char* const b_rd = smem + 32 * wn * 128;
-  bf16x8 af[4][2], bf0[2][2], bf1[2][2];
-  f32x4 acc[8][4];
-#define PP_READ_A(buf_, slot_)                                                                               \
-  {                                                                                                          \
-    const char* s_ = a_rd + ((buf_) * 4 + (slot_)) * P8_SLOT;                                                \
-    _Pragma("unroll") for (int i = 0; i < 4; ++i) {                                                          \
-      af[i][0] = *reinterpret_cast<const bf16x8*>(s_ + i * 2048 + rf0);                                      \
-      af[i][1] = *reinterpret_cast<const bf16x8*>(s_ + i * 2048 + rf1);                                      \
-    }                                                                                                        \
-  }
-#define PP_READ_B(dst_, buf_, slot_)                                                                         \
-  {                                                                                                          \
-    const char* s_ = b_rd + ((buf_) * 4 + (slot_)) * P8_SLOT;                                                \
-    _Pragma("unroll") for (int j = 0; j < 2; ++j) {                                                          \
-      dst_[j][0] = *reinterpret_cast<const bf16x8*>(s_ + j * 2048 + rf0);                                    \
-      dst_[j][1] = *reinterpret_cast<const bf16x8*>(s_ + j * 2048 + rf1);                                    \
-    }                                                                                                        \
-  }
-#define PP_MFMA(mb_, nb_, bfx_)                                                                              \
-  {                                                                                                          \
-    __builtin_amdgcn_s_setprio(1);                                                                           \
-    _Pragma("unroll") for (int ks = 0; ks < 2; ++ks)                                                         \
-      _Pragma("unroll") for (int i = 0; i < 4; ++i)                                                          \
-        _Pragma("unroll") for (int j = 0; j < 2; ++j)                                                        \
-          acc[(mb_) + i][(nb_) + j] =                                                                        \
-              __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfx_[j][ks], af[i][ks], acc[(mb_) + i][(nb_) + j], 0, 0, 0); \
-    __builtin_amdgcn_s_setprio(0);                                                                           \
-  }
-#define PP_BAR()                                  \
-  {                                               \
-    __builtin_amdgcn_sched_barrier(0);            \
-    __builtin_amdgcn_s_barrier();                 \
-    asm volatile("" ::: "memory");                \
-    __builtin_amdgcn_sched_barrier(0);            \
-  }
-#define PP_LGKM0()                                          \
-  {                                                         \
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      \
-    __builtin_amdgcn_sched_barrier(0);                      \
-  }
-// one K-tile (4 phases) out of buffer d_.  ST_: stage the next contents per the schedule (relative K-tile NEXT_REL_ into
-// buffer next_buf_); STAGE_FIRST_: phase 1/5 stages A_q1 of relative K-tile FIRST_REL_ into buffer first_buf_.
-#define PP_KTILE(d_, ST_, first_buf_, FIRST_REL_, next_buf_, NEXT_REL_, WAIT_, STAGE_FIRST_)                 \
-  {                                                                                                          \
-    PP_READ_B(bf0, d_, P8_BQ0)                                                                               \
-    __builtin_amdgcn_sched_barrier(0);                                                                       \
-    PP_READ_A(d_, P8_AQ0)                                                                                    \
-    __builtin_amdgcn_sched_barrier(0);                                                                       \
-    if (STAGE_FIRST_) PP_STAGE(first_buf_, P8_AQ1, FIRST_REL_)                                               \
-    asm volatile("s_waitcnt lgkmcnt(8)" ::: "memory");                                                       \
-    PP_BAR()                                                                                                 \
-    PP_LGKM0()                                                                                               \
-    PP_MFMA(0, 0, bf0)                                                                                       \
-    PP_BAR()                                                                                                 \
-    PP_READ_B(bf1, d_, P8_BQ1)                                                                               \
-    __builtin_amdgcn_sched_barrier(0);                                                                       \
-    if (ST_) PP_STAGE(next_buf_, P8_BQ0, NEXT_REL_)                                                          \
-    PP_BAR()                                                                                                 \
-    PP_LGKM0()                                                                                               \
-    PP_MFMA(0, 2, bf1)                                                                                       \
-    PP_BAR()                                                                                                 \
-    PP_READ_A(d_, P8_AQ1)                                                                                    \
-    __builtin_amdgcn_sched_barrier(0);                                                                       \
-    if (ST_) PP_STAGE(next_buf_, P8_AQ0, NEXT_REL_)                                                          \
-    PP_BAR()                                                                                                 \
-    PP_LGKM0()                                                                                               \
-    PP_MFMA(4, 2, bf1)                                                                                       \
-    PP_BAR()                                                                                                 \
-    if (ST_) PP_STAGE(next_buf_, P8_BQ1, NEXT_REL_)                                                          \
-    WAIT_;                                                                                                   \
-    PP_BAR()                                                                                                 \
-    PP_MFMA(4, 0, bf0)                                                                                       \
-    PP_BAR()                                                                                                 \
-  }
-#define PP_WAIT(n_) asm volatile("s_waitcnt vmcnt(" #n_ ")" ::: "memory")
-// wave-uniform 64-bit pointer -> SGPR pair
-// (readfirstlane returns a SIGNED int: each half is cast to unsigned before widening, or a low word with bit 31 set
-// sign-extends over the high word -- that produced a wild address in the first run of this kernel)
-#define PP_UNIFORM64(p_)                                                                                                      \
-  (((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((unsigned)((unsigned long long)(size_t)(p_) >> 32)) << 32) | \
-   (unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((unsigned)(size_t)(p_)))
-
-  int item = blockIdx.x;                         // < n_items (grid <= n_items)
-  int t = xcd_remap(item, n_items);
-  int m0 = (t / tiles_n) * BM2, n0 = (t % tiles_n) * BN2;
-  unsigned long long a_cur = PP_UNIFORM64(A + (long)m0 * lda), b_cur = PP_UNIFORM64(B + (long)n0 * ldb);
-  int par = 0;
-  bool first = true;
-  __syncthreads();                               // the zero-filled bias areas (no-bias case)
-  {
-    const unsigned long long bsrc = has_bias ? PP_UNIFORM64(ep.bias + n0) : a_cur;
-    const unsigned bdst = has_bias ? lds_b : lds_b + 16384;
-    PP_PROLOGUE(bsrc, bdst)
-  }
-  for (;;) {
-    // ---- tile start: K-tile 0 (and, older, the bias row) landed; the 8 pieces of K-tile 1 and, after the first tile,
-    // the previous tile's >= 16 stores may still be outstanding
-    if (first) { PP_WAIT(8); } else { PP_WAIT(24); }
-    PP_BAR()
-    if (__builtin_amdgcn_readfirstlane(wave) >= 4) PP_BAR()      // waves 4-7 run one barrier behind
-#pragma unroll
-    for (int i = 0; i < 8; ++i)
-#pragma unroll
-      for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    // first iteration: K-tile 1 is already staged (nothing in phase 1); its phase-4 wait steps over the stores too
-    if (first) {
-      PP_KTILE(0, 1, 0, 0, 0, 2, PP_WAIT(6), 0)
-    } else {
-      PP_KTILE(0, 1, 0, 0, 0, 2, PP_WAIT(22), 0)
-    }
-    PP_KTILE(1, 1, 0, 2, 1, 3, PP_WAIT(6), 1)
-    a_cur += 256;                                                // two K-tiles of 64 bf16
-    b_cur += 256;
-    for (int kt = 2; kt < nk - 2; kt += 2) {
-      PP_KTILE(0, 1, 1, 1, 0, 2, PP_WAIT(6), 1)
-      PP_KTILE(1, 1, 0, 2, 1, 3, PP_WAIT(6), 1)
-      a_cur += 256;
-      b_cur += 256;
-    }
-    PP_KTILE(0, 0, 1, 1, 0, 0, PP_WAIT(0), 1)                    // peeled last iteration: only A_q1 of K-tile nk-1 is staged
-    PP_KTILE(1, 0, 0, 0, 0, 0, , 0)
-    if (__builtin_amdgcn_readfirstlane(wave) < 4) PP_BAR()       // groups re-aligned; every wave is done reading LDS
-    // ---- next tile's prologue BEFORE this tile's stores
-    const int nitem = item + gridDim.x;
-    const bool has_next = nitem < n_items;
-    const int m0c = m0, n0c = n0;
-    if (has_next) {
-      t = xcd_remap(nitem, n_items);
-      m0 = (t / tiles_n) * BM2;
-      n0 = (t % tiles_n) * BN2;
-      a_cur = PP_UNIFORM64(A + (long)m0 * lda);
-      b_cur = PP_UNIFORM64(B + (long)n0 * ldb);
-      const unsigned long long bsrc = has_bias ? PP_UNIFORM64(ep.bias + n0) : a_cur;
-      const unsigned bdst = has_bias ? lds_b + (par ^ 1) * 8192 : lds_b + 16384;
-      PP_PROLOGUE(bsrc, bdst)
-    }
-    // ---- epilogue (bias from LDS: staged with this tile's prologue, waited for at its start)
-    const float* bl = reinterpret_cast<const float*>(bias_lds + par * 8192) + 128 * (wn >> 1);
-#pragma unroll
-    for (int h = 0; h < 2; ++h)
-      nt_epilogue<EPI, CT>(*reinterpret_cast<f32x4(*)[4][4]>(&acc[4 * h]), C, ldc, M, N, m0c + 128 * wm, n0c + 128 * (wn >> 1), h,
-                           wn & 1, lane, ep, bl);
-    if (!has_next) break;
-    item = nitem;
-    par ^= 1;
-    first = false;
-  }
-#undef PP_UNIFORM64
-#undef PP_WAIT
-#undef PP_KTILE
-#undef PP_LGKM0
-#undef PP_BAR
-#undef PP_MFMA
-#undef PP_READ_A
-#undef PP_READ_B
-#undef PP_PROLOGUE
-#undef PP_STAGE
 }
 
 __device__ __forceinline__ void tn_store(f32x4 (&acc)[4][4], float* __restrict__ Cs, long ldc, int M, int N, int m0, int n0,
@@ -1851,7 +1428,7 @@ struct TnSeg {
   int tiles;
   int a[6], b[6];
 };
-template <int S, bool SEG = false, bool BUFDMA = true>
+template <int S, bool SEG = false>
 __global__ __launch_bounds__(512, 2) void gemm_tn_ring_kernel(const bf16_t* __restrict__ A, int lda,
                                                               const bf16_t* __restrict__ B, int ldb, float* __restrict__ C,
                                                               long ldc, long slab_stride, int M, int N, int Kc, int tiles_n,
@@ -1896,15 +1473,8 @@ __global__ __launch_bounds__(512, 2) void gemm_tn_ring_kernel(const bf16_t* __re
     char* lb_ = la_ + 16384;                                                           \
     const unsigned ao_ = 2u * (unsigned)(SEG ? seg_ao : (kt0 + (kt_)) * astep);         \
     const unsigned bo_ = 2u * (unsigned)(SEG ? seg_bo : (kt0 + (kt_)) * bstep);         \
-    if constexpr (BUFDMA) {                                                            \
-      bufdma16_hidden(rsA, pa[0], ao_, la_);   bufdma16_hidden(rsA, pa[1], ao_, la_ + 1024);   \
-      bufdma16_hidden(rsB, pb[0], bo_, lb_);   bufdma16_hidden(rsB, pb[1], bo_, lb_ + 1024);   \
-    } else {                                     /* round-2 form: 64-bit lane addresses (A/B: TN force 2565) */ \
-      const char* ga_ = reinterpret_cast<const char*>(A) + ao_;                        \
-      const char* gb_ = reinterpret_cast<const char*>(B) + bo_;                        \
-      glds16_hidden(ga_ + pa[0], la_);   glds16_hidden(ga_ + pa[1], la_ + 1024);       \
-      glds16_hidden(gb_ + pb[0], lb_);   glds16_hidden(gb_ + pb[1], lb_ + 1024);       \
-    }                                                                                  \
+    bufdma16_hidden(rsA, pa[0], ao_, la_);   bufdma16_hidden(rsA, pa[1], ao_, la_ + 1024);     \
+    bufdma16_hidden(rsB, pb[0], bo_, lb_);   bufdma16_hidden(rsB, pb[1], bo_, lb_ + 1024);     \
     if constexpr (SEG) {                                                               \
       seg_ao += astep;                                                                 \
       seg_bo += bstep;                                                                 \
@@ -2143,13 +1713,28 @@ inline int nt_full_tiles(int tiles) {
   return (tiles >= NT_CUS && tail > 0 && 2 * tail <= NT_CUS) ? tiles - tail : tiles;
 }
 
+// Optional features of the 8-phase kernel that the automatic dispatch switches on (bit 1: column bands);
+// mv_gemm_force_variant(3000 | 3002) overrides it for in-process A/B runs (tools/ab_step.py, tools/bench_gemm.py).
+// Round 4 (profiles/r04_step_ab.txt): bands on = 35.54 vs 35.63 ms in the step (pairwise alternation; per shape the qkv product
+// gains 0...+4 % depending on which arm runs first).  A second feature measured and REMOVED: touching the operand lines two K-tiles
+// ahead of their DMA (one lane per line, +1 entry per K-tile in the vmcnt queue): bit-identical, -11...-17 % per shape, 36.95 vs
+// 34.94 ms in the step -- the touches take the same request path the DMA is limited by.
+constexpr int NT_FEATURES_DEFAULT = 2;
+// Column-band width (in 256-column tiles) for a product with tiles_n tile columns and contraction K, or 0.  MV_NT_BAND=W forces W
+// wherever it divides tiles_n (shape scans).  Measured per shape (round 3, finding 37; round 4): only the qkv projection
+// (9 tile columns, K = 768) gains; N = 3072 loses with every width.
+inline int nt_band_width(int tiles_n, int K, bool whole_tiles_only) {
+  static const int forced = getenv("MV_NT_BAND") ? atoi(getenv("MV_NT_BAND")) : 0;
+  if (forced > 0) return tiles_n % forced == 0 && tiles_n > forced ? forced : 0;
+  (void)whole_tiles_only;
+  return (tiles_n == 9 && K <= 1024) ? 3 : 0;
+}
+
 template <int EPI, typename CT>
 int launch_nt(const void* A, int lda, const void* B, int ldb, void* C, int ldc, int M, int N, int K, EpiArgs ep,
               hipStream_t s) {
   const int attr = MV_ONCE_PER_DEVICE(set_smem(gemm_nt_kernel<EPI, CT>) | set_smem(gemm_nt_glds_kernel<EPI, CT>) |
-                          set_smem(gemm_nt_glds_kernel<EPI, CT, false>) |
-                          (hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_nt_glds256_kernel<EPI, CT>),
-                                               hipFuncAttributeMaxDynamicSharedMemorySize, SMEM2_BYTES) == hipSuccess ? 0 : -1));
+                          set_smem(gemm_nt_glds_kernel<EPI, CT, false>));
   if (attr != 0) return MV_ERR_LAUNCH;
   const int tiles_m = mv_cdiv(M, BM), tiles_n = mv_cdiv(N, BN);
   const int t2m = mv_cdiv(M, BM2), t2n = mv_cdiv(N, BN2);
@@ -2157,15 +1742,17 @@ int launch_nt(const void* A, int lda, const void* B, int ldb, void* C, int ldc, 
   // grid fills the chip for >= 4 rounds (N >= 1536) or K is long enough to amortise its fill/drain (K >= 2048);
   // otherwise two 128x128 workgroups per CU overlap each other's epilogues better.  Where the ring kernel would be
   // picked and K % 128 == 0, the 8-phase kernel replaces it (+6-14 % on every ViT-B shape: whole 128-byte lines per
-  // DMA row, 16-MFMA phases).  MV_GEMM_TILE = 128 | 256 | 2564 (ring) | 2568 (8-phase) forces a variant (tuning, tests).
+  // DMA row, 16-MFMA phases).  MV_GEMM_TILE = 128 | 2564 (ring) | 2568 (8-phase) forces a variant (tuning, tests).
   int force = g_force_nt.load(std::memory_order_relaxed);
-  if (force == 2567) {                                   // automatic dispatch, aux prefetch of the 8-phase epilogue off (A/B)
+  // 3000 / 3002: automatic dispatch with the column bands of the 8-phase kernel off / on (A/B in one process, tools/ab_step.py);
+  // 3100 / 3102: the same with the 8-phase kernel forced wherever it is legal, as 2568 (unit tests on small shapes)
+  int feat = NT_FEATURES_DEFAULT;
+  if (force == 3000 || force == 3002) {
+    feat = force - 3000;
     force = 0;
-    ep.no_prefetch = 1;
-  }
-  if (force == 2565) {                                   // automatic dispatch, global_load_lds staging in the 8-phase kernel (A/B)
-    force = 0;
-    ep.glds_dma = 1;
+  } else if (force == 3100 || force == 3102) {
+    feat = force - 3100;
+    force = 2568;
   }
   const bool ring_ok = K > 0 && K % BKR == 0;
   const bool ring_pick = ring_ok && ((long)t2m * t2n >= 1024 || (K >= 2048 && (long)t2m * t2n >= 256));
@@ -2173,39 +1760,12 @@ int launch_nt(const void* A, int lda, const void* B, int ldb, void* C, int ldc, 
   // 8-phase kernel: wherever the ring would be picked, and from three quarters of one round of the chip on (half-item tail from
   // one full round; 225 tiles -- the qkv projection at batch 32 -- run 780 TFLOP/s here against 657 as 900 128-tiles)
   const bool p8_pick = p8_ok && (ring_pick || (long)t2m * t2n >= NT_CUS * 3 / 4);
-  if (((force == 2568 || force == 25680 || force == 2569) && p8_ok) || (force == 0 && p8_pick)) {
+  if (((force == 2568 || force == 25680) && p8_ok) || (force == 0 && p8_pick)) {
     const int a8 = MV_ONCE_PER_DEVICE(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_nt_8phase_kernel<EPI, CT>),
                                               hipFuncAttributeMaxDynamicSharedMemorySize, P8_SMEM) == hipSuccess ? 0 : -1);
     if (a8) return MV_ERR_LAUNCH;
     const int tiles = t2m * t2n, full = force == 25680 ? tiles : nt_full_tiles(tiles);     // 25680: whole tiles only (A/B)
-    // persistent variant (stores drain under the next tile): interior whole tiles, bias-only epilogues; 2569 forces it
-    constexpr bool pp_epi = EPI == MV_EPI_NONE || EPI == MV_EPI_GELU || EPI == MV_EPI_GELU_GRAD;
-    const bool pp_ok = pp_epi && M % BM2 == 0 && N % BN2 == 0 && K >= 256 && (long)BM2 * lda < (1L << 30) &&
-                       (long)BN2 * ldb < (1L << 30) && (ldc % 8) == 0 && (ep.ld_out2 % 8) == 0 &&
-                       (reinterpret_cast<uintptr_t>(ep.bias) & 15) == 0 && ep.alpha == 1.0f;
-    if (pp_ok && (force == PP_AUTO_FORCE || force == 2569)) {
-      if constexpr (pp_epi) {
-        const int ap = MV_ONCE_PER_DEVICE(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_nt_8phase_persistent_kernel<EPI, CT>),
-                                                  hipFuncAttributeMaxDynamicSharedMemorySize, PP_SMEM) == hipSuccess ? 0 : -1);
-        if (ap) return MV_ERR_LAUNCH;
-        gemm_nt_8phase_persistent_kernel<EPI, CT><<<full < NT_CUS ? full : NT_CUS, 512, PP_SMEM, s>>>(
-            (const bf16_t*)A, lda, (const bf16_t*)B, ldb, (CT*)C, ldc, M, N, K, t2n, ep, full);
-        if (tiles > full)                       // the tail round's half items: the one-item-per-workgroup kernel
-          gemm_nt_8phase_kernel<EPI, CT><<<2 * (tiles - full), 512, P8_SMEM, s>>>(
-              (const bf16_t*)A, lda, (const bf16_t*)B, ldb, (CT*)C, ldc, M, N, K, t2n, ep, full, full);
-        MV_CHECK_LAUNCH();
-        return MV_OK;
-      }
-    }
-    if (ep.glds_dma) {
-      const int ab = MV_ONCE_PER_DEVICE(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_nt_8phase_kernel<EPI, CT, NT_BF16, false, false>),
-                                                hipFuncAttributeMaxDynamicSharedMemorySize, P8_SMEM) == hipSuccess ? 0 : -1);
-      if (ab) return MV_ERR_LAUNCH;
-      gemm_nt_8phase_kernel<EPI, CT, NT_BF16, false, false><<<full + 2 * (tiles - full), 512, P8_SMEM, s>>>(
-          (const bf16_t*)A, lda, (const bf16_t*)B, ldb, (CT*)C, ldc, M, N, K, t2n, ep, full, 0);
-      MV_CHECK_LAUNCH();
-      return MV_OK;
-    }
+    if (feat & 2) ep.band = nt_band_width(t2n, K, full == tiles);
     gemm_nt_8phase_kernel<EPI, CT><<<full + 2 * (tiles - full), 512, P8_SMEM, s>>>(
         (const bf16_t*)A, lda, (const bf16_t*)B, ldb, (CT*)C, ldc, M, N, K, t2n, ep, full, 0);
     MV_CHECK_LAUNCH();
@@ -2217,10 +1777,7 @@ int launch_nt(const void* A, int lda, const void* B, int ldb, void* C, int ldc, 
     if (a4) return MV_ERR_LAUNCH;
     gemm_nt_ring_kernel<EPI, CT, 4><<<t2m * t2n, 512, 4 * RSTAGE_BYTES, s>>>((const bf16_t*)A, lda, (const bf16_t*)B, ldb,
                                                                               (CT*)C, ldc, M, N, K, t2n, ep);
-  } else if (force == 256 && K > 0 && K % BK == 0)
-    gemm_nt_glds256_kernel<EPI, CT><<<t2m * t2n, 512, SMEM2_BYTES, s>>>((const bf16_t*)A, lda, (const bf16_t*)B, ldb,
-                                                                         (CT*)C, ldc, M, N, K, t2n, ep);
-  else if (K > 0 && K % BK == 0) {
+  } else if (K > 0 && K % BK == 0) {
     if ((long)M * lda < (1L << 31) && (long)N * ldb < (1L << 31))       // 32-bit byte offsets of the buffer-descriptor DMA
       gemm_nt_glds_kernel<EPI, CT><<<tiles_m * tiles_n, 256, SMEM_BYTES, s>>>((const bf16_t*)A, lda, (const bf16_t*)B, ldb,
                                                                                (CT*)C, ldc, M, N, K, tiles_n, ep);
@@ -2453,9 +2010,9 @@ extern "C" int mv_gemm_nt_i8(const void* A, int lda, const void* B, int ldb, voi
 }
 
 extern "C" int mv_gemm_force_variant(int nt_variant, int tn_variant) {
-  const bool nt_ok = nt_variant == 0 || nt_variant == 128 || nt_variant == 256 || nt_variant == 2564 ||
-                     nt_variant == 2568 || nt_variant == 25680 || nt_variant == 2569 || nt_variant == 2567 || nt_variant == 2565;
-  const bool tn_ok = tn_variant == 0 || tn_variant == 128 || tn_variant == 256 || tn_variant == 2565;
+  const bool nt_ok = nt_variant == 0 || nt_variant == 128 || nt_variant == 2564 || nt_variant == 2568 || nt_variant == 25680 ||
+                     nt_variant == 3000 || nt_variant == 3002 || nt_variant == 3100 || nt_variant == 3102;
+  const bool tn_ok = tn_variant == 0 || tn_variant == 128 || tn_variant == 256;
   MV_REQUIRE(nt_ok && tn_ok, MV_ERR_UNSUPPORTED);
   g_force_nt.store(nt_variant, std::memory_order_relaxed);
   g_force_tn.store(tn_variant, std::memory_order_relaxed);
@@ -2538,14 +2095,7 @@ extern "C" int mv_gemm_tn_bf16(const void* A, int lda, const void* B, int ldb, f
   if (ring) {
     const int a4 = MV_ONCE_PER_DEVICE(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_tn_ring_kernel<4>),
                                               hipFuncAttributeMaxDynamicSharedMemorySize, 4 * RSTAGE_BYTES) == hipSuccess ? 0 : -1);
-    const int a4g = MV_ONCE_PER_DEVICE(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_tn_ring_kernel<4, false, false>),
-                                               hipFuncAttributeMaxDynamicSharedMemorySize, 4 * RSTAGE_BYTES) == hipSuccess ? 0 : -1);
-    if (a4 || a4g) return MV_ERR_LAUNCH;
-    if (g_force_tn.load(std::memory_order_relaxed) == 2565)
-      gemm_tn_ring_kernel<4, false, false><<<tiles_mn * pl.splits, 512, 4 * RSTAGE_BYTES, s>>>(
-          (const bf16_t*)A, lda, (const bf16_t*)B, ldb, direct ? C : workspace, direct ? (long)ldc : (long)N,
-          direct ? 0 : slab_stride, M, N, Kc, pl.tiles_n, tiles_mn, pl.steps_per_split, TnSeg{});
-    else
+    if (a4) return MV_ERR_LAUNCH;
     gemm_tn_ring_kernel<4><<<tiles_mn * pl.splits, 512, 4 * RSTAGE_BYTES, s>>>(
         (const bf16_t*)A, lda, (const bf16_t*)B, ldb, direct ? C : workspace, direct ? (long)ldc : (long)N,
         direct ? 0 : slab_stride, M, N, Kc, pl.tiles_n, tiles_mn, pl.steps_per_split, TnSeg{});

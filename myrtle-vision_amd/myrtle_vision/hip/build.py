@@ -60,7 +60,9 @@ def _link_command(hipcc, objs):
 
 def _digest():
     h = hashlib.sha256()
-    for f in sorted(os.listdir(CSRC)) + ["../../include/myrtle_vision_hip.h"]:
+    # every file of csrc/ itself (csrc/diag/ holds retired kernels kept as source for the record: not built, not digested)
+    files = [f for f in sorted(os.listdir(CSRC)) if os.path.isfile(os.path.join(CSRC, f))]
+    for f in files + ["../../include/myrtle_vision_hip.h"]:
         with open(os.path.join(CSRC, f), "rb") as fh:
             h.update(f.encode() + b"\0" + fh.read())
     h.update((" ".join(FLAGS) + repr(sorted(EXTRA_FLAGS.items()))).encode())

@@ -2,7 +2,8 @@
 """A/B of GEMM kernel variants INSIDE the ViT-B/16 training step, one process, one device: the variants take turns in
 blocks of STEPS steps for ROUNDS rounds (cdna guide rule 24); prints mean, std and min of ms/step per variant.
 
-    NT_VARIANTS=0,2569 ROUNDS=10 STEPS=10 python tools/ab_step.py
+    NT_VARIANTS=3000,3002 ROUNDS=10 STEPS=10 python tools/ab_step.py      # column bands off / on (compare PAIRS only: with more
+                                                                           # than two arms each one always follows the same predecessor)
     GELU_BITS=8,16 ROUNDS=8 python tools/ab_step.py        # instead: width of the gelu' the MLP block keeps (functional.GELU_GRAD_BITS)
 """
 import os
@@ -22,10 +23,10 @@ from myrtle_vision.utils.utils import seed_everything  # noqa: E402
 import myrtle_vision.hip.functional as _F  # noqa: E402
 
 GELU_AB = "GELU_BITS" in os.environ
-TN_AB = "TN_VARIANTS" in os.environ              # TN_VARIANTS=2564,2565: dW ring kernel with four / five stages
+TN_AB = "TN_VARIANTS" in os.environ              # TN_VARIANTS=128,256: dW kernels forced
 ATTN_AB = "ATTN_BWD_VARIANTS" in os.environ      # ATTN_BWD_VARIANTS=4,5: attention backward with four / two waves per workgroup
 VARIANTS = [int(v) for v in os.environ.get("GELU_BITS" if GELU_AB else "TN_VARIANTS" if TN_AB else "ATTN_BWD_VARIANTS" if ATTN_AB
-                                           else "NT_VARIANTS", "0,2569").split(",")]
+                                           else "NT_VARIANTS", "3000,3002").split(",")]
 
 
 def select(v):
