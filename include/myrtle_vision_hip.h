@@ -165,6 +165,11 @@ int mv_patchify(const float* img, void* out, int out_dtype, int B, int C, int H,
 int mv_embed_cls(const float* cls, const float* pos, float* x, int B, int T, int D, mv_stream_t stream);
 /* backward of the embedding assembly: dpos[t, :] (+)= sum_b dx[b, t, :];  dcls[:] (+)= sum_b dx[b, 0, :] */
 int mv_embed_bwd(const float* dx, float* dpos, float* dcls, int accumulate, int B, int T, int D, mv_stream_t stream);
+/* mv_embed_bwd and mv_gather_patch_rows in one pass over dx (vit.py:271-311 backward): dpos / dcls as mv_embed_bwd (either may be NULL; written, not
+ * accumulated) and dy = rows 1..T-1 of every image in dy_dtype (NULL: skipped) -- the dY operand of the patch GEMM's dW product.
+ * D % 4 == 0, pointers 16-byte aligned. */
+int mv_embed_bwd_gather(const float* dx, void* dy, int dy_dtype, float* dpos, float* dcls, int B, int T, int D,
+                        mv_stream_t stream);
 /* gather rows 1..T-1 of every image: dst[b*(T-1)+t-1, :] = (dtype) src[b, t, :]  (dY for the patch GEMM) */
 int mv_gather_patch_rows(const float* src, void* dst, int dst_dtype, int B, int T, int D, mv_stream_t stream);
 

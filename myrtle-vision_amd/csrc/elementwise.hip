@@ -807,6 +807,66 @@ extern "C" int mv_embed_bwd(const float* dx, float* dpos, float* dcls, int accum
   return MV_OK;
 }
 
+// Backward of the embedding assembly in ONE pass over dx [B, T, D] (round 4; replaces embed_bwd_kernel + gather_patch_rows_kernel:
+// 103 + 36 us per ViT-B step, the first of them a 256-deep serial load chain per thread): block (t, 128-column chunk), 32 threads
+// x float4 across the chunk, 8 thread rows striding the batch; every dx element is read once, leaves as dy (rows 1..T-1 of each
+// image, the dY operand of the patch GEMM's dW product, in the activation dtype) and enters the batch sums dpos[t] (and dcls for
+// t = 0); the 8 partial sums meet in LDS in a fixed order (deterministic).
+template <typename DT>
+__global__ __launch_bounds__(256) void embed_bwd_gather_kernel(const float* __restrict__ dx, DT* __restrict__ dy,
+                                                               float* __restrict__ dpos, float* __restrict__ dcls, int B,
+                                                               int T, int D) {
+  __shared__ float4 red[8][32];
+  const int chunks = (D + 127) / 128;
+  const int t = blockIdx.x / chunks, ch = blockIdx.x - t * chunks;
+  const int cx = threadIdx.x & 31, ry = threadIdx.x >> 5;
+  const int c = ch * 128 + cx * 4;
+  float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (c < D) {
+#pragma unroll 4
+    for (int b = ry; b < B; b += 8) {
+      const float4 v = *reinterpret_cast<const float4*>(dx + ((long)b * T + t) * D + c);
+      acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
+      if (t > 0 && dy) {
+        DT* o = dy + ((long)b * (T - 1) + t - 1) * D + c;
+        if constexpr (sizeof(DT) == 4) {
+          *reinterpret_cast<float4*>(o) = v;
+        } else {
+          const bf16x4 w = {(bf16_t)v.x, (bf16_t)v.y, (bf16_t)v.z, (bf16_t)v.w};
+          *reinterpret_cast<bf16x4*>(o) = w;
+        }
+      }
+    }
+  }
+  red[ry][cx] = acc;
+  __syncthreads();
+  if (ry == 0 && c < D) {
+    float4 s = red[0][cx];
+#pragma unroll
+    for (int r = 1; r < 8; ++r) {
+      const float4 u = red[r][cx];
+      s.x += u.x; s.y += u.y; s.z += u.z; s.w += u.w;
+    }
+    if (dpos) *reinterpret_cast<float4*>(dpos + (long)t * D + c) = s;
+    if (dcls && t == 0) *reinterpret_cast<float4*>(dcls + c) = s;
+  }
+}
+
+extern "C" int mv_embed_bwd_gather(const float* dx, void* dy, int dy_dtype, float* dpos, float* dcls, int B, int T, int D,
+                                   mv_stream_t stream) {
+  MV_REQUIRE(B >= 0 && T > 0 && D > 0 && D % 4 == 0, MV_ERR_SHAPE);
+  MV_REQUIRE(dy_dtype == MV_F32 || dy_dtype == MV_BF16, MV_ERR_UNSUPPORTED);
+  MV_REQUIRE(mv_aligned16(dx) && mv_aligned16(dy) && mv_aligned16(dpos) && mv_aligned16(dcls), MV_ERR_ALIGN);
+  if (B == 0) return MV_OK;
+  const int grid = T * ((D + 127) / 128);
+  if (dy_dtype == MV_F32)
+    embed_bwd_gather_kernel<float><<<grid, 256, 0, S_>>>(dx, (float*)dy, dpos, dcls, B, T, D);
+  else
+    embed_bwd_gather_kernel<bf16_t><<<grid, 256, 0, S_>>>(dx, (bf16_t*)dy, dpos, dcls, B, T, D);
+  MV_CHECK_LAUNCH();
+  return MV_OK;
+}
+
 extern "C" int mv_gather_patch_rows(const float* src, void* dst, int dst_dtype, int B, int T, int D,
                                     mv_stream_t stream) {
   MV_REQUIRE(B >= 0 && T > 1 && D > 0 && D % 4 == 0, MV_ERR_SHAPE);

@@ -1760,11 +1760,12 @@ int launch_nt(const void* A, int lda, const void* B, int ldb, void* C, int ldc, 
   // 8-phase kernel: wherever the ring would be picked, and from three quarters of one round of the chip on (half-item tail from
   // one full round; 225 tiles -- the qkv projection at batch 32 -- run 780 TFLOP/s here against 657 as 900 128-tiles)
   const bool p8_pick = p8_ok && (ring_pick || (long)t2m * t2n >= NT_CUS * 3 / 4);
-  if (((force == 2568 || force == 25680) && p8_ok) || (force == 0 && p8_pick)) {
+  if (((force == 2568 || force == 25680 || force == 25681) && p8_ok) || (force == 0 && p8_pick)) {
     const int a8 = MV_ONCE_PER_DEVICE(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_nt_8phase_kernel<EPI, CT>),
                                               hipFuncAttributeMaxDynamicSharedMemorySize, P8_SMEM) == hipSuccess ? 0 : -1);
     if (a8) return MV_ERR_LAUNCH;
-    const int tiles = t2m * t2n, full = force == 25680 ? tiles : nt_full_tiles(tiles);     // 25680: whole tiles only (A/B)
+    // 25680: whole tiles only, 25681: half items only (A/B)
+    const int tiles = t2m * t2n, full = force == 25680 ? tiles : force == 25681 ? 0 : nt_full_tiles(tiles);
     if (feat & 2) ep.band = nt_band_width(t2n, K, full == tiles);
     gemm_nt_8phase_kernel<EPI, CT><<<full + 2 * (tiles - full), 512, P8_SMEM, s>>>(
         (const bf16_t*)A, lda, (const bf16_t*)B, ldb, (CT*)C, ldc, M, N, K, t2n, ep, full, 0);
@@ -2010,7 +2011,7 @@ extern "C" int mv_gemm_nt_i8(const void* A, int lda, const void* B, int ldb, voi
 }
 
 extern "C" int mv_gemm_force_variant(int nt_variant, int tn_variant) {
-  const bool nt_ok = nt_variant == 0 || nt_variant == 128 || nt_variant == 2564 || nt_variant == 2568 || nt_variant == 25680 ||
+  const bool nt_ok = nt_variant == 0 || nt_variant == 128 || nt_variant == 2564 || nt_variant == 2568 || nt_variant == 25680 || nt_variant == 25681 ||
                      nt_variant == 3000 || nt_variant == 3002 || nt_variant == 3100 || nt_variant == 3102;
   const bool tn_ok = tn_variant == 0 || tn_variant == 128 || tn_variant == 256;
   MV_REQUIRE(nt_ok && tn_ok, MV_ERR_UNSUPPORTED);

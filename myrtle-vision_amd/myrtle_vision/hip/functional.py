@@ -442,8 +442,7 @@ class _PatchEmbed(Function):
         B, T, D, pd, npatch = ctx.dims
         dx = _c(dx.float())
         weight, bias, cls_token, pos = ctx.params
-        dpos, dcls = ops.embed_bwd(dx, B, T, D, pos=pos, cls_token=cls_token)
-        dy = ops.gather_patch_rows(dx, B, T, D, patches.dtype)
+        dpos, dcls, dy = ops.embed_bwd_gather(dx, B, T, D, patches.dtype, pos=pos, cls_token=cls_token)   # one pass over dx
         dw, db = ops.linear_dw(dy, patches, B * npatch, D, pd, weight=weight, bias=bias)
         return None, dw, db, dcls.view(ctx.cls_shape), dpos.view(ctx.pos_shape), None, None
 

@@ -55,6 +55,7 @@ SIGNATURES = {
     "mv_embed_cls": ("ppp" "iii" "p", _I),
     "mv_embed_bwd": ("ppp" "i" "iii" "p", _I),
     "mv_gather_patch_rows": ("ppi" "iii" "p", _I),
+    "mv_embed_bwd_gather": ("ppi" "pp" "iii" "p", _I),
     "mv_cast": ("pipi" "l" "p", _I),
     "mv_split3_bf16": ("plpll" "lii" "p", _I),
     "mv_split3_ex_workspace_bytes": ("li", _Z),

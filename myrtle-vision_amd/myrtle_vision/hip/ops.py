@@ -837,6 +837,16 @@ def embed_bwd(dx, B, T, D, pos=None, cls_token=None):
     return dpos, dcls
 
 
+def embed_bwd_gather(dx, B, T, D, out_dtype, pos=None, cls_token=None):
+    """One pass over dx [B, T, D]: (dpos [T, D], dcls [D], dy [B * (T - 1), D] in ``out_dtype``)."""
+    dpos = grad_out(pos, (T, D), dx.device)
+    dcls = grad_out(cls_token, (D,), dx.device)
+    dy = torch.empty(B * (T - 1), D, dtype=out_dtype, device=dx.device)
+    check(lib().mv_embed_bwd_gather(_p(dx), _p(dy), _DT[out_dtype], _p(dpos), _p(dcls), B, T, D, _s()), "embed_bwd_gather",
+          B=B, T=T, D=D)
+    return dpos, dcls, dy
+
+
 def gather_patch_rows(src, B, T, D, out_dtype):
     out = torch.empty(B * (T - 1), D, dtype=out_dtype, device=src.device)
     check(lib().mv_gather_patch_rows(_p(src), _p(out), _DT[out_dtype], B, T, D, _s()), "gather_patch_rows", B=B, T=T, D=D)

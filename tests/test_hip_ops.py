@@ -706,6 +706,14 @@ def test_embed_helpers(ops):
     assert relerr(dpos, dx.double().sum(0)) < 1e-6 and relerr(dcls, dx[:, 0].double().sum(0)) < 1e-6
     rows = ops.gather_patch_rows(dx.cuda(), B, T, D, torch.bfloat16)
     assert torch.equal(rows.cpu(), bf(dx[:, 1:].reshape(-1, D)))
+    # round 4: the two of them in one pass over dx (what _PatchEmbed.backward runs), batch sizes around the 8-row stride
+    for B2, T2, D2 in [(5, 197, 192), (256, 197, 768), (3, 257, 192), (1, 2, 4), (9, 17, 132)]:
+        dx2 = torch.randn(B2, T2, D2, generator=g(4))
+        for dt in (torch.bfloat16, torch.float32):
+            dpos2, dcls2, dy2 = ops.embed_bwd_gather(dx2.cuda(), B2, T2, D2, dt)
+            want = dx2[:, 1:].reshape(-1, D2)
+            assert torch.equal(dy2.cpu(), bf(want) if dt == torch.bfloat16 else want)
+            assert relerr(dpos2, dx2.double().sum(0)) < 2e-6 and relerr(dcls2, dx2[:, 0].double().sum(0)) < 2e-6
 
 
 def test_cast_weightprep_gelu_add(ops):
