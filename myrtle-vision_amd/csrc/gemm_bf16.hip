@@ -1759,13 +1759,20 @@ int launch_nt(const void* A, int lda, const void* B, int ldb, void* C, int ldc, 
   const bool p8_ok = K >= 128 && K % 128 == 0 && (long)M * lda < (1L << 31) && (long)N * ldb < (1L << 31);
   // 8-phase kernel: wherever the ring would be picked, and from three quarters of one round of the chip on (half-item tail from
   // one full round; 225 tiles -- the qkv projection at batch 32 -- run 780 TFLOP/s here against 657 as 900 128-tiles)
-  const bool p8_pick = p8_ok && (ring_pick || (long)t2m * t2n >= NT_CUS * 3 / 4);
+  // Round 4 (tools/bench_gemm.py M=12608 / M=6304, profiles/r04_gemm_small_batch.txt): from half a round on (150 tiles: the
+  // 768-wide outputs at batch 64) whole tiles beat the 128-tile kernel by 7 % (K = 768) to 19-26 % (K >= 2304); from a quarter of
+  // a round on (75 tiles: the same outputs at batch 32) the tiles run as HALF items only -- 150 workgroups of 128 x 256 instead
+  // of 75 of 256 x 256 or 300 of 128 x 128 -- for +4...15 %.
+  const long t2 = (long)t2m * t2n;
+  const bool p8_halves = p8_ok && !ring_pick && t2 >= NT_CUS / 4 && t2 < NT_CUS / 2;
+  const bool p8_pick = p8_ok && (ring_pick || t2 >= NT_CUS / 4);
   if (((force == 2568 || force == 25680 || force == 25681) && p8_ok) || (force == 0 && p8_pick)) {
     const int a8 = MV_ONCE_PER_DEVICE(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_nt_8phase_kernel<EPI, CT>),
                                               hipFuncAttributeMaxDynamicSharedMemorySize, P8_SMEM) == hipSuccess ? 0 : -1);
     if (a8) return MV_ERR_LAUNCH;
     // 25680: whole tiles only, 25681: half items only (A/B)
-    const int tiles = t2m * t2n, full = force == 25680 ? tiles : force == 25681 ? 0 : nt_full_tiles(tiles);
+    const int tiles = t2m * t2n,
+              full = force == 25680 ? tiles : (force == 25681 || (force == 0 && p8_halves)) ? 0 : nt_full_tiles(tiles);
     if (feat & 2) ep.band = nt_band_width(t2n, K, full == tiles);
     gemm_nt_8phase_kernel<EPI, CT><<<full + 2 * (tiles - full), 512, P8_SMEM, s>>>(
         (const bf16_t*)A, lda, (const bf16_t*)B, ldb, (CT*)C, ldc, M, N, K, t2n, ep, full, 0);
