@@ -238,6 +238,10 @@ def main():
     ap.add_argument("--graph", action="store_true",
                     help="capture the training step in ONE HIP graph and replay it (utils/graph.py): single GPU, static shapes; "
                          "the event timer is off in this mode, so the line carries no per-kernel roofline section")
+    ap.add_argument("--prune-dead-tokens", action="store_true",
+                    help="cls workload: ViT(prune_dead_tokens=True) -- the last block's FeedForward on the cls rows only (what the "
+                         "classification decoder reads); identical logits / loss / gradients, 5.5 GFLOP per image less.  Off in "
+                         "the headline line, which computes every token of every block as the reference does")
     ap.add_argument("--dry-run", action="store_true",
                     help="no compute: only the multi-process launch, rendezvous, barriers and the JSON line (CPU test)")
     ap.add_argument("--dry-run-fail-rank", type=int, default=None,
@@ -291,7 +295,9 @@ def main():
         size = 256 if args.workload == "seg256" else 224
         cfg.update(decoder="segmentation", num_classes=17, image_size=size)
     q_format = "PyTorchINT8" if args.workload == "infer-int8" else (args.q_format or "FP32")
-    vit = ViT(precision=args.precision, q_format=q_format, **cfg).to(dev)
+    if args.prune_dead_tokens and args.workload != "cls":
+        raise SystemExit("--prune-dead-tokens: classification workload only (the segmentation decoder reads every patch token)")
+    vit = ViT(precision=args.precision, q_format=q_format, prune_dead_tokens=args.prune_dead_tokens, **cfg).to(dev)
     arena = ParamArena(vit.named_parameters(), skip=vit.unused_parameter_names())
     opt = AdamW(arena, lr=6.25e-5, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.05)      # vit_base.json
     reducer = GradAllReducer(arena, exchange_dtype=exchange_dtype_from_env(), measure=True)    # MV_DDP_EXCHANGE=bf16: opt-in
@@ -387,6 +393,8 @@ def main():
             "config": {"workload": WORKLOAD[args.workload] + ("" if not args.no_optimizer else " [optimizer step OFF]")
                        + (f" [q_format {args.q_format}]" if args.q_format else "")
                        + (" [attention core: fused bf16 kernel]" if args.int8_bf16_attention else "")
+                       + (" [prune_dead_tokens: last block's FeedForward on the cls rows only; 99.83 GFLOP/img executed]"
+                          if args.prune_dead_tokens else "")
                        + (" [activations saved for backward in bf16; gelu'(h) as an 8-bit code]"
                           if args.precision == "bf16" and args.workload != "infer-int8" and not args.q_format else ""),
                        "step_launch": "one HIP graph replay per step" if args.graph else "eager (one launch per kernel)",
@@ -412,7 +420,8 @@ def main():
                            "env": {k: os.environ[k] for k in ("NCCL_MAX_NCHANNELS", "NCCL_MIN_NCHANNELS", "NCCL_ALGO", "NCCL_PROTO",
                                                                "MV_DDP_EXCHANGE") if k in os.environ}}
         if args.workload == "cls":
-            out["step_mfma_frac"] = round(img_s / world * TRAIN_GFLOP_PER_IMG * 1e9 / (BF16_DENSE_PEAK_TFLOPS * 1e12), 4)
+            gflop = TRAIN_GFLOP_PER_IMG - (5.55 if args.prune_dead_tokens else 0.0)      # FLOPs actually executed per image
+            out["step_mfma_frac"] = round(img_s / world * gflop * 1e9 / (BF16_DENSE_PEAK_TFLOPS * 1e12), 4)
         if timer is not None:
             summ = timer.summary()
             k = summ.get("gemm_nt_bf16")

@@ -113,6 +113,13 @@ class Residual(nn.Module):
             return fused
         return self.res_add.add(self.fn(x), x)
 
+    def _fusable_plain(self):
+        """True when this is a plain Residual(PreNorm(FeedForward)) that nothing observes (no hooks, no quantiser stubs)."""
+        pn = self.fn
+        return (type(pn) is PreNorm and _plain(pn.norm, LayerNorm) and self.res_add.plain() and not self._forward_hooks
+                and not self._forward_pre_hooks and not pn._forward_hooks and not pn._forward_pre_hooks
+                and type(pn.fn) is FeedForward and pn.fn.fusable() and not pn.fn._forward_hooks and not pn.fn._forward_pre_hooks)
+
     def _fused(self, x):
         """One HIP-fused call for Residual(PreNorm(Attention | FeedForward)) when nothing observes the insides."""
         pn = self.fn
@@ -307,11 +314,25 @@ class Transformer(nn.Module):
                 )
             )
 
+    # Extension (off by default; ``ViT(..., prune_dead_tokens=True)`` switches it on for the classification decoder): the decoder
+    # reads x[:, 0] only (reference vit.py:335-342) and the LAST block's FeedForward is a per-token function, so its output for
+    # the 196 patch tokens is dead -- nothing reads it and its gradient is exactly zero.  With the flag the last FeedForward runs
+    # on the cls rows alone ([B, 1, D]): identical logits, loss and parameter gradients (the same sums over fewer, non-zero rows),
+    # 5.5 GFLOP per image (5 %) less work.  Applied only while nothing observes the block (no hooks, plain fusable modules).
+    cls_only_tail = False
+
+    def _tail_prunable(self, blk):
+        ff = blk[1]
+        return (self.cls_only_tail and ff._fusable_plain() and not blk._forward_hooks and not blk._forward_pre_hooks)
+
     def forward(self, x: torch.Tensor):
-        for transformer_block in self.layers:
+        last = len(self.layers) - 1
+        for i, transformer_block in enumerate(self.layers):
             with self.cm_attention:
                 x = transformer_block[0](x)
             with self.cm_feedforward:
+                if i == last and x.dim() == 3 and self._tail_prunable(transformer_block):
+                    x = x[:, :1]                  # the slice's backward scatters the cls gradient into zeros for the other rows
                 x = transformer_block[1](x)
         return x
 
@@ -338,6 +359,7 @@ class ViT(nn.Module):
         profile: bool = False,
         q_format: Optional[Union[str, QFormat]] = None,
         precision: Optional[str] = None,
+        prune_dead_tokens: Optional[bool] = None,
     ):
         super().__init__()
         assert image_size % patch_size == 0, "Image dimensions must be divisible by the patch size."
@@ -376,6 +398,9 @@ class ViT(nn.Module):
         self.dropout = Dropout(emb_dropout)
 
         self.transformer = Transformer(dim, depth, heads, dim_head, mlp_dim, dropout, profile)
+        if prune_dead_tokens is None:
+            prune_dead_tokens = os.environ.get("MYRTLE_VISION_PRUNE_DEAD_TOKENS", "0") == "1"
+        self.transformer.cls_only_tail = bool(prune_dead_tokens) and decoder == "classification"
 
         if decoder == "classification":
             self.decoder = ClassificationDecoder(dim, num_classes)

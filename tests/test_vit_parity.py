@@ -32,11 +32,11 @@ def report(tag, value):
             f.write(f"{tag} {value:.3e}\n")
 
 
-def build(name, precision, q_format=None):
+def build(name, precision, q_format=None, **extra):
     from myrtle_vision.models.vit import ViT
     arrays, meta = load_golden(name)
     kw = dict(meta["kwargs"])
-    vit = ViT(patch_size=16, q_format="FP32", precision=precision, **kw)
+    vit = ViT(patch_size=16, q_format="FP32", precision=precision, **kw, **extra)
     sd = vit.state_dict()
     assert {k: list(v.shape) for k, v in sd.items()} == meta["param_shapes"]
     assert list(sd.keys()) == meta["state_keys"]            # the reference's state-dict ORDER (checkpoint wire format)
@@ -65,9 +65,9 @@ def canonical(name):
     return ".".join(parts)
 
 
-def check_case(name, precision, tol_logits, tol_grad, q_format=None):
+def check_case(name, precision, tol_logits, tol_grad, q_format=None, **extra):
     from myrtle_vision.hip.functional import cross_entropy
-    vit, img, labels, arrays, meta = build(name, precision, q_format)
+    vit, img, labels, arrays, meta = build(name, precision, q_format, **extra)
     vit.train()
     logits = vit(img)
     loss = cross_entropy(logits, labels)
@@ -192,6 +192,40 @@ def test_bf16x3_matches_reference(name):
     LayerNorm, GELU, residual stream as in fp32 mode) at the SAME bar as fp32 mode: logits, loss and gradients to 1e-3 of the
     reference, bit-exact class indices -- the fast arithmetic inside north_star's tolerance."""
     check_case(name, "bf16x3", 1e-3, 1e-3)
+
+
+@pytest.mark.parametrize("name,precision", [("micro_cls", "fp32"), ("micro_cls_256", "fp32"), ("tiny_cls", "fp32"), ("base_cls", "fp32"),
+                                            ("base_cls", "bf16x3"), ("tiny_cls", "bf16"), ("base_cls", "bf16")])
+def test_prune_dead_tokens_changes_nothing(name, precision):
+    """``ViT(prune_dead_tokens=True)`` (extension, off by default): the last block's FeedForward runs on the cls rows only -- the
+    classification decoder reads nothing else (reference vit.py:335-342) and the other rows' gradient is exactly zero.  Same bars
+    against the REFERENCE's logits, loss and every parameter gradient as the unpruned model, and against the unpruned model
+    itself: fp32 modes to fp32 rounding (the two run the last MLP's products over different row counts, i.e. kernels)."""
+    from myrtle_vision.hip.functional import cross_entropy
+    exact = precision in EXACT
+    check_case(name, precision, 1e-3 if exact else BF16_LOGITS, 1e-3 if exact else 3e-2, prune_dead_tokens=True)
+    outs = []
+    for prune in (False, True):
+        vit, img, labels, _, _ = build(name, precision, prune_dead_tokens=prune)
+        assert vit.transformer.cls_only_tail == prune
+        vit.train()
+        logits = vit(img)
+        cross_entropy(logits, labels).backward()
+        outs.append((logits.detach().float(), {k: p.grad.float().clone() for k, p in vit.named_parameters() if p.grad is not None}))
+    (l0, g0), (l1, g1) = outs
+    assert set(g0) == set(g1)
+    tol = 2e-5 if exact else 2e-2
+    assert float((l0 - l1).abs().max() / l0.abs().max()) < tol
+    for k in g0:
+        assert float((g0[k] - g1[k]).norm() / g0[k].norm().clamp_min(1e-30)) < tol, k
+    # a hook on the last block switches the pruning off for that call (something observes the full output)
+    vit, img, _, _, _ = build(name, precision, prune_dead_tokens=True)
+    seen = []
+    h = vit.transformer.layers[-1][1].register_forward_hook(lambda m, a, o: seen.append(tuple(o.shape)))
+    with torch.no_grad():
+        vit(img)
+    h.remove()
+    assert seen and seen[0][1] == img.shape[-1] // 16 * (img.shape[-2] // 16) + 1
 
 
 @pytest.mark.parametrize("name", CASES)
