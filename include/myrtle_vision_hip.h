@@ -29,7 +29,7 @@ extern "C" {
 
 typedef void* mv_stream_t; /* hipStream_t */
 
-enum { MV_F32 = 0, MV_BF16 = 1, MV_I8 = 2 /* mv_gemm_nt_i8 with MV_EPI_GELU_Q8 only */ };
+enum { MV_F32 = 0, MV_BF16 = 1, MV_I8 = 2 /* mv_gemm_nt_i8 with MV_EPI_GELU_Q8 only */, MV_F16 = 3 /* mv_cast destination only */ };
 
 enum {
   MV_OK = 0,
@@ -138,6 +138,18 @@ int mv_attention_fwd(const void* qkv, void* out, float* lse, int B, int N, int H
  * so no separate pass over dqkv is needed for it. */
 int mv_attention_bwd(const void* qkv, const void* out, const void* dout, const float* lse, void* dqkv, float* colsum,
                      int B, int N, int H, float scale, mv_stream_t stream);
+/* The attention core of precision "bf16x3" (vit.py:87-96 between fp32 tensors): the fused kernels above on IEEE-half operands with
+ * fp32 accumulation, softmax and OUTPUTS; N <= 208.  qkv16: half [B, N, 3, H, 64] (mv_cast to MV_F16 of the fp32 to_qkv output);
+ * out / lse as mv_attention_fwd but out is fp32.  Backward: mv_attention_bwd_prep_f16 turns the fp32 dout [B, N, H*64] into half
+ * scaled by a power of two s (its largest magnitude -> [2^7, 2^8): gradients lie below half's normal range otherwise), leaves s in
+ * gscale[0] (device) and delta[b, h, n] = s * sum_d dout * out; workspace: mv_attention_bwd_prep_f16_workspace_bytes() bytes.
+ * mv_attention_bwd_f16 then writes dqkv fp32 [B, N, 3, H, 64] with s divided out (exactly). */
+int mv_attention_fwd_f16(const void* qkv16, float* out, float* lse, int B, int N, int H, float scale, mv_stream_t stream);
+size_t mv_attention_bwd_prep_f16_workspace_bytes(void);
+int mv_attention_bwd_prep_f16(const float* dout, const float* out, void* dout16, float* delta, float* gscale, void* workspace,
+                              int B, int N, int H, mv_stream_t stream);
+int mv_attention_bwd_f16(const void* qkv16, const void* dout16, const float* delta, const float* lse, const float* gscale,
+                         float* dqkv, int B, int N, int H, float scale, mv_stream_t stream);
 /* Test / tuning hook (process-global, atomic, like mv_gemm_force_variant): backward kernel for the following
  * mv_attention_bwd calls -- 0 auto (N <= 208: 4; N <= 288: 2; else 8), 4 = dS exchanged through LDS (N <= 208), 5 = the same
  * with two waves of 512 registers per workgroup (192 < N <= 208; equal results up to the placement of the softmax scale), 2 = two

@@ -52,6 +52,37 @@ __device__ __forceinline__ bf16x4 pack4(f32x4 a) {
   bf16x4 r = {(bf16_t)a[0], (bf16_t)a[1], (bf16_t)a[2], (bf16_t)a[3]};
   return r;
 }
+// F16 forms (round 4, precision "bf16x3"): the SAME kernels on IEEE-half operands -- 11 significand bits instead of 8, the same
+// 2-byte geometry, LDS images, fragment maps and MFMA rate (v_mfma_f32_16x16x32_f16).  Fragments stay in their bf16x8 / bf16x4
+// containers (they are only moved); what changes is the matrix instruction and every float -> element conversion.
+typedef __attribute__((ext_vector_type(8))) _Float16 f16x8_t;
+typedef __attribute__((ext_vector_type(4))) _Float16 f16x4_t;
+template <bool F16>
+__device__ __forceinline__ f32x4 mma32(bf16x8 a, bf16x8 b, f32x4 c, int, int, int) {
+  if constexpr (F16)
+    return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8_t, a), __builtin_bit_cast(f16x8_t, b), c, 0, 0, 0);
+  else
+    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
+}
+template <bool F16>
+__device__ __forceinline__ bf16x8 pack8t(f32x4 a, f32x4 b) {
+  if constexpr (F16) {
+    const f16x8_t r = {(_Float16)a[0], (_Float16)a[1], (_Float16)a[2], (_Float16)a[3],
+                       (_Float16)b[0], (_Float16)b[1], (_Float16)b[2], (_Float16)b[3]};
+    return __builtin_bit_cast(bf16x8, r);
+  } else {
+    return pack8(a, b);
+  }
+}
+template <bool F16>
+__device__ __forceinline__ bf16x4 pack4t(f32x4 a) {
+  if constexpr (F16) {
+    const f16x4_t r = {(_Float16)a[0], (_Float16)a[1], (_Float16)a[2], (_Float16)a[3]};
+    return __builtin_bit_cast(bf16x4, r);
+  } else {
+    return pack4(a);
+  }
+}
 // Outputs leave as 16-byte stores: a lane holds 4 consecutive features (8 bytes) of each 16-feature tile; for an adjacent
 // tile pair v_permlane16_swap (lanes l <-> l ^ 16, same row) leaves lane group g with 8 consecutive features of tile
 // (g & 1), starting at feature 8 (g >> 1) -- a row's four lanes then cover 64 contiguous bytes per instruction instead of
@@ -363,6 +394,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd2_kernel(const bf16_t* __restr
 // key tiles (six pairs + one), V sits FIRST in LDS and K behind it: the P.V product's last pair reads "V rows 208..223" out of
 // K's first 16 rows -- finite values times p = 0 exactly (keys >= N are masked to -inf before the exponential), the same
 // argument as the clamped padding rows.  3 072 workgroups then take 4 rounds of 768 instead of 6 of 512.
+template <bool F16 = false>   // F16: half operands, fp32 output (precision "bf16x3")
 __global__ __launch_bounds__(256, 3) void attn_fwd13_kernel(const bf16_t* __restrict__ qkv, bf16_t* __restrict__ out,
                                                             float* __restrict__ lse, int N, int H, float scale_log2e) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -429,13 +461,13 @@ __global__ __launch_bounds__(256, 3) void attn_fwd13_kernel(const bf16_t* __rest
       const bf16x8 ka0 = row_frag128(sK, kp * 16, L.rf[0]), ka1 = row_frag128(sK, kp * 16, L.rf[1]);
       if (two) {
         const bf16x8 kb0 = row_frag128(sK, (kp + 1) * 16, L.rf[0]), kb1 = row_frag128(sK, (kp + 1) * 16, L.rf[1]);
-        acc[0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ka0, qf[0], acc[0], 0, 0, 0);
-        acc[1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kb0, qf[0], acc[1], 0, 0, 0);
-        acc[0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ka1, qf[1], acc[0], 0, 0, 0);
-        acc[1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kb1, qf[1], acc[1], 0, 0, 0);
+        acc[0] = mma32<F16>(ka0, qf[0], acc[0], 0, 0, 0);
+        acc[1] = mma32<F16>(kb0, qf[0], acc[1], 0, 0, 0);
+        acc[0] = mma32<F16>(ka1, qf[1], acc[0], 0, 0, 0);
+        acc[1] = mma32<F16>(kb1, qf[1], acc[1], 0, 0, 0);
       } else {
-        acc[0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ka0, qf[0], acc[0], 0, 0, 0);
-        acc[0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ka1, qf[1], acc[0], 0, 0, 0);
+        acc[0] = mma32<F16>(ka0, qf[0], acc[0], 0, 0, 0);
+        acc[0] = mma32<F16>(ka1, qf[1], acc[0], 0, 0, 0);
       }
 #pragma unroll
       for (int t = 0; t < 2; ++t) {
@@ -476,20 +508,29 @@ __global__ __launch_bounds__(256, 3) void attn_fwd13_kernel(const bf16_t* __rest
     for (int dt = 0; dt < 4; ++dt) o[dt] = (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int u = 0; u < (NKS + 1) / 2; ++u) {
-      const bf16x8 pf = pack8(st[2 * u], st[2 * u + 1]);
+      const bf16x8 pf = pack8t<F16>(st[2 * u], st[2 * u + 1]);
 #pragma unroll
       for (int dt = 0; dt < 4; ++dt)
-        o[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(tr_frag128(sV, 32 * u, L.tr[dt]), pf, o[dt], 0, 0, 0);
+        o[dt] = mma32<F16>(tr_frag128(sV, 32 * u, L.tr[dt]), pf, o[dt], 0, 0, 0);
     }
     const float inv = 1.0f / sum;
 #pragma unroll
     for (int dt = 0; dt < 4; ++dt) o[dt] *= inv;
+    if constexpr (F16) {                                 // fp32 output: the lane's four features of each 16-feature tile
+      if (qrow < N) {
+        float* orow = reinterpret_cast<float*>(out) + ((long)b * N + qrow) * D + h * 64;
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt) *reinterpret_cast<f32x4*>(orow + 16 * dt + 4 * g) = o[dt];
+        if (g == 0) lse[((long)b * H + h) * N + qrow] = (mx + __builtin_amdgcn_logf(sum)) * LN2;
+      }
+    } else {
     const u32x4 w0 = pair16(o[0], o[1]), w1 = pair16(o[2], o[3]);
     if (qrow < N) {
       bf16_t* orow = out + ((long)b * N + qrow) * D + h * 64;
       *reinterpret_cast<u32x4*>(orow + pair16_off(0, g)) = w0;
       *reinterpret_cast<u32x4*>(orow + pair16_off(2, g)) = w1;
       if (g == 0) lse[((long)b * H + h) * N + qrow] = (mx + __builtin_amdgcn_logf(sum)) * LN2;
+    }
     }
   }
   if (!v_ready) {                                      // a wave without a query tile (N < 64) still owes the workgroup its barrier
@@ -724,11 +765,15 @@ __global__ __launch_bounds__(512, 1) void attn_bwd_kernel(const bf16_t* __restri
 // phases between barriers have nothing to overlap with.  This variant keeps the same mathematics and fragment maps but
 // fits two workgroups on a CU: single-buffered Q/dO pair and dS^T (two barriers per query pair instead of one), V
 // trimmed to the 13 real key tiles -> 79,616 B.  Wave w owns key tiles w, w+4, w+8, w+12 (128 accumulator VGPRs).
-template <int NW>   // waves per workgroup: 4 (256 registers per lane) or 2 (one wave per SIMD: 512)
+// F16 (precision "bf16x3"): half operands; dout arrives multiplied by a power of two s = *gscale that brings the gradient into
+// half's range (mv_attention_bwd_prep_f16), delta_in = s * rowsum(dO . O) comes precomputed (no O loads), and dQ / dK / dV leave as
+// fp32 times 1 / s.
+template <int NW, bool F16 = false>   // waves per workgroup: 4 (256 registers per lane) or 2 (one wave per SIMD: 512)
 __global__ __launch_bounds__(64 * NW, NW / 2) void attn_bwd4_kernel(const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ out,
                                                            const bf16_t* __restrict__ dout, const float* __restrict__ lse,
                                                            bf16_t* __restrict__ dqkv, float* __restrict__ colsum, int N, int H,
-                                                           float scale) {
+                                                           float scale, const float* __restrict__ delta_in = nullptr,
+                                                           const float* __restrict__ gscale = nullptr) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr int NKT = 13, NPK = 224, NPV = 208, NQP = 7, KPW = (NKT + NW - 1) / NW, NT = 64 * NW;
   char* sK = smem;                           // [224][64] bf16 (rows >= N zero; rows 208..223 exist for the key-pair reads)
@@ -759,7 +804,10 @@ __global__ __launch_bounds__(64 * NW, NW / 2) void attn_bwd4_kernel(const bf16_t
     float l2 = INFINITY;
     if (row < N) l2 = lse[((long)b * H + h) * N + row] * LOG2E;
     sLse[row] = l2;
+    if constexpr (F16) sDelta[row] = row < N ? delta_in[((long)b * H + h) * N + row] : 0.f;
   }
+  [[maybe_unused]] const float inv_s = F16 ? 1.0f / *gscale : 1.0f;
+  [[maybe_unused]] float* const dbase32 = reinterpret_cast<float*>(dqkv) + (long)b * N * 3 * D + h * 64;
 
   // pair staging: 2 tiles x 32 rows x 8 chunks = 512 chunks, PE = 512 / NT per thread (the first half Q, the second dO)
   constexpr int PE = 512 / NT;
@@ -812,11 +860,12 @@ __global__ __launch_bounds__(64 * NW, NW / 2) void attn_bwd4_kernel(const bf16_t
 #pragma unroll
     for (int e = 0; e < PE; ++e) x0[e] = load_pair(0, e);
 #pragma unroll
-    for (int j = 0; j < PE / 2; ++j) o0[j] = load_o(0, j);
+    for (int j = 0; j < PE / 2; ++j) o0[j] = F16 ? zero4 : load_o(0, j);
 #pragma unroll
     for (int e = 0; e < PE; ++e) store_pair(e, x0[e]);
 #pragma unroll
-    for (int j = 0; j < PE / 2; ++j) put_delta(0, j, x0[PE / 2 + j], o0[j]);
+    for (int j = 0; j < PE / 2; ++j)
+      if constexpr (!F16) put_delta(0, j, x0[PE / 2 + j], o0[j]);
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // this wave's K/V DMA pieces have landed
   __syncthreads();
@@ -835,7 +884,7 @@ __global__ __launch_bounds__(64 * NW, NW / 2) void attn_bwd4_kernel(const bf16_t
 #pragma unroll
       for (int e = 0; e < PE; ++e) nx[e] = load_pair(u + 1, e);
 #pragma unroll
-      for (int j = 0; j < PE / 2; ++j) nxo[j] = load_o(u + 1, j);
+      for (int j = 0; j < PE / 2; ++j) nxo[j] = F16 ? zero4 : load_o(u + 1, j);
     }
     if constexpr (NW == 2) {
       if (32 * u < N) {
@@ -888,8 +937,8 @@ __global__ __launch_bounds__(64 * NW, NW / 2) void attn_bwd4_kernel(const bf16_t
             dpv[i & 1][t] = dl4[t];                       // the accumulator starts at -delta[q]: dP - delta leaves the MFMA
 #pragma unroll
             for (int ks = 0; ks < 2; ++ks) {
-              sv[i & 1][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qrow[t][ks], kf[i & 1][ks], sv[i & 1][t], 0, 0, 0);
-              dpv[i & 1][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(dorow[t][ks], vf[i & 1][ks], dpv[i & 1][t], 0, 0, 0);
+              sv[i & 1][t] = mma32<F16>(qrow[t][ks], kf[i & 1][ks], sv[i & 1][t], 0, 0, 0);
+              dpv[i & 1][t] = mma32<F16>(dorow[t][ks], vf[i & 1][ks], dpv[i & 1][t], 0, 0, 0);
             }
           }
         };
@@ -905,8 +954,8 @@ __global__ __launch_bounds__(64 * NW, NW / 2) void attn_bwd4_kernel(const bf16_t
               pp[t][r] = pv;
               ds[t][r] = pv * dpv[i & 1][t][r];                    // dS / scale: dK and dQ take the factor at their stores
             }
-          pf[i & 1] = pack8(pp[0], pp[1]);
-          const bf16x4 d0 = pack4(ds[0]), d1 = pack4(ds[1]);
+          pf[i & 1] = pack8t<F16>(pp[0], pp[1]);
+          const bf16x4 d0 = pack4t<F16>(ds[0]), d1 = pack4t<F16>(ds[1]);
           dsf[i & 1] = cat8(d0, d1);
           *reinterpret_cast<bf16x4*>(sDS + swds4(key, 0, g)) = d0;
           *reinterpret_cast<bf16x4*>(sDS + swds4(key, 1, g)) = d1;
@@ -914,8 +963,8 @@ __global__ __launch_bounds__(64 * NW, NW / 2) void attn_bwd4_kernel(const bf16_t
         auto stage_c = [&](int i) __attribute__((always_inline)) {
 #pragma unroll
           for (int dt = 0; dt < 4; ++dt) {
-            adv[i][dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(dotr[dt], pf[i & 1], adv[i][dt], 0, 0, 0);
-            adk[i][dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qtr[dt], dsf[i & 1], adk[i][dt], 0, 0, 0);
+            adv[i][dt] = mma32<F16>(dotr[dt], pf[i & 1], adv[i][dt], 0, 0, 0);
+            adk[i][dt] = mma32<F16>(qtr[dt], dsf[i & 1], adk[i][dt], 0, 0, 0);
           }
         };
         read_kv(0);
@@ -970,8 +1019,8 @@ __global__ __launch_bounds__(64 * NW, NW / 2) void attn_bwd4_kernel(const bf16_t
           dp[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
           for (int ks = 0; ks < 2; ++ks) {
-            s[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(row_frag128(sQ, t * 16, L.rf[ks]), kf[ks], s[t], 0, 0, 0);
-            dp[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(row_frag128(sDO, t * 16, L.rf[ks]), vf[ks], dp[t], 0, 0, 0);
+            s[t] = mma32<F16>(row_frag128(sQ, t * 16, L.rf[ks]), kf[ks], s[t], 0, 0, 0);
+            dp[t] = mma32<F16>(row_frag128(sDO, t * 16, L.rf[ks]), vf[ks], dp[t], 0, 0, 0);
           }
         }
         f32x4 pp[2], ds[2];
@@ -985,15 +1034,15 @@ __global__ __launch_bounds__(64 * NW, NW / 2) void attn_bwd4_kernel(const bf16_t
             pp[t][r] = p;
             ds[t][r] = p * (dp[t][r] - sDelta[ql]) * scale;
           }
-        const bf16x8 pf = pack8(pp[0], pp[1]);
-        const bf16x8 dsf = pack8(ds[0], ds[1]);
+        const bf16x8 pf = pack8t<F16>(pp[0], pp[1]);
+        const bf16x8 dsf = pack8t<F16>(ds[0], ds[1]);
 #pragma unroll
         for (int dt = 0; dt < 4; ++dt) {
-          adv[i][dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(dotr[dt], pf, adv[i][dt], 0, 0, 0);
-          adk[i][dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qtr[dt], dsf, adk[i][dt], 0, 0, 0);
+          adv[i][dt] = mma32<F16>(dotr[dt], pf, adv[i][dt], 0, 0, 0);
+          adk[i][dt] = mma32<F16>(qtr[dt], dsf, adk[i][dt], 0, 0, 0);
         }
 #pragma unroll
-        for (int t = 0; t < 2; ++t) *reinterpret_cast<bf16x4*>(sDS + swds4(key, t, g)) = pack4(ds[t]);
+        for (int t = 0; t < 2; ++t) *reinterpret_cast<bf16x4*>(sDS + swds4(key, t, g)) = pack4t<F16>(ds[t]);
       }
     }
     __syncthreads();                                   // S-phase done everywhere: dS^T complete, Q/dO pair no longer read
@@ -1001,7 +1050,8 @@ __global__ __launch_bounds__(64 * NW, NW / 2) void attn_bwd4_kernel(const bf16_t
 #pragma unroll
       for (int e = 0; e < PE; ++e) store_pair(e, nx[e]);
 #pragma unroll
-      for (int j = 0; j < PE / 2; ++j) put_delta(u + 1, j, nx[PE / 2 + j], nxo[j]);   // read by the next S-phase, after the barrier below
+      for (int j = 0; j < PE / 2; ++j)
+        if constexpr (!F16) put_delta(u + 1, j, nx[PE / 2 + j], nxo[j]);   // read by the next S-phase, after the barrier below
     }
     // dQ^T[d][q] = sum_key K^T[d][key] dS^T[key][q]: 2 q-tiles x 4 d-tiles = 8 output tiles.  Four waves: two each (one q-tile,
     // a d-tile pair); two waves: four each (both q-tiles of d-tile pair `wave`: the K^T fragments serve both)
@@ -1038,8 +1088,8 @@ __global__ __launch_bounds__(64 * NW, NW / 2) void attn_bwd4_kernel(const bf16_t
         if (v + RD - 1 < NQP) ATTN_DQ_READ((v + RD - 1) % RD, v + RD - 1)
 #pragma unroll
         for (int tq = 0; tq < QT; ++tq) {
-          dq[tq][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kv0[v % RD], dsv[v % RD][tq], dq[tq][0], 0, 0, 0);
-          dq[tq][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kv1[v % RD], dsv[v % RD][tq], dq[tq][1], 0, 0, 0);
+          dq[tq][0] = mma32<F16>(kv0[v % RD], dsv[v % RD][tq], dq[tq][0], 0, 0, 0);
+          dq[tq][1] = mma32<F16>(kv1[v % RD], dsv[v % RD][tq], dq[tq][1], 0, 0, 0);
         }
         __builtin_amdgcn_sched_barrier(0);
       }
@@ -1051,8 +1101,15 @@ __global__ __launch_bounds__(64 * NW, NW / 2) void attn_bwd4_kernel(const bf16_t
           dq[tq][0] *= scale;
           dq[tq][1] *= scale;
         }
+        if constexpr (F16) {
+          if (q < N) {
+            *reinterpret_cast<f32x4*>(dbase32 + (long)q * 3 * D + 16 * (2 * dh) + 4 * g) = dq[tq][0] * inv_s;
+            *reinterpret_cast<f32x4*>(dbase32 + (long)q * 3 * D + 16 * (2 * dh + 1) + 4 * g) = dq[tq][1] * inv_s;
+          }
+        } else {
         const u32x4 dqw = pair16(dq[tq][0], dq[tq][1]);      // (every lane executes the exchange)
         if (q < N) *reinterpret_cast<u32x4*>(dbase + (long)q * 3 * D + pair16_off(2 * dh, g)) = dqw;
+        }
         dqs0 += dq[tq][0];
         dqs1 += dq[tq][1];
       }
@@ -1071,6 +1128,15 @@ __global__ __launch_bounds__(64 * NW, NW / 2) void attn_bwd4_kernel(const bf16_t
     const int kt = wave + NW * i;
     const int key = kt * 16 + (lane & 15);
     if (kt < nkt_valid && kt < NKT) {                     // wave-uniform: the lane exchange below runs on whole waves
+      if constexpr (F16) {
+        if (key < N) {
+#pragma unroll
+          for (int dt = 0; dt < 4; ++dt) {
+            *reinterpret_cast<f32x4*>(dbase32 + (long)key * 3 * D + D + 16 * dt + 4 * g) = adk[i][dt] * inv_s;
+            *reinterpret_cast<f32x4*>(dbase32 + (long)key * 3 * D + 2 * D + 16 * dt + 4 * g) = adv[i][dt] * inv_s;
+          }
+        }
+      } else {
 #pragma unroll
       for (int dp = 0; dp < 4; dp += 2) {
         const u32x4 wk = pair16(adk[i][dp], adk[i][dp + 1]), wv = pair16(adv[i][dp], adv[i][dp + 1]);
@@ -1078,6 +1144,7 @@ __global__ __launch_bounds__(64 * NW, NW / 2) void attn_bwd4_kernel(const bf16_t
           *reinterpret_cast<u32x4*>(dbase + (long)key * 3 * D + D + pair16_off(dp, g)) = wk;
           *reinterpret_cast<u32x4*>(dbase + (long)key * 3 * D + 2 * D + pair16_off(dp, g)) = wv;
         }
+      }
       }
     }
   }
@@ -1440,9 +1507,9 @@ extern "C" int mv_attention_fwd(const void* qkv, void* out, float* lse, int B, i
   const int fv = g_fwd_variant.load(std::memory_order_relaxed);
   if (N <= 208 && (fv == 3 || fv == 0)) {    // 13 key tiles, 53 248 B: three workgroups per CU
     constexpr int smem13 = 2 * 13 * 16 * 128;
-    const int a = MV_ONCE_PER_DEVICE(set_smem(attn_fwd13_kernel, smem13));
+    const int a = MV_ONCE_PER_DEVICE(set_smem(attn_fwd13_kernel<false>, smem13));
     if (a) return MV_ERR_LAUNCH;
-    attn_fwd13_kernel<<<B * H, 256, smem13, s>>>((const bf16_t*)qkv, (bf16_t*)out, lse, N, H, sl);
+    attn_fwd13_kernel<false><<<B * H, 256, smem13, s>>>((const bf16_t*)qkv, (bf16_t*)out, lse, N, H, sl);
   } else if (N <= 224 && fv == 2) {          // query-tile pairs per wave: half the LDS fragment traffic per FLOP
     const int a = MV_ONCE_PER_DEVICE(set_smem(attn_fwd2_kernel<14>, fwd_smem(14)));
     if (a) return MV_ERR_LAUNCH;
@@ -1460,6 +1527,121 @@ extern "C" int mv_attention_fwd(const void* qkv, void* out, float* lse, int B, i
     if (a) return MV_ERR_LAUNCH;
     attn_fwd_kernel<20><<<B * H, 256, fwd_smem(20), s>>>((const bf16_t*)qkv, (bf16_t*)out, lse, N, H, sl);
   }
+  MV_CHECK_LAUNCH();
+  return MV_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// precision "bf16x3": the fused attention core on IEEE-half operands (N <= 208, i.e. the 197-token case)
+// ------------------------------------------------------------------------------------------------
+// The Linear products of that mode are 2^-16 accurate; an fp32 attention core on the f32 MFMA (1/16 of the half rate) was 23 % of
+// its step.  Half operands (11 significand bits: every rounding 8x below bf16's) with fp32 accumulation, fp32 softmax and fp32
+// outputs keep the end-to-end error inside 1e-3 (tests/test_vit_parity.py) at the bf16 kernels' speed -- they ARE those kernels,
+// instantiated with F16 = true.  Forward: q, k, v are O(1) and p in [0, 1]: no range problem.  Backward: gradients can sit far
+// below half's normal range (2^-14), so dO is multiplied by a power of two s chosen from its largest magnitude
+// (mv_attention_bwd_prep_f16: max |dO| -> 2^8, which leaves 2^8 of headroom for dP = dO V^T and dS); s multiplies everything
+// linear in dO -- delta, dP, dS, dQ, dK, dV -- and the kernel divides it out of its fp32 outputs, exactly (a power of two).
+__global__ void attn_absmax_kernel(const float* __restrict__ x, long n, unsigned* __restrict__ amax_bits) {
+  float m = 0.f;
+  const long n4 = n >> 2;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long)gridDim.x * blockDim.x) {
+    const float4 v = reinterpret_cast<const float4*>(x)[i];
+    m = fmaxf(fmaxf(fmaxf(fabsf(v.x), fabsf(v.y)), fmaxf(fabsf(v.z), fabsf(v.w))), m);
+  }
+  for (long i = (n4 << 2) + (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x)
+    m = fmaxf(m, fabsf(x[i]));
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
+  if ((threadIdx.x & 63) == 0 && m > 0.f && m == m) atomicMax(amax_bits, __float_as_uint(m));   // non-negative floats order as their bits
+}
+// s = 2^(8 - ceil(log2(amax))) (1 for an all-zero or non-finite gradient), computed identically by every thread that needs it
+__device__ __forceinline__ float attn_grad_scale(unsigned amax_bits) {
+  const float a = __uint_as_float(amax_bits);
+  if (!(a > 0.f) || a > 3.0e38f) return 1.0f;
+  int e;
+  frexpf(a, &e);                                          // a = f * 2^e, f in [0.5, 1)  ->  a * 2^(8 - e) in [2^7, 2^8)
+  e = 8 - e;
+  e = e > 100 ? 100 : (e < -100 ? -100 : e);
+  return ldexpf(1.0f, e);
+}
+// one thread per (token row, head, 8 features): dO * s -> half, delta = s * sum_d dO O over the head's 64 features (8 lanes)
+__global__ __launch_bounds__(256) void attn_bwd_prep_f16_kernel(const float* __restrict__ dout, const float* __restrict__ out,
+                                                                const unsigned* __restrict__ amax_bits, _Float16* __restrict__ dout16,
+                                                                float* __restrict__ delta, float* __restrict__ gscale, long rows,
+                                                                int N, int H) {
+  const float s = attn_grad_scale(*amax_bits);
+  if (blockIdx.x == 0 && threadIdx.x == 0) *gscale = s;
+  const long total = rows * H * 8;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+    const long row = i / (H * 8);
+    const int hc = (int)(i - row * (H * 8)), h = hc >> 3;
+    const float4 a0 = *reinterpret_cast<const float4*>(dout + row * H * 64 + hc * 8);
+    const float4 a1 = *reinterpret_cast<const float4*>(dout + row * H * 64 + hc * 8 + 4);
+    const float4 o0 = *reinterpret_cast<const float4*>(out + row * H * 64 + hc * 8);
+    const float4 o1 = *reinterpret_cast<const float4*>(out + row * H * 64 + hc * 8 + 4);
+    const float d[8] = {a0.x * s, a0.y * s, a0.z * s, a0.w * s, a1.x * s, a1.y * s, a1.z * s, a1.w * s};
+    float dl = d[0] * o0.x + d[1] * o0.y + d[2] * o0.z + d[3] * o0.w + d[4] * o1.x + d[5] * o1.y + d[6] * o1.z + d[7] * o1.w;
+    const f16x8_t w = {(_Float16)d[0], (_Float16)d[1], (_Float16)d[2], (_Float16)d[3],
+                       (_Float16)d[4], (_Float16)d[5], (_Float16)d[6], (_Float16)d[7]};
+    *reinterpret_cast<f16x8_t*>(dout16 + row * H * 64 + hc * 8) = w;
+    dl += __shfl_xor(dl, 1, 64);
+    dl += __shfl_xor(dl, 2, 64);
+    dl += __shfl_xor(dl, 4, 64);
+    if ((hc & 7) == 0) {
+      const long b = row / N, n = row - b * N;
+      delta[(b * H + h) * N + n] = dl;
+    }
+  }
+}
+
+extern "C" int mv_attention_fwd_f16(const void* qkv16, float* out, float* lse, int B, int N, int H, float scale,
+                                    mv_stream_t stream) {
+  MV_REQUIRE(B >= 0 && N > 0 && H > 0, MV_ERR_SHAPE);
+  MV_REQUIRE(N <= 208, MV_ERR_UNSUPPORTED);
+  MV_REQUIRE(mv_aligned16(qkv16) && mv_aligned16(out), MV_ERR_ALIGN);
+  if (B == 0) return MV_OK;
+  constexpr int smem13 = 2 * 13 * 16 * 128;
+  const int a = MV_ONCE_PER_DEVICE(set_smem(attn_fwd13_kernel<true>, smem13));
+  if (a) return MV_ERR_LAUNCH;
+  attn_fwd13_kernel<true><<<B * H, 256, smem13, (hipStream_t)stream>>>((const bf16_t*)qkv16, (bf16_t*)out, lse, N, H, scale * LOG2E);
+  MV_CHECK_LAUNCH();
+  return MV_OK;
+}
+
+extern "C" size_t mv_attention_bwd_prep_f16_workspace_bytes(void) { return 256; }
+
+extern "C" int mv_attention_bwd_prep_f16(const float* dout, const float* out, void* dout16, float* delta, float* gscale,
+                                         void* workspace, int B, int N, int H, mv_stream_t stream) {
+  MV_REQUIRE(B >= 0 && N > 0 && H > 0, MV_ERR_SHAPE);
+  MV_REQUIRE(mv_aligned16(dout) && mv_aligned16(out) && mv_aligned16(dout16) && workspace && gscale && delta, MV_ERR_ALIGN);
+  if (B == 0) return MV_OK;
+  hipStream_t s = (hipStream_t)stream;
+  unsigned* amax = reinterpret_cast<unsigned*>(workspace);
+  mv_zero_f32_kernel<<<1, 64, 0, s>>>(reinterpret_cast<float*>(amax), 1);
+  const long n = (long)B * N * H * 64;
+  int grid = (int)((n / 4 + 255) / 256);
+  if (grid > 2048) grid = 2048;
+  if (grid < 1) grid = 1;
+  attn_absmax_kernel<<<grid, 256, 0, s>>>(dout, n, amax);
+  const long total = (long)B * N * H * 8;
+  int g2 = (int)((total + 255) / 256);
+  if (g2 > 4096) g2 = 4096;
+  attn_bwd_prep_f16_kernel<<<g2, 256, 0, s>>>(dout, out, amax, (_Float16*)dout16, delta, gscale, (long)B * N, N, H);
+  MV_CHECK_LAUNCH();
+  return MV_OK;
+}
+
+extern "C" int mv_attention_bwd_f16(const void* qkv16, const void* dout16, const float* delta, const float* lse,
+                                    const float* gscale, float* dqkv, int B, int N, int H, float scale, mv_stream_t stream) {
+  MV_REQUIRE(B >= 0 && N > 0 && H > 0, MV_ERR_SHAPE);
+  MV_REQUIRE(N <= 208, MV_ERR_UNSUPPORTED);
+  MV_REQUIRE(mv_aligned16(qkv16) && mv_aligned16(dout16) && mv_aligned16(dqkv) && delta && lse && gscale, MV_ERR_ALIGN);
+  if (B == 0) return MV_OK;
+  constexpr int smem4 = 224 * 128 + 208 * 128 + 8192 + 224 * 64 + 2 * 224 * 4;
+  const int a = MV_ONCE_PER_DEVICE(set_smem(attn_bwd4_kernel<4, true>, smem4));
+  if (a) return MV_ERR_LAUNCH;
+  attn_bwd4_kernel<4, true><<<B * H, 256, smem4, (hipStream_t)stream>>>((const bf16_t*)qkv16, nullptr, (const bf16_t*)dout16, lse,
+                                                                         (bf16_t*)dqkv, nullptr, N, H, scale, delta, gscale);
   MV_CHECK_LAUNCH();
   return MV_OK;
 }

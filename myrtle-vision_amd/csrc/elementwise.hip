@@ -123,6 +123,19 @@ __global__ void cast_kernel(const S* __restrict__ src, T* __restrict__ dst, long
     dst[i] = (T)(float)src[i];
 }
 
+// fp32 -> IEEE half (the operands of the "bf16x3" attention core); n % 4 handled like cast_kernel
+__global__ void cast_f16_kernel(const float* __restrict__ src, _Float16* __restrict__ dst, long n) {
+  typedef __attribute__((ext_vector_type(4))) _Float16 h4;
+  const long n4 = n >> 2;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long)gridDim.x * blockDim.x) {
+    const float4 f = reinterpret_cast<const float4*>(src)[i];
+    const h4 w = {(_Float16)f.x, (_Float16)f.y, (_Float16)f.z, (_Float16)f.w};
+    reinterpret_cast<h4*>(dst)[i] = w;
+  }
+  for (long i = (n4 << 2) + (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x)
+    dst[i] = (_Float16)src[i];
+}
+
 // w fp32 [R][C] -> wb bf16 [R][ldw] (pad columns zero) and wt bf16 [C][ldt] (pad zero).  32x32 tile through LDS.
 __device__ __forceinline__ void weight_prep_tile(const float* __restrict__ w, bf16_t* wb, int ldw, bf16_t* wt, int ldt, int R,
                                                  int C, int r0, int c0, float (*tile)[33]) {
@@ -894,6 +907,8 @@ extern "C" int mv_cast(const void* src, int src_dtype, void* dst, int dst_dtype,
     cast_kernel<bf16_t, float><<<grid, 256, 0, S_>>>((const bf16_t*)src, (float*)dst, n);
   else if (src_dtype == MV_F32 && dst_dtype == MV_F32)
     cast_kernel<float, float><<<grid, 256, 0, S_>>>((const float*)src, (float*)dst, n);
+  else if (src_dtype == MV_F32 && dst_dtype == MV_F16)
+    cast_f16_kernel<<<grid, 256, 0, S_>>>((const float*)src, (_Float16*)dst, n);
   else
     return MV_ERR_UNSUPPORTED;
   MV_CHECK_LAUNCH();

@@ -535,7 +535,14 @@ class _AttnBlock(Function):
             qkv = torch.empty(B, T, inner3, dtype=adt, device=x.device)
             ops.nt_x6(y6, wqkv, "fwd", M, qkv.view(M, inner3), bias=bqkv)
             o = None
-            if ops.attention_f32_fused_supported(adt, T, dh):
+            ctx.f16 = False
+            if ops.attention_f16_supported(adt, T, dh):
+                # precision "bf16x3": the fused attention kernels on half operands (2^-12 per rounding, fp32 sums, softmax and
+                # outputs); the half copy of q/k/v replaces the fp32 tensor among the saved activations
+                qkv = ops.cast_f16(qkv)
+                o, probs = ops.attention_fwd_f16(qkv, B, T, heads, scale)            # "probs" slot: the log-sum-exp [B, H, T]
+                ctx.fused32, ctx.f16 = True, True
+            elif ops.attention_f32_fused_supported(adt, T, dh):
                 if any(ctx.needs_input_grad):
                     o, probs = ops.attention_fwd_f32_lse(qkv, B, T, heads, scale)   # "probs" slot: the log-sum-exp [B, H, T]
                 else:
@@ -600,7 +607,9 @@ class _AttnBlock(Function):
             dwo = ops.tn_x6(d6, o6, M, wo)
             do = torch.empty(B, T, inner, dtype=torch.float32, device=x.device)
             ops.nt_x6(d6, wo, "dx", M, do.view(M, inner))
-            if ctx.fused32:
+            if ctx.f16:
+                dqkv = ops.attention_bwd_f16(qkv, ctx.saved_tensors[10], do, probs, B, T, heads, scale)
+            elif ctx.fused32:
                 dqkv = ops.attention_bwd_f32_fused(qkv, ctx.saved_tensors[10], do, probs, B, T, heads, scale)
             else:
                 dqkv = ops.attention_bwd_fp32(probs, qkv, do, B, T, heads, inner // heads, scale)

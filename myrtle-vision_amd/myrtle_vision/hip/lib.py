@@ -12,7 +12,7 @@ import torch  # noqa: F401  -- FIRST: brings PyTorch-ROCm's HIP runtime into the
 
 from .build import LIB_PATH
 
-MV_F32, MV_BF16, MV_I8 = 0, 1, 2
+MV_F32, MV_BF16, MV_I8, MV_F16 = 0, 1, 2, 3
 EPI_NONE, EPI_GELU, EPI_RESIDUAL, EPI_DGELU, EPI_EMBED, EPI_GELU_GRAD, EPI_MUL, EPI_GELU_Q8 = 0, 1, 2, 3, 4, 5, 6, 7
 EPI_GELU_GRAD8, EPI_MUL8 = 8, 9
 
@@ -49,6 +49,10 @@ SIGNATURES = {
     "mv_attention_fwd": ("ppp" "iii" "f" "p", _I),
     "mv_attention_bwd": ("pppppp" "iii" "f" "p", _I),
     "mv_attention_fwd_f32": ("pp" "iii" "f" "p", _I),
+    "mv_attention_fwd_f16": ("ppp" "iii" "f" "p", _I),
+    "mv_attention_bwd_prep_f16_workspace_bytes": ("", _Z),
+    "mv_attention_bwd_prep_f16": ("pppppp" "iii" "p", _I),
+    "mv_attention_bwd_f16": ("pppppp" "iii" "f" "p", _I),
     "mv_softmax_fwd": ("pp" "li" "f" "p", _I),
     "mv_softmax_bwd": ("ppp" "li" "f" "p", _I),
     "mv_patchify": ("ppi" "iiiii" "p", _I),

@@ -733,6 +733,44 @@ def attention_f32_fused_supported(qkv_dtype, N, dim_head):
     return qkv_dtype == torch.float32 and dim_head == 64 and N <= 272
 
 
+def attention_f16_supported(qkv_dtype, N, dim_head):
+    """The half-operand attention core of precision "bf16x3" (the bf16 kernels instantiated on IEEE half): fp32 q/k/v, N <= 208."""
+    return qkv_dtype == torch.float32 and dim_head == 64 and N <= 208 and current_segments() == 3
+
+
+def cast_f16(src):
+    """fp32 -> IEEE half (stored in a torch.float16 tensor)."""
+    require_cuda(src)
+    out = torch.empty(src.shape, dtype=torch.float16, device=src.device)
+    check(lib().mv_cast(_p(src), MV_F32, _p(out), _l.MV_F16, src.numel(), _s()), "cast(f16)", n=src.numel())
+    return out
+
+
+def attention_fwd_f16(qkv16, B, N, H, scale):
+    """-> (out fp32 [B, N, H*64], lse fp32 [B, H, N]) from half q/k/v [B, N, 3, H, 64]."""
+    out = torch.empty(B, N, H * 64, dtype=torch.float32, device=qkv16.device)
+    lse = torch.empty(B, H, N, dtype=torch.float32, device=qkv16.device)
+    check(lib().mv_attention_fwd_f16(_p(qkv16), _p(out), _p(lse), B, N, H, scale, _s()), "attention_fwd_f16", B=B, N=N, H=H)
+    return out, lse
+
+
+def attention_bwd_f16(qkv16, out, dout, lse, B, N, H, scale):
+    """-> dqkv fp32 [B, N, 3*H*64].  ``out`` / ``dout`` fp32 [B, N, H*64]: dout is scaled into half's range by a power of two
+    taken from its own largest magnitude (one reduction + one conversion pass that also leaves delta), the kernel divides the
+    factor out of its fp32 outputs."""
+    dev = qkv16.device
+    dout16 = torch.empty(B, N, H * 64, dtype=torch.float16, device=dev)
+    delta = torch.empty(B, H, N, dtype=torch.float32, device=dev)
+    gscale = torch.empty(1, dtype=torch.float32, device=dev)
+    ws = workspace(lib().mv_attention_bwd_prep_f16_workspace_bytes(), dev)
+    check(lib().mv_attention_bwd_prep_f16(_p(dout), _p(out), _p(dout16), _p(delta), _p(gscale), _p(ws), B, N, H, _s()),
+          "attention_bwd_prep_f16", B=B, N=N, H=H)
+    dqkv = torch.empty(B, N, 3 * H * 64, dtype=torch.float32, device=dev)
+    check(lib().mv_attention_bwd_f16(_p(qkv16), _p(dout16), _p(delta), _p(lse), _p(gscale), _p(dqkv), B, N, H, scale, _s()),
+          "attention_bwd_f16", B=B, N=N, H=H)
+    return dqkv
+
+
 def attention_fwd_f32(qkv, B, N, H, scale):
     """Exact fp32 attention core, forward only (no probabilities kept): qkv fp32 [B, N, 3*H*64] -> out fp32 [B, N, H*64]."""
     require_cuda(qkv)

@@ -642,6 +642,36 @@ def test_attention_fused_fp32_forward(ops, B, N, H):
     assert relerr(out2, want2) < 5e-5 and torch.equal(out2, ops.attention_fwd_f32(qkv2.cuda(), B, N, H, scale))
 
 
+@pytest.mark.parametrize("B,N,H", [(2, 197, 3), (3, 50, 1), (1, 17, 12), (2, 208, 2), (1, 193, 2)])
+@pytest.mark.parametrize("gscale", [1.0, 3.0e-7, 4.0e4])
+def test_attention_f16_fwd_bwd(ops, B, N, H, gscale):
+    """The attention core of precision "bf16x3": the fused bf16 kernels instantiated on IEEE-half operands (fp32 sums, softmax,
+    outputs).  Against fp64 on the SAME half-rounded q/k/v: forward to 2^-11-class error (the only roundings left are P -> half
+    and the fp32 sums); backward to 2e-3 of each of dq / dk / dv (P, dS and dO in half), and -- the point of the scaling by a power
+    of two -- the SAME relative error whether the incoming gradient is O(1), 3e-7 (far below half's normal range, 6e-5) or 4e4
+    (above half's largest value divided by the key count)."""
+    scale = 64 ** -0.5
+    qkv = torch.randn(B, N, 3 * H * 64, generator=g(1)) * 1.2
+    dout = torch.randn(B, N, H * 64, generator=g(2)) * gscale
+    q16 = ops.cast_f16(qkv.cuda())
+    assert q16.dtype == torch.float16 and torch.equal(q16.cpu(), qkv.half())
+    ref_in = qkv.half().double().requires_grad_(True)
+    want, _ = attn_ref(ref_in, H, scale)
+    want.backward(dout.double())
+    out, lse = ops.attention_fwd_f16(q16, B, N, H, scale)
+    assert out.dtype == torch.float32 and relerr(out, want) < 6e-4
+    q, k, _ = qkv.half().double().view(B, N, 3, H, 64).permute(2, 0, 3, 1, 4)
+    assert float((lse.cpu().double() - torch.logsumexp((q @ k.transpose(-2, -1)) * scale, dim=-1)).abs().max()) < 2e-5
+    dqkv = ops.attention_bwd_f16(q16, out, dout.cuda(), lse, B, N, H, scale)
+    assert dqkv.dtype == torch.float32 and bool(torch.isfinite(dqkv).all())
+    got, ref = dqkv.cpu().view(B, N, 3, H, 64), ref_in.grad.view(B, N, 3, H, 64)
+    for i, name in enumerate("qkv"):
+        assert relerr(got[:, :, i], ref[:, :, i]) < 2e-3, (name, relerr(got[:, :, i], ref[:, :, i]))
+    # deterministic, and an all-zero gradient gives exact zeros (scale 1, no 0 * inf)
+    assert torch.equal(dqkv, ops.attention_bwd_f16(q16, out, dout.cuda(), lse, B, N, H, scale))
+    assert not ops.attention_bwd_f16(q16, out, torch.zeros_like(dout).cuda(), lse, B, N, H, scale).any()
+
+
 @pytest.mark.parametrize("B,N,H", [(2, 197, 3), (1, 257, 2), (3, 50, 1), (1, 17, 12), (2, 208, 2), (1, 272, 1)])
 def test_attention_fused_fp32_backward(ops, B, N, H):
     """mv_attention_fwd_f32_lse + mv_attention_bwd_f32 (fp32 training without the [B, H, N, N] tensors) against fp64
