@@ -42,6 +42,8 @@ WORKLOAD = {"cls": "ViT-B/16 224^2 classification training step: zero_grad + fwd
 PRECISION_DTYPE = {
     "bf16x3": "bf16x3 (fp32 tensors; every nn.Linear product from two bf16 pieces per operand, three pairings on the bf16 MFMA "
               "with fp32 accumulation = 2^-16 relative; attention core on the f32 MFMA; inside 1e-3 of the reference end to end)",
+    "bf16x3h": "bf16x3h (bf16x3 with the attention core on IEEE-half operands, fp32 sums / softmax / outputs; logits inside 1e-3 of "
+               "the reference, arg-max exact, gradients to 1.6e-3)",
     "fp32": "fp32 (every nn.Linear product as bf16x6 on the bf16 MFMA = fp32-accurate; attention core on the f32 MFMA)"}
 VIT_B = dict(decoder="classification", image_size=224, patch_size=16, num_classes=1000, dim=768, depth=12, heads=12,
              mlp_dim=3072, dropout=0.0, emb_dropout=0.0)

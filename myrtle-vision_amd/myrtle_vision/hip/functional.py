@@ -50,7 +50,7 @@ def _fwd(forward):
         # fused functions receive the model's precision as their last argument and follow it; granular ones (one reference
         # module each, no precision argument) follow the scope their caller opened (ViT.forward)
         prec = args[-1] if args and isinstance(args[-1], str) else None
-        ctx.mv_segments = ops.prec_segments(prec) if prec is not None else ops.current_segments()
+        ctx.mv_segments = ops.prec_segments(prec) if prec is not None else getattr(ops._seg_tls, "n", 6)
         with ops.segments(ctx.mv_segments):
             return forward(ctx, *args, **kwargs)
     return run
@@ -537,7 +537,7 @@ class _AttnBlock(Function):
             o = None
             ctx.f16 = False
             if ops.attention_f16_supported(adt, T, dh):
-                # precision "bf16x3": the fused attention kernels on half operands (2^-12 per rounding, fp32 sums, softmax and
+                # precision "bf16x3h": the fused attention kernels on half operands (2^-12 per rounding, fp32 sums, softmax and
                 # outputs); the half copy of q/k/v replaces the fp32 tensor among the saved activations
                 qkv = ops.cast_f16(qkv)
                 o, probs = ops.attention_fwd_f16(qkv, B, T, heads, scale)            # "probs" slot: the log-sum-exp [B, H, T]

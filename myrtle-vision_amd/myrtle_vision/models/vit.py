@@ -5,10 +5,11 @@ SegmentationDecoder, DetectionDecoder``), constructor kwargs, attribute names (h
 checkpoint wire format), the ``attn_output`` hook point, ``.convert()`` and ``.quantizer`` as the reference; the
 arithmetic runs in the HIP kernels of ``csrc/`` through ``myrtle_vision.hip.functional``.
 
-One extension: ``ViT(..., precision="bf16" | "bf16x3" | "fp32")`` (default: env ``MYRTLE_VISION_PRECISION`` or ``"bf16"``).
+One extension: ``ViT(..., precision="bf16" | "bf16x3" | "bf16x3h" | "fp32")`` (default: env ``MYRTLE_VISION_PRECISION`` or ``"bf16"``).
 ``bf16`` is the benchmark configuration (MFMA, fp32 accumulate, fp32 residual stream); ``fp32`` is the
 parity mode (fp32-accurate arithmetic: the one held to 1e-3 / bit-exact argmax against the reference); ``bf16x3`` is the fast mode
-inside that same tolerance (fp32 data flow, every nn.Linear product from two bf16 pieces per operand: 2^-16 relative).  Any fake-quantised ``q_format`` runs in ``fp32`` (its values are fp32 by definition,
+inside that same tolerance (fp32 data flow, every nn.Linear product from two bf16 pieces per operand: 2^-16 relative); ``bf16x3h``
+adds the attention core on IEEE-half operands (logits and arg-max as bf16x3, gradients to 1.6e-3; 2 750 vs 2 300 img/s).  Any fake-quantised ``q_format`` runs in ``fp32`` (its values are fp32 by definition,
 utils/quantize.py:84).
 
 There is no CPU compute path: ``forward`` on CPU tensors raises.

@@ -22,7 +22,7 @@ CASES = ["micro_cls", "micro_cls_256", "micro_seg", "micro_seg_256", "tiny_cls",
 BF16_LOGITS, BF16_GRAD = 1.5e-2, 2e-2
 
 
-EXACT = ("fp32", "bf16x3")      # the two modes held to north_star's 1e-3 / bit-exact arg-max against the reference
+EXACT = ("fp32", "bf16x3", "bf16x3h")      # the modes held to north_star's 1e-3 / bit-exact arg-max against the reference
 
 
 def report(tag, value):
@@ -104,7 +104,7 @@ def check_case(name, precision, tol_logits, tol_grad, q_format=None, **extra):
         # over 1.1 M logits is held to 1e-3 of ITSELF (measured 6e-6) and the norms to 1e-3 of the l2 scale)
         idx = slice(0, 4) if precision == "fp32" and q_format is None else slice(1, 3)
         assert np.abs(s_got[idx] - s_want[idx]).max() / s_want[1] < tol_logits
-        if precision == "bf16x3":
+        if precision in ("bf16x3", "bf16x3h"):
             assert abs(s_got[0] - s_want[0]) < tol_logits * max(abs(s_want[0]), s_want[1])
             assert abs(s_got[3] - s_want[3]) < tol_logits * max(abs(s_want[3]), s_want[1])
     assert abs(float(loss) - float(arrays["loss"])) < tol_logits * max(1.0, abs(float(arrays["loss"])))
@@ -194,8 +194,17 @@ def test_bf16x3_matches_reference(name):
     check_case(name, "bf16x3", 1e-3, 1e-3)
 
 
+@pytest.mark.parametrize("name", CASES)
+def test_bf16x3h_matches_reference(name):
+    """``precision="bf16x3h"``: bf16x3 with the attention core on IEEE-half operands (fp32 sums, softmax and outputs; 197-token
+    models -- the 257-token fixtures run the fp32 core as in bf16x3).  Logits and loss at north_star's 1e-3 (measured <= 1.6e-4)
+    and bit-exact class indices; gradients at 3e-3 (measured <= 1.6e-3 on ViT-B: each layer's q and k carry a 2^-12 rounding under
+    the exponential, a per-layer Jacobian error of ~1e-4 that adds up over twelve layers; bf16 mode: 1.2e-2)."""
+    check_case(name, "bf16x3h", 1e-3, 3e-3)
+
+
 @pytest.mark.parametrize("name,precision", [("micro_cls", "fp32"), ("micro_cls_256", "fp32"), ("tiny_cls", "fp32"), ("base_cls", "fp32"),
-                                            ("base_cls", "bf16x3"), ("tiny_cls", "bf16"), ("base_cls", "bf16")])
+                                            ("base_cls", "bf16x3"), ("base_cls", "bf16x3h"), ("tiny_cls", "bf16"), ("base_cls", "bf16")])
 def test_prune_dead_tokens_changes_nothing(name, precision):
     """``ViT(prune_dead_tokens=True)`` (extension, off by default): the last block's FeedForward runs on the cls rows only -- the
     classification decoder reads nothing else (reference vit.py:335-342) and the other rows' gradient is exactly zero.  Same bars
@@ -203,7 +212,8 @@ def test_prune_dead_tokens_changes_nothing(name, precision):
     itself: fp32 modes to fp32 rounding (the two run the last MLP's products over different row counts, i.e. kernels)."""
     from myrtle_vision.hip.functional import cross_entropy
     exact = precision in EXACT
-    check_case(name, precision, 1e-3 if exact else BF16_LOGITS, 1e-3 if exact else 3e-2, prune_dead_tokens=True)
+    check_case(name, precision, 1e-3 if exact else BF16_LOGITS, 3e-3 if precision == "bf16x3h" else 1e-3 if exact else 3e-2,
+               prune_dead_tokens=True)
     outs = []
     for prune in (False, True):
         vit, img, labels, _, _ = build(name, precision, prune_dead_tokens=prune)
@@ -214,7 +224,8 @@ def test_prune_dead_tokens_changes_nothing(name, precision):
         outs.append((logits.detach().float(), {k: p.grad.float().clone() for k, p in vit.named_parameters() if p.grad is not None}))
     (l0, g0), (l1, g1) = outs
     assert set(g0) == set(g1)
-    tol = 2e-5 if exact else 2e-2
+    tol = 2e-3 if precision == "bf16x3h" else 2e-5 if exact else 2e-2     # (x3h: the last MLP's different row count changes what
+    #                                                                       the half roundings upstream see through dX)
     assert float((l0 - l1).abs().max() / l0.abs().max()) < tol
     for k in g0:
         assert float((g0[k] - g1[k]).norm() / g0[k].norm().clamp_min(1e-30)) < tol, k
@@ -270,7 +281,7 @@ def test_top1_agreement_rate(name):
     scale = np.abs(want).max()
     top2 = np.sort(want, axis=1)[:, -2:]
     margin = (top2[:, 1] - top2[:, 0]) / scale
-    for precision in ("fp32", "bf16x3", "bf16"):
+    for precision in ("fp32", "bf16x3", "bf16x3h", "bf16"):
         vit, img, labels, _, _ = build(name, precision)
         vit.eval()
         with torch.no_grad():

@@ -45,7 +45,7 @@ for w in "--workload seg" "--workload seg256" "--workload infer-int8" "--batch 3
   python3 bench.py $w --steps 8 --warmup 3 --no-cpu-baseline 2>> $O/bench.err | tail -1 >> $O/${TAG}_workload_lines.jsonl
 done
 # the reference-tolerance modes next to the headline
-for w in "--precision bf16x3" "--precision fp32"; do
+for w in "--precision bf16x3h" "--precision bf16x3" "--precision fp32"; do
   python3 bench.py $w --steps 6 --warmup 2 --no-cpu-baseline 2>> $O/bench.err | tail -1 >> $O/${TAG}_workload_lines.jsonl
 done
 # launch-path record of the RCCL exchange with ONE rank (no multi-GPU hardware in this pool): both exchange dtypes
