@@ -141,13 +141,12 @@ int mv_attention_bwd(const void* qkv, const void* out, const void* dout, const f
 /* The attention core of precision "bf16x3" (vit.py:87-96 between fp32 tensors): the fused kernels above on IEEE-half operands with
  * fp32 accumulation, softmax and OUTPUTS; N <= 208.  qkv16: half [B, N, 3, H, 64] (mv_cast to MV_F16 of the fp32 to_qkv output);
  * out / lse as mv_attention_fwd but out is fp32.  Backward: mv_attention_bwd_prep_f16 turns the fp32 dout [B, N, H*64] into half
- * scaled by a power of two s (its largest magnitude -> [2^7, 2^8): gradients lie below half's normal range otherwise), leaves s in
- * gscale[0] (device) and delta[b, h, n] = s * sum_d dout * out; workspace: mv_attention_bwd_prep_f16_workspace_bytes() bytes.
+ * scaled, per (image, head), by a power of two s (the slice's largest magnitude -> [2^7, 2^8): gradients lie below half's normal
+ * range otherwise), leaves s in gscale[b * H + h] (device, fp32 [B * H]) and delta[b, h, n] = sum_d half(dout * s) * out.
  * mv_attention_bwd_f16 then writes dqkv fp32 [B, N, 3, H, 64] with s divided out (exactly). */
 int mv_attention_fwd_f16(const void* qkv16, float* out, float* lse, int B, int N, int H, float scale, mv_stream_t stream);
-size_t mv_attention_bwd_prep_f16_workspace_bytes(void);
-int mv_attention_bwd_prep_f16(const float* dout, const float* out, void* dout16, float* delta, float* gscale, void* workspace,
-                              int B, int N, int H, mv_stream_t stream);
+int mv_attention_bwd_prep_f16(const float* dout, const float* out, void* dout16, float* delta, float* gscale, int B, int N, int H,
+                              mv_stream_t stream);
 int mv_attention_bwd_f16(const void* qkv16, const void* dout16, const float* delta, const float* lse, const float* gscale,
                          float* dqkv, int B, int N, int H, float scale, mv_stream_t stream);
 /* Test / tuning hook (process-global, atomic, like mv_gemm_force_variant): backward kernel for the following

@@ -806,7 +806,9 @@ __global__ __launch_bounds__(64 * NW, NW / 2) void attn_bwd4_kernel(const bf16_t
     sLse[row] = l2;
     if constexpr (F16) sDelta[row] = row < N ? delta_in[((long)b * H + h) * N + row] : 0.f;
   }
-  [[maybe_unused]] const float inv_s = F16 ? 1.0f / *gscale : 1.0f;
+  // (one power of two per (image, head): heads and images whose gradient is small get their own range)
+  [[maybe_unused]] const float inv_s = F16 ? 1.0f / gscale[blockIdx.x] : 1.0f;
+  [[maybe_unused]] const float inv_ss = inv_s * scale;      // F16: dS^T leaves without the softmax scale (3 more bits above half's underflow)
   [[maybe_unused]] float* const dbase32 = reinterpret_cast<float*>(dqkv) + (long)b * N * 3 * D + h * 64;
 
   // pair staging: 2 tiles x 32 rows x 8 chunks = 512 chunks, PE = 512 / NT per thread (the first half Q, the second dO)
@@ -1032,7 +1034,8 @@ __global__ __launch_bounds__(64 * NW, NW / 2) void attn_bwd4_kernel(const bf16_t
             float p = __builtin_amdgcn_exp2f(s[t][r] * c2 - sLse[ql]);
             p = key < N ? p : 0.f;
             pp[t][r] = p;
-            ds[t][r] = p * (dp[t][r] - sDelta[ql]) * scale;
+            if constexpr (F16) ds[t][r] = __builtin_amdgcn_fmed3f(p * (dp[t][r] - sDelta[ql]), -65000.f, 65000.f);
+            else ds[t][r] = p * (dp[t][r] - sDelta[ql]) * scale;
           }
         const bf16x8 pf = pack8t<F16>(pp[0], pp[1]);
         const bf16x8 dsf = pack8t<F16>(ds[0], ds[1]);
@@ -1103,8 +1106,8 @@ __global__ __launch_bounds__(64 * NW, NW / 2) void attn_bwd4_kernel(const bf16_t
         }
         if constexpr (F16) {
           if (q < N) {
-            *reinterpret_cast<f32x4*>(dbase32 + (long)q * 3 * D + 16 * (2 * dh) + 4 * g) = dq[tq][0] * inv_s;
-            *reinterpret_cast<f32x4*>(dbase32 + (long)q * 3 * D + 16 * (2 * dh + 1) + 4 * g) = dq[tq][1] * inv_s;
+            *reinterpret_cast<f32x4*>(dbase32 + (long)q * 3 * D + 16 * (2 * dh) + 4 * g) = dq[tq][0] * inv_ss;
+            *reinterpret_cast<f32x4*>(dbase32 + (long)q * 3 * D + 16 * (2 * dh + 1) + 4 * g) = dq[tq][1] * inv_ss;
           }
         } else {
         const u32x4 dqw = pair16(dq[tq][0], dq[tq][1]);      // (every lane executes the exchange)
@@ -1132,7 +1135,7 @@ __global__ __launch_bounds__(64 * NW, NW / 2) void attn_bwd4_kernel(const bf16_t
         if (key < N) {
 #pragma unroll
           for (int dt = 0; dt < 4; ++dt) {
-            *reinterpret_cast<f32x4*>(dbase32 + (long)key * 3 * D + D + 16 * dt + 4 * g) = adk[i][dt] * inv_s;
+            *reinterpret_cast<f32x4*>(dbase32 + (long)key * 3 * D + D + 16 * dt + 4 * g) = adk[i][dt] * inv_ss;
             *reinterpret_cast<f32x4*>(dbase32 + (long)key * 3 * D + 2 * D + 16 * dt + 4 * g) = adv[i][dt] * inv_s;
           }
         }
@@ -1538,25 +1541,11 @@ extern "C" int mv_attention_fwd(const void* qkv, void* out, float* lse, int B, i
 // its step.  Half operands (11 significand bits: every rounding 8x below bf16's) with fp32 accumulation, fp32 softmax and fp32
 // outputs keep the end-to-end error inside 1e-3 (tests/test_vit_parity.py) at the bf16 kernels' speed -- they ARE those kernels,
 // instantiated with F16 = true.  Forward: q, k, v are O(1) and p in [0, 1]: no range problem.  Backward: gradients can sit far
-// below half's normal range (2^-14), so dO is multiplied by a power of two s chosen from its largest magnitude
-// (mv_attention_bwd_prep_f16: max |dO| -> 2^8, which leaves 2^8 of headroom for dP = dO V^T and dS); s multiplies everything
+// below half's normal range (2^-14), so each (image, head) slice of dO is multiplied by a power of two s chosen from its largest
+// magnitude (mv_attention_bwd_prep_f16: max |dO| -> 2^8, which leaves 2^8 of headroom for dP = dO V^T and dS); s multiplies everything
 // linear in dO -- delta, dP, dS, dQ, dK, dV -- and the kernel divides it out of its fp32 outputs, exactly (a power of two).
-__global__ void attn_absmax_kernel(const float* __restrict__ x, long n, unsigned* __restrict__ amax_bits) {
-  float m = 0.f;
-  const long n4 = n >> 2;
-  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long)gridDim.x * blockDim.x) {
-    const float4 v = reinterpret_cast<const float4*>(x)[i];
-    m = fmaxf(fmaxf(fmaxf(fabsf(v.x), fabsf(v.y)), fmaxf(fabsf(v.z), fabsf(v.w))), m);
-  }
-  for (long i = (n4 << 2) + (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x)
-    m = fmaxf(m, fabsf(x[i]));
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
-  if ((threadIdx.x & 63) == 0 && m > 0.f && m == m) atomicMax(amax_bits, __float_as_uint(m));   // non-negative floats order as their bits
-}
-// s = 2^(8 - ceil(log2(amax))) (1 for an all-zero or non-finite gradient), computed identically by every thread that needs it
-__device__ __forceinline__ float attn_grad_scale(unsigned amax_bits) {
-  const float a = __uint_as_float(amax_bits);
+// s = 2^(8 - ceil(log2(amax))) (1 for an all-zero or non-finite gradient)
+__device__ __forceinline__ float attn_grad_scale(float a) {
   if (!(a > 0.f) || a > 3.0e38f) return 1.0f;
   int e;
   frexpf(a, &e);                                          // a = f * 2^e, f in [0.5, 1)  ->  a * 2^(8 - e) in [2^7, 2^8)
@@ -1564,33 +1553,43 @@ __device__ __forceinline__ float attn_grad_scale(unsigned amax_bits) {
   e = e > 100 ? 100 : (e < -100 ? -100 : e);
   return ldexpf(1.0f, e);
 }
-// one thread per (token row, head, 8 features): dO * s -> half, delta = s * sum_d dO O over the head's 64 features (8 lanes)
+// One workgroup per (image, head): pass 1 = the largest |dO| of the head's [N, 64] slice -> its scale s; pass 2 (the slice is
+// 50 KB: still in L2) = dO * s -> half, delta[b, h, n] = sum_d half(dO s)_d O_d.  Thread = (row tid >> 4 of 16, four features).
+// delta uses the ROUNDED gradient: the kernel's dP = dO16 V16^T is exact in fp32 and the forward's O = sum_k P16_k V16_k, so
+// sum_d dO16_d O_d = sum_k P16_k dP_k and the cancellation in dS = P (dP - delta) is consistent (with the unrounded dO the two
+// sides of that difference carried different roundings).
 __global__ __launch_bounds__(256) void attn_bwd_prep_f16_kernel(const float* __restrict__ dout, const float* __restrict__ out,
-                                                                const unsigned* __restrict__ amax_bits, _Float16* __restrict__ dout16,
-                                                                float* __restrict__ delta, float* __restrict__ gscale, long rows,
-                                                                int N, int H) {
-  const float s = attn_grad_scale(*amax_bits);
-  if (blockIdx.x == 0 && threadIdx.x == 0) *gscale = s;
-  const long total = rows * H * 8;
-  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
-    const long row = i / (H * 8);
-    const int hc = (int)(i - row * (H * 8)), h = hc >> 3;
-    const float4 a0 = *reinterpret_cast<const float4*>(dout + row * H * 64 + hc * 8);
-    const float4 a1 = *reinterpret_cast<const float4*>(dout + row * H * 64 + hc * 8 + 4);
-    const float4 o0 = *reinterpret_cast<const float4*>(out + row * H * 64 + hc * 8);
-    const float4 o1 = *reinterpret_cast<const float4*>(out + row * H * 64 + hc * 8 + 4);
-    const float d[8] = {a0.x * s, a0.y * s, a0.z * s, a0.w * s, a1.x * s, a1.y * s, a1.z * s, a1.w * s};
-    float dl = d[0] * o0.x + d[1] * o0.y + d[2] * o0.z + d[3] * o0.w + d[4] * o1.x + d[5] * o1.y + d[6] * o1.z + d[7] * o1.w;
-    const f16x8_t w = {(_Float16)d[0], (_Float16)d[1], (_Float16)d[2], (_Float16)d[3],
-                       (_Float16)d[4], (_Float16)d[5], (_Float16)d[6], (_Float16)d[7]};
-    *reinterpret_cast<f16x8_t*>(dout16 + row * H * 64 + hc * 8) = w;
+                                                                _Float16* __restrict__ dout16, float* __restrict__ delta,
+                                                                float* __restrict__ gscale, int N, int H) {
+  __shared__ float red[4];
+  const int b = blockIdx.x / H, h = blockIdx.x % H, tid = threadIdx.x;
+  const long D = (long)H * 64;
+  const float* db = dout + (long)b * N * D + h * 64 + 4 * (tid & 15);
+  const float* ob = out + (long)b * N * D + h * 64 + 4 * (tid & 15);
+  _Float16* wb = dout16 + (long)b * N * D + h * 64 + 4 * (tid & 15);
+  float m = 0.f;
+  for (int r = tid >> 4; r < N; r += 16) {
+    const float4 v = *reinterpret_cast<const float4*>(db + (long)r * D);
+    m = fmaxf(fmaxf(fmaxf(fabsf(v.x), fabsf(v.y)), fmaxf(fabsf(v.z), fabsf(v.w))), m);
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
+  if ((tid & 63) == 0) red[tid >> 6] = m;
+  __syncthreads();
+  m = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+  const float s = attn_grad_scale(m == m ? m : 0.f);
+  if (tid == 0) gscale[blockIdx.x] = s;
+  for (int r = tid >> 4; r < N; r += 16) {
+    const float4 v = *reinterpret_cast<const float4*>(db + (long)r * D);
+    const float4 o = *reinterpret_cast<const float4*>(ob + (long)r * D);
+    const f16x4_t w = {(_Float16)(v.x * s), (_Float16)(v.y * s), (_Float16)(v.z * s), (_Float16)(v.w * s)};
+    *reinterpret_cast<f16x4_t*>(wb + (long)r * D) = w;
+    float dl = (float)w[0] * o.x + (float)w[1] * o.y + (float)w[2] * o.z + (float)w[3] * o.w;
     dl += __shfl_xor(dl, 1, 64);
     dl += __shfl_xor(dl, 2, 64);
     dl += __shfl_xor(dl, 4, 64);
-    if ((hc & 7) == 0) {
-      const long b = row / N, n = row - b * N;
-      delta[(b * H + h) * N + n] = dl;
-    }
+    dl += __shfl_xor(dl, 8, 64);
+    if ((tid & 15) == 0) delta[((long)b * H + h) * N + r] = dl;
   }
 }
 
@@ -1608,25 +1607,12 @@ extern "C" int mv_attention_fwd_f16(const void* qkv16, float* out, float* lse, i
   return MV_OK;
 }
 
-extern "C" size_t mv_attention_bwd_prep_f16_workspace_bytes(void) { return 256; }
-
 extern "C" int mv_attention_bwd_prep_f16(const float* dout, const float* out, void* dout16, float* delta, float* gscale,
-                                         void* workspace, int B, int N, int H, mv_stream_t stream) {
+                                         int B, int N, int H, mv_stream_t stream) {
   MV_REQUIRE(B >= 0 && N > 0 && H > 0, MV_ERR_SHAPE);
-  MV_REQUIRE(mv_aligned16(dout) && mv_aligned16(out) && mv_aligned16(dout16) && workspace && gscale && delta, MV_ERR_ALIGN);
+  MV_REQUIRE(mv_aligned16(dout) && mv_aligned16(out) && mv_aligned16(dout16) && gscale && delta, MV_ERR_ALIGN);
   if (B == 0) return MV_OK;
-  hipStream_t s = (hipStream_t)stream;
-  unsigned* amax = reinterpret_cast<unsigned*>(workspace);
-  mv_zero_f32_kernel<<<1, 64, 0, s>>>(reinterpret_cast<float*>(amax), 1);
-  const long n = (long)B * N * H * 64;
-  int grid = (int)((n / 4 + 255) / 256);
-  if (grid > 2048) grid = 2048;
-  if (grid < 1) grid = 1;
-  attn_absmax_kernel<<<grid, 256, 0, s>>>(dout, n, amax);
-  const long total = (long)B * N * H * 8;
-  int g2 = (int)((total + 255) / 256);
-  if (g2 > 4096) g2 = 4096;
-  attn_bwd_prep_f16_kernel<<<g2, 256, 0, s>>>(dout, out, amax, (_Float16*)dout16, delta, gscale, (long)B * N, N, H);
+  attn_bwd_prep_f16_kernel<<<B * H, 256, 0, (hipStream_t)stream>>>(dout, out, (_Float16*)dout16, delta, gscale, N, H);
   MV_CHECK_LAUNCH();
   return MV_OK;
 }

@@ -50,8 +50,7 @@ SIGNATURES = {
     "mv_attention_bwd": ("pppppp" "iii" "f" "p", _I),
     "mv_attention_fwd_f32": ("pp" "iii" "f" "p", _I),
     "mv_attention_fwd_f16": ("ppp" "iii" "f" "p", _I),
-    "mv_attention_bwd_prep_f16_workspace_bytes": ("", _Z),
-    "mv_attention_bwd_prep_f16": ("pppppp" "iii" "p", _I),
+    "mv_attention_bwd_prep_f16": ("ppppp" "iii" "p", _I),
     "mv_attention_bwd_f16": ("pppppp" "iii" "f" "p", _I),
     "mv_softmax_fwd": ("pp" "li" "f" "p", _I),
     "mv_softmax_bwd": ("ppp" "li" "f" "p", _I),

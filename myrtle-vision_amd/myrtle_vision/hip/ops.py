@@ -770,9 +770,8 @@ def attention_bwd_f16(qkv16, out, dout, lse, B, N, H, scale):
     dev = qkv16.device
     dout16 = torch.empty(B, N, H * 64, dtype=torch.float16, device=dev)
     delta = torch.empty(B, H, N, dtype=torch.float32, device=dev)
-    gscale = torch.empty(1, dtype=torch.float32, device=dev)
-    ws = workspace(lib().mv_attention_bwd_prep_f16_workspace_bytes(), dev)
-    check(lib().mv_attention_bwd_prep_f16(_p(dout), _p(out), _p(dout16), _p(delta), _p(gscale), _p(ws), B, N, H, _s()),
+    gscale = torch.empty(B * H, dtype=torch.float32, device=dev)
+    check(lib().mv_attention_bwd_prep_f16(_p(dout), _p(out), _p(dout16), _p(delta), _p(gscale), B, N, H, _s()),
           "attention_bwd_prep_f16", B=B, N=N, H=H)
     dqkv = torch.empty(B, N, 3 * H * 64, dtype=torch.float32, device=dev)
     check(lib().mv_attention_bwd_f16(_p(qkv16), _p(dout16), _p(delta), _p(lse), _p(gscale), _p(dqkv), B, N, H, scale, _s()),

@@ -117,7 +117,7 @@ def check_case(name, precision, tol_logits, tol_grad, q_format=None, **extra):
             continue
         w = arrays[f"gsum:{c}"]
         got = summarize(p.grad.float().cpu()).numpy()
-        if precision in EXACT:
+        if precision in EXACT and precision != "bf16x3h":
             # [sum, l2, absmax, weighted sum] against the l2 scale; first 16 values against absmax
             e = max(np.abs(got[:4] - w[:4]).max() / max(w[1], 1e-30), np.abs(got[4:] - w[4:]).max() / max(w[2], 1e-30))
         else:
@@ -197,10 +197,36 @@ def test_bf16x3_matches_reference(name):
 @pytest.mark.parametrize("name", CASES)
 def test_bf16x3h_matches_reference(name):
     """``precision="bf16x3h"``: bf16x3 with the attention core on IEEE-half operands (fp32 sums, softmax and outputs; 197-token
-    models -- the 257-token fixtures run the fp32 core as in bf16x3).  Logits and loss at north_star's 1e-3 (measured <= 1.6e-4)
-    and bit-exact class indices; gradients at 3e-3 (measured <= 1.6e-3 on ViT-B: each layer's q and k carry a 2^-12 rounding under
-    the exponential, a per-layer Jacobian error of ~1e-4 that adds up over twelve layers; bf16 mode: 1.2e-2)."""
-    check_case(name, "bf16x3h", 1e-3, 3e-3)
+    models -- the 257-token fixtures run the fp32 core as in bf16x3).  Against the REFERENCE: logits and loss at north_star's 1e-3
+    (measured <= 1.6e-4), bit-exact class indices, gradient norms and sampled values at 1e-3; every gradient element is held to
+    1e-3 (relative L2 per tensor) through the fp32 mode in test_bf16x3h_vs_fp32_full_tensors."""
+    check_case(name, "bf16x3h", 1e-3, 1e-3)
+
+
+@pytest.mark.parametrize("name", CASES)
+def test_bf16x3h_vs_fp32_full_tensors(name):
+    """Full-tensor chain for the gradients of ``bf16x3h``: reference -(summaries to 1e-3, measured 4e-5)-> fp32 HIP -(here: EVERY
+    element of EVERY gradient tensor)-> bf16x3h HIP.  Bar 1e-3 relative L2 per tensor (measured <= 4.5e-4 on ViT-B and ViT-Tiny at
+    depth 12; bf16 mode: 1.0e-2) and 1e-3 on the logits.  (The fixtures' summaries hold plain and position-weighted SUMS over up
+    to 2.4 M elements against the l2 scale, which multiplies a correlated error of 1e-6 per element a thousand-fold: fit for the
+    fp32-accurate modes, not a measure of a 2^-12 arithmetic -- test_bf16x3h_matches_reference compares norms and sampled values.)"""
+    from myrtle_vision.hip.functional import cross_entropy
+    res = {}
+    for prec in ("fp32", "bf16x3h"):
+        vit, img, labels, arrays, meta = build(name, prec)
+        logits = vit(img)
+        cross_entropy(logits, labels).backward()
+        res[prec] = (logits.detach().float(), {k: p.grad.float() for k, p in vit.named_parameters() if p.grad is not None})
+    l32, lh = res["fp32"][0], res["bf16x3h"][0]
+    e = float((l32 - lh).abs().max() / l32.abs().max())
+    report(f"{name}/bf16x3h-vs-fp32 logits", e)
+    assert e < 1e-3
+    worst = 0.0
+    for k, g32 in res["fp32"][1].items():
+        e = float((g32 - res["bf16x3h"][1][k]).norm() / g32.norm().clamp_min(1e-30))
+        worst = max(worst, e)
+        assert e < 1e-3, (k, e)
+    report(f"{name}/bf16x3h-vs-fp32 grad-rel-l2", worst)
 
 
 @pytest.mark.parametrize("name,precision", [("micro_cls", "fp32"), ("micro_cls_256", "fp32"), ("tiny_cls", "fp32"), ("base_cls", "fp32"),
@@ -212,8 +238,7 @@ def test_prune_dead_tokens_changes_nothing(name, precision):
     itself: fp32 modes to fp32 rounding (the two run the last MLP's products over different row counts, i.e. kernels)."""
     from myrtle_vision.hip.functional import cross_entropy
     exact = precision in EXACT
-    check_case(name, precision, 1e-3 if exact else BF16_LOGITS, 3e-3 if precision == "bf16x3h" else 1e-3 if exact else 3e-2,
-               prune_dead_tokens=True)
+    check_case(name, precision, 1e-3 if exact else BF16_LOGITS, 1e-3 if exact else 3e-2, prune_dead_tokens=True)
     outs = []
     for prune in (False, True):
         vit, img, labels, _, _ = build(name, precision, prune_dead_tokens=prune)
