@@ -29,7 +29,7 @@ extern "C" {
 
 typedef void* mv_stream_t; /* hipStream_t */
 
-enum { MV_F32 = 0, MV_BF16 = 1, MV_I8 = 2 /* mv_gemm_nt_i8 with MV_EPI_GELU_Q8 only */, MV_F16 = 3 /* mv_cast destination only */ };
+enum { MV_F32 = 0, MV_BF16 = 1, MV_I8 = 2 /* mv_gemm_nt_i8 with MV_EPI_GELU_Q8 only */, MV_F16 = 3 /* IEEE half: mv_cast destination, mv_gemm_nt_bf16 output with MV_EPI_NONE */ };
 
 enum {
   MV_OK = 0,

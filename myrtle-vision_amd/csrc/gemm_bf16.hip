@@ -76,8 +76,9 @@ __device__ __forceinline__ void store4(CT* p, const float v[4], bool vec, int nv
     if constexpr (sizeof(CT) == 4) {
       *reinterpret_cast<float4*>(p) = make_float4(v[0], v[1], v[2], v[3]);
     } else {
-      bf16x4 o = {(bf16_t)v[0], (bf16_t)v[1], (bf16_t)v[2], (bf16_t)v[3]};
-      *reinterpret_cast<bf16x4*>(p) = o;
+      typedef CT ct4 __attribute__((ext_vector_type(4)));       // bf16 or IEEE half
+      const ct4 o = {(CT)v[0], (CT)v[1], (CT)v[2], (CT)v[3]};
+      *reinterpret_cast<ct4*>(p) = o;
     }
   } else {
 #pragma unroll
@@ -165,9 +166,11 @@ __device__ __forceinline__ float dgelu_fast(float x) {
 // lanes with even lane>>4 (l <-> l^16).  Afterwards lane g = lane>>4 owns 8 consecutive columns (16 bytes) of ONE tile:
 //   tile j0 + (g&1), columns 8 (g>>1) .. +7   ->   half as many, twice as wide stores (the store tail of a 256x256
 // bf16 tile is issue-bound: 32 dwordx2 per lane before, 16 dwordx4 now; cdna guide T21).
+template <typename CT = bf16_t>
 __device__ __forceinline__ u32x4 pair_swap_bf16(const float (&va)[4], const float (&vb)[4]) {
-  const bf16x4 pa = {(bf16_t)va[0], (bf16_t)va[1], (bf16_t)va[2], (bf16_t)va[3]};
-  const bf16x4 pb = {(bf16_t)vb[0], (bf16_t)vb[1], (bf16_t)vb[2], (bf16_t)vb[3]};
+  typedef CT ct4 __attribute__((ext_vector_type(4)));         // bf16 (default) or IEEE half (MV_F16 outputs, round 4)
+  const ct4 pa = {(CT)va[0], (CT)va[1], (CT)va[2], (CT)va[3]};
+  const ct4 pb = {(CT)vb[0], (CT)vb[1], (CT)vb[2], (CT)vb[3]};
   typedef unsigned u32x2_t __attribute__((ext_vector_type(2)));
   const u32x2_t a = __builtin_bit_cast(u32x2_t, pa), b = __builtin_bit_cast(u32x2_t, pb);
   const u32x2_t r0 = __builtin_amdgcn_permlane16_swap(a[0], b[0], false, false);
@@ -374,7 +377,7 @@ __device__ __forceinline__ void nt_epilogue(f32x4 (&acc)[4][4], CT* __restrict__
                 st16(reinterpret_cast<bf16_t*>(ep.out2) + (long)(mb + i * 16) * ep.ld_out2 + nw + 32 * jp,
                      pair_swap_bf16(hpre[0], hpre[1]));
             }
-            st16(C + crow[i] * ldc + nw + 32 * jp, pair_swap_bf16(v[0], v[1]));
+            st16(C + crow[i] * ldc + nw + 32 * jp, pair_swap_bf16<CT>(v[0], v[1]));
           }
           if constexpr (EPI == MV_EPI_GELU_GRAD8) {
             // The lane holds one word (4 codes = columns 4g .. 4g+3) of each of the four 16-column tiles.  A 4 x 4 transpose
@@ -1824,6 +1827,8 @@ extern "C" int mv_gemm_nt_bf16_scaled(const void* A, int lda, const void* B, int
   EpiArgs ep{alpha, bias, aux, ld_aux, aux_i, out2, ld_out2, nullptr, 0.f, 0.f};
   switch (epilogue) {
     case MV_EPI_NONE:
+      if (c_dtype == MV_F16)       // IEEE-half output (round 4: q / k / v of precision "bf16x3h", straight from the to_qkv product)
+        return launch_nt<MV_EPI_NONE, _Float16>(A, lda, B, ldb, C, ldc, M, N, K, ep, s);
       return c_dtype == MV_F32 ? launch_nt<MV_EPI_NONE, float>(A, lda, B, ldb, C, ldc, M, N, K, ep, s)
                                : launch_nt<MV_EPI_NONE, bf16_t>(A, lda, B, ldb, C, ldc, M, N, K, ep, s);
     case MV_EPI_GELU:

@@ -532,16 +532,15 @@ class _AttnBlock(Function):
             # output (what the forward and the dW products both read), not the tensors themselves
             dh = inner // heads
             y6 = ops.split_ex(y, M, D)
-            qkv = torch.empty(B, T, inner3, dtype=adt, device=x.device)
+            ctx.f16 = ops.attention_f16_supported(adt, T, dh)
+            # precision "bf16x3h": the fused attention kernels on half operands (2^-12 per rounding, fp32 sums, softmax and outputs);
+            # q / k / v leave the to_qkv product as half (one rounding of the fp32 accumulator + bias, no fp32 tensor, no cast pass)
+            qkv = torch.empty(B, T, inner3, dtype=torch.float16 if ctx.f16 else adt, device=x.device)
             ops.nt_x6(y6, wqkv, "fwd", M, qkv.view(M, inner3), bias=bqkv)
             o = None
-            ctx.f16 = False
-            if ops.attention_f16_supported(adt, T, dh):
-                # precision "bf16x3h": the fused attention kernels on half operands (2^-12 per rounding, fp32 sums, softmax and
-                # outputs); the half copy of q/k/v replaces the fp32 tensor among the saved activations
-                qkv = ops.cast_f16(qkv)
+            if ctx.f16:
                 o, probs = ops.attention_fwd_f16(qkv, B, T, heads, scale)            # "probs" slot: the log-sum-exp [B, H, T]
-                ctx.fused32, ctx.f16 = True, True
+                ctx.fused32 = True
             elif ops.attention_f32_fused_supported(adt, T, dh):
                 if any(ctx.needs_input_grad):
                     o, probs = ops.attention_fwd_f32_lse(qkv, B, T, heads, scale)   # "probs" slot: the log-sum-exp [B, H, T]

@@ -580,8 +580,9 @@ def _nt_x6(a6, b6, out, ldc, M, N, Kc, bias, epi, aux=None, ld_aux=0, aux_i=0, t
     Kx = nseg * Kc
     t0 = _timer.begin() if _timer is not None else None
     S = _x6_ksplits(M, N) if epi in (EPI_NONE, EPI_RESIDUAL) and ldc == N and (aux is None or ld_aux == N) else 1
-    if S > 1 and Kx % (128 * S) != 0:
+    if S > 1 and (Kx % (128 * S) != 0 or out.dtype != torch.float32):
         S = 1
+    c_dt = MV_F32 if out.dtype == torch.float32 else _l.MV_F16       # half output: q / k / v of precision "bf16x3h" (EPI_NONE only)
     if S > 1:
         slabs = workspace(S * M * N * 4, out.device)
         check(lib().mv_gemm_nt_bf16_ksplit(_p(a6), Kx, _p(b6), Kx, _p(slabs), M, N, Kx, S, _p(bias), _s()),
@@ -591,7 +592,7 @@ def _nt_x6(a6, b6, out, ldc, M, N, Kc, bias, epi, aux=None, ld_aux=0, aux_i=0, t
         if t0 is not None:
             _timer.end(f"gemm_nt_bf16x{nseg}", t0, 2.0 * M * N * Kc, shape=f"{tag} N{N} K{Kc} epi{epi} S{S}")
         return
-    check(lib().mv_gemm_nt_bf16(_p(a6), Kx, _p(b6), Kx, _p(out), ldc, MV_F32, M, N, Kx, _p(bias), epi, _p(aux),
+    check(lib().mv_gemm_nt_bf16(_p(a6), Kx, _p(b6), Kx, _p(out), ldc, c_dt, M, N, Kx, _p(bias), epi, _p(aux),
                                 ld_aux, aux_i, None, 0, _s()), f"gemm_nt_bf16(x{nseg})", M=M, N=N, K=Kx, epi=epi)
     if t0 is not None:
         _timer.end(f"gemm_nt_bf16x{nseg}", t0, 2.0 * M * N * Kc, shape=f"{tag} N{N} K{Kc} epi{epi}")

@@ -220,6 +220,18 @@ def test_gemm_nt_8phase_optional_features(ops, M, N, K):
         return outs
 
     got = {}
+    # round 4: IEEE-half output (MV_EPI_NONE) = the fp32 result rounded once, on the 8-phase and on the 128-tile kernels
+    for variant in (2568, 128):
+        check(lib().mv_gemm_force_variant(variant, 0), "force_variant")
+        try:
+            o32 = torch.full((M, N), float("nan"), device="cuda"); ops.linear_fwd(ad, M, K, wd, bd, o32, N)
+            o16 = torch.full((M, ldn), float("nan"), device="cuda", dtype=torch.float16)
+            check(lib().mv_gemm_nt_bf16(ad.data_ptr(), K, ops.prepared_weight(wd).w.data_ptr(), ops.prepared_weight(wd).ldw,
+                                        o16.data_ptr(), ldn, 3, M, N, K, bd.data_ptr(), ops.EPI_NONE, None, 0, 0, None, 0,
+                                        torch.cuda.current_stream().cuda_stream), "gemm_nt_bf16(f16 out)")
+            assert torch.equal(o16[:, :N], o32.half())
+        finally:
+            check(lib().mv_gemm_force_variant(0, 0), "force_variant")
     for variant in (2568, 3100, 3102):
         check(lib().mv_gemm_force_variant(variant, 0), "force_variant")
         try:
