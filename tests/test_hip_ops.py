@@ -229,7 +229,11 @@ def test_gemm_nt_8phase_optional_features(ops, M, N, K):
             check(lib().mv_gemm_nt_bf16(ad.data_ptr(), K, ops.prepared_weight(wd).w.data_ptr(), ops.prepared_weight(wd).ldw,
                                         o16.data_ptr(), ldn, 3, M, N, K, bd.data_ptr(), ops.EPI_NONE, None, 0, 0, None, 0,
                                         torch.cuda.current_stream().cuda_stream), "gemm_nt_bf16(f16 out)")
-            assert torch.equal(o16[:, :N], o32.half())
+            # one rounding of the fp32 result: within half an ulp of half everywhere, and the same value as torch's cast except
+            # on exact ties (about 2^-13 of random data: the hardware conversion and torch break them differently)
+            got16 = o16[:, :N].float()
+            assert bool(((got16 - o32).abs() <= o32.abs() * 2.0 ** -11 + 2.0 ** -24).all())
+            assert float((o16[:, :N] != o32.half()).float().mean()) < 2e-4
         finally:
             check(lib().mv_gemm_force_variant(0, 0), "force_variant")
     for variant in (2568, 3100, 3102):
@@ -666,13 +670,14 @@ def test_attention_f16_fwd_bwd(ops, B, N, H, gscale):
     qkv = torch.randn(B, N, 3 * H * 64, generator=g(1)) * 1.2
     dout = torch.randn(B, N, H * 64, generator=g(2)) * gscale
     q16 = ops.cast_f16(qkv.cuda())
-    assert q16.dtype == torch.float16 and torch.equal(q16.cpu(), qkv.half())
-    ref_in = qkv.half().double().requires_grad_(True)
+    assert q16.dtype == torch.float16 and float((q16.cpu() != qkv.half()).float().mean()) < 2e-4       # (ties: see the GEMM test)
+    assert bool(((q16.cpu().float() - qkv).abs() <= qkv.abs() * 2.0 ** -11 + 2.0 ** -24).all())
+    ref_in = q16.cpu().double().requires_grad_(True)
     want, _ = attn_ref(ref_in, H, scale)
     want.backward(dout.double())
     out, lse = ops.attention_fwd_f16(q16, B, N, H, scale)
     assert out.dtype == torch.float32 and relerr(out, want) < 6e-4
-    q, k, _ = qkv.half().double().view(B, N, 3, H, 64).permute(2, 0, 3, 1, 4)
+    q, k, _ = q16.cpu().double().view(B, N, 3, H, 64).permute(2, 0, 3, 1, 4)
     assert float((lse.cpu().double() - torch.logsumexp((q @ k.transpose(-2, -1)) * scale, dim=-1)).abs().max()) < 2e-5
     dqkv = ops.attention_bwd_f16(q16, out, dout.cuda(), lse, B, N, H, scale)
     assert dqkv.dtype == torch.float32 and bool(torch.isfinite(dqkv).all())
