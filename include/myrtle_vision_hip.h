@@ -78,6 +78,11 @@ size_t mv_layernorm_bwd_workspace_bytes(int rows, int dim);
  * y: y_dtype [rows, dim] dense; mean/rstd: fp32 [rows] (saved for backward). */
 int mv_layernorm_fwd(const float* x, long ldx, const float* gamma, const float* beta, void* y, int y_dtype,
                      float* mean, float* rstd, int rows, int dim, float eps, mv_stream_t stream);
+/* The same LayerNorm with the output leaving as the bf16 pieces of the split-operand Linear products (nseg = 6: mv_split3_bf16's
+ * role-0 side-by-side layout [rows, 6 * dim], nseg = 3: mv_split2_bf16's [rows, 3 * dim]); bit-identical to mv_layernorm_fwd (fp32)
+ * followed by the split, without the fp32 tensor in between.  dim <= 1024. */
+int mv_layernorm_fwd_split(const float* x, long ldx, const float* gamma, const float* beta, void* y_split, int nseg, float* mean,
+                           float* rstd, int rows, int dim, float eps, mv_stream_t stream);
 /* dx[rows, dim] (fp32, row stride lddx) = dLN(dy) (+ dx_add if non-null, same layout as dx; may alias dx);
  * dgamma/dbeta: fp32 [dim], overwritten (accumulate=0) or added to (accumulate=1).
  * Optional fused by-products for the consumer of dx in the backward chain (both may be NULL):
@@ -143,12 +148,14 @@ int mv_attention_bwd(const void* qkv, const void* out, const void* dout, const f
  * out / lse as mv_attention_fwd but out is fp32.  Backward: mv_attention_bwd_prep_f16 turns the fp32 dout [B, N, H*64] into half
  * scaled, per (image, head), by a power of two s (the slice's largest magnitude -> [2^7, 2^8): gradients lie below half's normal
  * range otherwise), leaves s in gscale[b * H + h] (device, fp32 [B * H]) and delta[b, h, n] = sum_d half(dout * s) * out.
- * mv_attention_bwd_f16 then writes dqkv fp32 [B, N, 3, H, 64] with s divided out (exactly). */
+ * mv_attention_bwd_f16 then writes dqkv with s divided out (exactly): nseg = 0: fp32 [B, N, 3, H, 64]; nseg = 3 / 6: the bf16 pieces of
+ * the split-operand products ([B * N, nseg * 3 * H * 64], mv_split2_bf16 / mv_split3_bf16 role 0) -- the dY operand of to_qkv's dW
+ * and dX products without an fp32 tensor and a split pass; colsum (optional) as mv_attention_bwd. */
 int mv_attention_fwd_f16(const void* qkv16, float* out, float* lse, int B, int N, int H, float scale, mv_stream_t stream);
 int mv_attention_bwd_prep_f16(const float* dout, const float* out, void* dout16, float* delta, float* gscale, int B, int N, int H,
                               mv_stream_t stream);
 int mv_attention_bwd_f16(const void* qkv16, const void* dout16, const float* delta, const float* lse, const float* gscale,
-                         float* dqkv, int B, int N, int H, float scale, mv_stream_t stream);
+                         void* dqkv, int nseg, float* colsum, int B, int N, int H, float scale, mv_stream_t stream);
 /* Test / tuning hook (process-global, atomic, like mv_gemm_force_variant): backward kernel for the following
  * mv_attention_bwd calls -- 0 auto (N <= 208: 4; N <= 288: 2; else 8), 4 = dS exchanged through LDS (N <= 208), 5 = the same
  * with two waves of 512 registers per workgroup (192 < N <= 208; equal results up to the placement of the softmax scale), 2 = two

@@ -768,7 +768,10 @@ __global__ __launch_bounds__(512, 1) void attn_bwd_kernel(const bf16_t* __restri
 // F16 (precision "bf16x3"): half operands; dout arrives multiplied by a power of two s = *gscale that brings the gradient into
 // half's range (mv_attention_bwd_prep_f16), delta_in = s * rowsum(dO . O) comes precomputed (no O loads), and dQ / dK / dV leave as
 // fp32 times 1 / s.
-template <int NW, bool F16 = false>   // waves per workgroup: 4 (256 registers per lane) or 2 (one wave per SIMD: 512)
+// SPLIT = 3 / 6 (F16 only): dQ / dK / dV leave as the bf16 PIECES of the split-operand products (mv_split2_bf16 / mv_split3_bf16 role 0,
+// rows of SPLIT * 3 D, segments 3 D apart) instead of fp32 -- the dY operand of to_qkv's dW and dX products, without an fp32 dqkv and
+// a split pass over it (8 B per element of traffic per layer); the bias gradient comes from the kernel's own column sums.
+template <int NW, bool F16 = false, int SPLIT = 0>   // waves per workgroup: 4 (256 registers per lane) or 2 (one wave per SIMD: 512)
 __global__ __launch_bounds__(64 * NW, NW / 2) void attn_bwd4_kernel(const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ out,
                                                            const bf16_t* __restrict__ dout, const float* __restrict__ lse,
                                                            bf16_t* __restrict__ dqkv, float* __restrict__ colsum, int N, int H,
@@ -810,6 +813,27 @@ __global__ __launch_bounds__(64 * NW, NW / 2) void attn_bwd4_kernel(const bf16_t
   [[maybe_unused]] const float inv_s = F16 ? 1.0f / gscale[blockIdx.x] : 1.0f;
   [[maybe_unused]] const float inv_ss = inv_s * scale;      // F16: dS^T leaves without the softmax scale (3 more bits above half's underflow)
   [[maybe_unused]] float* const dbase32 = reinterpret_cast<float*>(dqkv) + (long)b * N * 3 * D + h * 64;
+  // F16 output of four consecutive features at (token row, column col of this head's slice of q | k | v)
+  auto put4 = [&](long row, int col, f32x4 v) __attribute__((always_inline)) {
+    if constexpr (SPLIT == 0) {
+      *reinterpret_cast<f32x4*>(dbase32 + row * 3 * D + col) = v;
+    } else {
+      bf16_t* o = dqkv + ((long)b * N + row) * (SPLIT * 3 * D) + h * 64 + col;
+      bf16x4 p[3];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const bf16_t p0 = (bf16_t)v[e];
+        const float r1 = v[e] - (float)p0;
+        const bf16_t p1 = (bf16_t)r1;
+        p[0][e] = p0;
+        p[1][e] = p1;
+        p[2][e] = (bf16_t)(r1 - (float)p1);
+      }
+      constexpr int order[6] = {0, 0, 1, 0, 1, 2};
+#pragma unroll
+      for (int sg = 0; sg < SPLIT; ++sg) *reinterpret_cast<bf16x4*>(o + (long)sg * 3 * D) = p[order[sg]];
+    }
+  };
 
   // pair staging: 2 tiles x 32 rows x 8 chunks = 512 chunks, PE = 512 / NT per thread (the first half Q, the second dO)
   constexpr int PE = 512 / NT;
@@ -1106,8 +1130,8 @@ __global__ __launch_bounds__(64 * NW, NW / 2) void attn_bwd4_kernel(const bf16_t
         }
         if constexpr (F16) {
           if (q < N) {
-            *reinterpret_cast<f32x4*>(dbase32 + (long)q * 3 * D + 16 * (2 * dh) + 4 * g) = dq[tq][0] * inv_ss;
-            *reinterpret_cast<f32x4*>(dbase32 + (long)q * 3 * D + 16 * (2 * dh + 1) + 4 * g) = dq[tq][1] * inv_ss;
+            put4(q, 16 * (2 * dh) + 4 * g, dq[tq][0] * inv_ss);
+            put4(q, 16 * (2 * dh + 1) + 4 * g, dq[tq][1] * inv_ss);
           }
         } else {
         const u32x4 dqw = pair16(dq[tq][0], dq[tq][1]);      // (every lane executes the exchange)
@@ -1135,8 +1159,8 @@ __global__ __launch_bounds__(64 * NW, NW / 2) void attn_bwd4_kernel(const bf16_t
         if (key < N) {
 #pragma unroll
           for (int dt = 0; dt < 4; ++dt) {
-            *reinterpret_cast<f32x4*>(dbase32 + (long)key * 3 * D + D + 16 * dt + 4 * g) = adk[i][dt] * inv_ss;
-            *reinterpret_cast<f32x4*>(dbase32 + (long)key * 3 * D + 2 * D + 16 * dt + 4 * g) = adv[i][dt] * inv_s;
+            put4(key, (int)D + 16 * dt + 4 * g, adk[i][dt] * inv_ss);
+            put4(key, 2 * (int)D + 16 * dt + 4 * g, adv[i][dt] * inv_s);
           }
         }
       } else {
@@ -1158,7 +1182,7 @@ __global__ __launch_bounds__(64 * NW, NW / 2) void attn_bwd4_kernel(const bf16_t
     const int dq_d0 = 32 * (NW == 4 ? (wave & 1) : wave);
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
-      const float v0 = rowsum16(dqs0[r]), v1 = rowsum16(dqs1[r]);
+      const float v0 = rowsum16(dqs0[r]) * (F16 ? inv_ss : 1.0f), v1 = rowsum16(dqs1[r]) * (F16 ? inv_ss : 1.0f);
       if ((lane & 15) == 0) {
         red[wave * 192 + dq_d0 + 4 * g + r] = v0;
         red[wave * 192 + dq_d0 + 16 + 4 * g + r] = v1;
@@ -1174,8 +1198,8 @@ __global__ __launch_bounds__(64 * NW, NW / 2) void attn_bwd4_kernel(const bf16_t
           vk += adk[i][dt][r];
           vv += adv[i][dt][r];
         }
-        vk = rowsum16(vk);
-        vv = rowsum16(vv);
+        vk = rowsum16(vk) * (F16 ? inv_ss : 1.0f);
+        vv = rowsum16(vv) * (F16 ? inv_s : 1.0f);
         if ((lane & 15) == 0) {
           red[wave * 192 + 64 + dt * 16 + 4 * g + r] = vk;
           red[wave * 192 + 128 + dt * 16 + 4 * g + r] = vv;
@@ -1618,16 +1642,23 @@ extern "C" int mv_attention_bwd_prep_f16(const float* dout, const float* out, vo
 }
 
 extern "C" int mv_attention_bwd_f16(const void* qkv16, const void* dout16, const float* delta, const float* lse,
-                                    const float* gscale, float* dqkv, int B, int N, int H, float scale, mv_stream_t stream) {
+                                    const float* gscale, void* dqkv, int nseg, float* colsum, int B, int N, int H, float scale,
+                                    mv_stream_t stream) {
   MV_REQUIRE(B >= 0 && N > 0 && H > 0, MV_ERR_SHAPE);
-  MV_REQUIRE(N <= 208, MV_ERR_UNSUPPORTED);
+  MV_REQUIRE(N <= 208 && (nseg == 0 || nseg == 3 || nseg == 6), MV_ERR_UNSUPPORTED);
   MV_REQUIRE(mv_aligned16(qkv16) && mv_aligned16(dout16) && mv_aligned16(dqkv) && delta && lse && gscale, MV_ERR_ALIGN);
   if (B == 0) return MV_OK;
   constexpr int smem4 = 224 * 128 + 208 * 128 + 8192 + 224 * 64 + 2 * 224 * 4;
-  const int a = MV_ONCE_PER_DEVICE(set_smem(attn_bwd4_kernel<4, true>, smem4));
-  if (a) return MV_ERR_LAUNCH;
-  attn_bwd4_kernel<4, true><<<B * H, 256, smem4, (hipStream_t)stream>>>((const bf16_t*)qkv16, nullptr, (const bf16_t*)dout16, lse,
-                                                                         (bf16_t*)dqkv, nullptr, N, H, scale, delta, gscale);
+  hipStream_t s = (hipStream_t)stream;
+#define MV_BWD_F16(SPLIT_)                                                                                                   \
+  {                                                                                                                          \
+    const int a = MV_ONCE_PER_DEVICE(set_smem(attn_bwd4_kernel<4, true, SPLIT_>, smem4));                                    \
+    if (a) return MV_ERR_LAUNCH;                                                                                             \
+    attn_bwd4_kernel<4, true, SPLIT_><<<B * H, 256, smem4, s>>>((const bf16_t*)qkv16, nullptr, (const bf16_t*)dout16, lse,   \
+                                                                (bf16_t*)dqkv, colsum, N, H, scale, delta, gscale);           \
+  }
+  if (nseg == 0) MV_BWD_F16(0) else if (nseg == 3) MV_BWD_F16(3) else MV_BWD_F16(6)
+#undef MV_BWD_F16
   MV_CHECK_LAUNCH();
   return MV_OK;
 }

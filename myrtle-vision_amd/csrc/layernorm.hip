@@ -12,7 +12,11 @@ namespace {
 // YT = int8_t: the output goes straight into the NEXT layer's quint8 quantiser (q_inv = 1 / scale, q_zp) and leaves as int8
 // MFMA operands q - 128: the fp32 LayerNorm output of the converted int8 model (620 MB at batch 1024) is neither written
 // nor read back.  Same expressions as the float path followed by affine_code_one: bit-identical to LayerNorm + quantiser.
-template <int VPL, typename YT>
+// NSEG = 3 / 6 (round 4; YT = bf16_t): the output leaves as the bf16 PIECES of the split-operand Linear products (mv_split2_bf16 /
+// mv_split3_bf16, role 0: p0 p0 p1 [p0 p1 p2], `dim` columns apart in rows of NSEG * dim) -- the fp32 LayerNorm output is neither
+// written nor read back by a split pass (8 B per element of traffic and a launch per LayerNorm in precision fp32 / bf16x3 / bf16x3h).
+// Same expressions, then the same piece arithmetic as split3_kernel: bit-identical to LayerNorm + split.
+template <int VPL, typename YT, int NSEG = 0>
 __global__ __launch_bounds__(256) void ln_fwd_kernel(const float* __restrict__ x, long ldx,
                                                      const float* __restrict__ gamma,
                                                      const float* __restrict__ beta, YT* __restrict__ y,
@@ -47,7 +51,7 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const float* __restrict__ x
       mean[row] = mu;
       rstd[row] = rs;
     }
-    YT* yr = y + row * (long)dim;
+    YT* yr = y + row * (long)dim * (NSEG ? NSEG : 1);
 #pragma unroll
     for (int i = 0; i < VPL; ++i) {
       const int c = lane + 64 * i;
@@ -56,7 +60,22 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const float* __restrict__ x
         const float4 b = reinterpret_cast<const float4*>(beta)[c];
         const float o0 = (v[i].x - mu) * rs * g.x + b.x, o1 = (v[i].y - mu) * rs * g.y + b.y;
         const float o2 = (v[i].z - mu) * rs * g.z + b.z, o3 = (v[i].w - mu) * rs * g.w + b.w;
-        if constexpr (sizeof(YT) == 1) {
+        if constexpr (NSEG != 0) {
+          const float o[4] = {o0, o1, o2, o3};
+          bf16x4 p[3];
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            const bf16_t p0 = (bf16_t)o[e];
+            const float r1 = o[e] - (float)p0;
+            const bf16_t p1 = (bf16_t)r1;
+            p[0][e] = p0;
+            p[1][e] = p1;
+            p[2][e] = (bf16_t)(r1 - (float)p1);
+          }
+          constexpr int order[6] = {0, 0, 1, 0, 1, 2};
+#pragma unroll
+          for (int sgm = 0; sgm < NSEG; ++sgm) reinterpret_cast<bf16x4*>(yr + (long)sgm * dim)[c] = p[order[sgm]];
+        } else if constexpr (sizeof(YT) == 1) {
           reinterpret_cast<unsigned*>(yr)[c] = affine_i8_pack4<0>(o0, o1, o2, o3, q_inv, q_zp);
         } else if constexpr (sizeof(YT) == 4) {
           reinterpret_cast<float4*>(yr)[c] = make_float4(o0, o1, o2, o3);
@@ -225,6 +244,32 @@ extern "C" int mv_layernorm_fwd(const float* x, long ldx, const float* gamma, co
       else
         ln_fwd_kernel<16, bf16_t><<<grid, 256, 0, s>>>(x, ldx, gamma, beta, (bf16_t*)y, mean, rstd, rows, dim, eps);
   }
+  MV_CHECK_LAUNCH();
+  return MV_OK;
+}
+
+extern "C" int mv_layernorm_fwd_split(const float* x, long ldx, const float* gamma, const float* beta, void* y_split, int nseg,
+                                      float* mean, float* rstd, int rows, int dim, float eps, mv_stream_t stream) {
+  MV_REQUIRE(rows >= 0 && dim > 0 && dim % 4 == 0 && dim <= 1024 && ldx % 4 == 0, MV_ERR_SHAPE);
+  MV_REQUIRE(nseg == 3 || nseg == 6, MV_ERR_UNSUPPORTED);
+  MV_REQUIRE(mv_aligned16(x) && mv_aligned16(gamma) && mv_aligned16(beta) && mv_aligned16(y_split), MV_ERR_ALIGN);
+  if (rows == 0) return MV_OK;
+  hipStream_t s = (hipStream_t)stream;
+  int grid = mv_cdiv(rows, 4);
+  if (grid > 2048) grid = 2048;
+  bf16_t* y = (bf16_t*)y_split;
+#define LN_SPLIT_CASE(V)                                                                                               \
+  case V:                                                                                                              \
+    if (nseg == 3) ln_fwd_kernel<V, bf16_t, 3><<<grid, 256, 0, s>>>(x, ldx, gamma, beta, y, mean, rstd, rows, dim, eps); \
+    else ln_fwd_kernel<V, bf16_t, 6><<<grid, 256, 0, s>>>(x, ldx, gamma, beta, y, mean, rstd, rows, dim, eps);           \
+    break;
+  switch (mv_cdiv(dim / 4, 64)) {
+    LN_SPLIT_CASE(1) LN_SPLIT_CASE(2) LN_SPLIT_CASE(3)
+    default:
+      if (nseg == 3) ln_fwd_kernel<4, bf16_t, 3><<<grid, 256, 0, s>>>(x, ldx, gamma, beta, y, mean, rstd, rows, dim, eps);
+      else ln_fwd_kernel<4, bf16_t, 6><<<grid, 256, 0, s>>>(x, ldx, gamma, beta, y, mean, rstd, rows, dim, eps);
+  }
+#undef LN_SPLIT_CASE
   MV_CHECK_LAUNCH();
   return MV_OK;
 }

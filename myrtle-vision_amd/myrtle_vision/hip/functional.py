@@ -523,15 +523,17 @@ class _AttnBlock(Function):
         M = B * T
         x = _c(x)
         ctx.up_bias = _chain_take(x)
-        y, mean, rstd = ops.layernorm_fwd(x, D, M, D, g, b, adt)
         inner3 = wqkv.shape[0]
         inner = inner3 // 3
         ctx.x6 = adt == torch.float32 and ops.x6_block_ok(M, D, inner3, inner)
+        if not (ctx.x6 and D <= 1024):
+            y, mean, rstd = ops.layernorm_fwd(x, D, M, D, g, b, adt)
         if ctx.x6:
             # fp32 mode, every Linear product on the bf16x6 path: the block keeps the SPLITS of LN(x) and of the attention
             # output (what the forward and the dW products both read), not the tensors themselves
             dh = inner // heads
-            y6 = ops.split_ex(y, M, D)
+            # LayerNorm writes the pieces itself (no fp32 y, no split pass)
+            y6, mean, rstd = ops.layernorm_fwd_split(x, D, M, D, g, b) if D <= 1024 else (ops.split_ex(y, M, D), mean, rstd)
             ctx.f16 = ops.attention_f16_supported(adt, T, dh)
             # precision "bf16x3h": the fused attention kernels on half operands (2^-12 per rounding, fp32 sums, softmax and outputs);
             # q / k / v leave the to_qkv product as half (one rounding of the fp32 accumulator + bias, no fp32 tensor, no cast pass)
@@ -606,14 +608,18 @@ class _AttnBlock(Function):
             dwo = ops.tn_x6(d6, o6, M, wo)
             do = torch.empty(B, T, inner, dtype=torch.float32, device=x.device)
             ops.nt_x6(d6, wo, "dx", M, do.view(M, inner))
-            if ctx.f16:
-                dqkv = ops.attention_bwd_f16(qkv, ctx.saved_tensors[10], do, probs, B, T, heads, scale)
-            elif ctx.fused32:
-                dqkv = ops.attention_bwd_f32_fused(qkv, ctx.saved_tensors[10], do, probs, B, T, heads, scale)
-            else:
-                dqkv = ops.attention_bwd_fp32(probs, qkv, do, B, T, heads, inner // heads, scale)
             dbqkv = ops.grad_out(bqkv, (inner3,), x.device)
-            dq6 = ops.split_ex(dqkv.view(M, inner3), M, inner3, colsum_out=dbqkv)
+            if ctx.f16:
+                # the kernel writes the pieces of dqkv and per-image column sums itself: no fp32 dqkv, no split pass
+                part = torch.empty(B, inner3, dtype=torch.float32, device=x.device)
+                dq6 = ops.attention_bwd_f16(qkv, ctx.saved_tensors[10], do, probs, B, T, heads, scale, split=True, colsum=part)
+                ops.colsum(part, B, inner3, inner3, dbqkv)
+            else:
+                if ctx.fused32:
+                    dqkv = ops.attention_bwd_f32_fused(qkv, ctx.saved_tensors[10], do, probs, B, T, heads, scale)
+                else:
+                    dqkv = ops.attention_bwd_fp32(probs, qkv, do, B, T, heads, inner // heads, scale)
+                dq6 = ops.split_ex(dqkv.view(M, inner3), M, inner3, colsum_out=dbqkv)
             dwqkv = ops.tn_x6(dq6, y6, M, wqkv)
             dy = torch.empty(M, D, dtype=torch.float32, device=x.device)
             ops.nt_x6(dq6, wqkv, "dx", M, dy)
@@ -664,12 +670,13 @@ class _MlpBlock(Function):
         Hd = w1.shape[0]
         x = _c(x)
         ctx.up_bias = _chain_take(x)
-        y, mean, rstd = ops.layernorm_fwd(x, D, M, D, g, b, adt)
         ctx.x6 = adt == torch.float32 and ops.x6_block_ok(M, D, Hd)
+        if not (ctx.x6 and D <= 1024):
+            y, mean, rstd = ops.layernorm_fwd(x, D, M, D, g, b, adt)
         if ctx.x6:
             # fp32 mode on the bf16x6 path: keeps the splits of LN(x) and of gelu(h) plus the pre-activation h; the fp32
-            # activation gelu(h) is never stored (the split kernel applies the GELU on its way)
-            y6 = ops.split_ex(y, M, D)
+            # activation gelu(h) is never stored (the split kernel applies the GELU on its way); LayerNorm writes its pieces itself
+            y6, mean, rstd = ops.layernorm_fwd_split(x, D, M, D, g, b) if D <= 1024 else (ops.split_ex(y, M, D), mean, rstd)
             h = torch.empty(M, Hd, dtype=adt, device=x.device)
             ops.nt_x6(y6, w1, "fwd", M, h, bias=b1)
             a6 = ops.split_ex(h, M, Hd, op=1)

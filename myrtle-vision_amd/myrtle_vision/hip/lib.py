@@ -26,6 +26,7 @@ SIGNATURES = {
     "mv_gemm_tn_workspace_bytes": ("iii", _Z),
     "mv_layernorm_bwd_workspace_bytes": ("ii", _Z),
     "mv_layernorm_fwd": ("plpppipp" "iifp", _I),
+    "mv_layernorm_fwd_split": ("plpppipp" "iifp", _I),
     "mv_layernorm_bwd": ("pi" "plp" "pp" "ppl" "ppi" "pz" "ii" "pp" "p", _I),
     "mv_gemm_nt_bf16": ("pipipii" "iii" "pi" "pii" "pi" "p", _I),
     "mv_gemm_nt_bf16_scaled": ("pipipii" "iii" "f" "pi" "pii" "pi" "p", _I),
@@ -51,7 +52,7 @@ SIGNATURES = {
     "mv_attention_fwd_f32": ("pp" "iii" "f" "p", _I),
     "mv_attention_fwd_f16": ("ppp" "iii" "f" "p", _I),
     "mv_attention_bwd_prep_f16": ("ppppp" "iii" "p", _I),
-    "mv_attention_bwd_f16": ("pppppp" "iii" "f" "p", _I),
+    "mv_attention_bwd_f16": ("pppppp" "ip" "iii" "f" "p", _I),
     "mv_softmax_fwd": ("pp" "li" "f" "p", _I),
     "mv_softmax_bwd": ("ppp" "li" "f" "p", _I),
     "mv_patchify": ("ppi" "iiiii" "p", _I),

@@ -338,6 +338,18 @@ def layernorm_fwd(x, ldx, rows, dim, gamma, beta, out_dtype, eps=1e-5):
     return y, mean, rstd
 
 
+def layernorm_fwd_split(x, ldx, rows, dim, gamma, beta, eps=1e-5):
+    """LayerNorm whose output leaves as the bf16 pieces of the split-operand products (``split_ex(layernorm_fwd(...))`` without the
+    fp32 tensor in between, bit-identical): -> (y_split [rows, nseg * dim], mean, rstd)."""
+    require_cuda(x, gamma, beta)
+    y = _split_buffer(rows, dim, x.device)
+    mean = torch.empty(rows, dtype=torch.float32, device=x.device)
+    rstd = torch.empty(rows, dtype=torch.float32, device=x.device)
+    check(lib().mv_layernorm_fwd_split(_p(x), ldx, _p(gamma), _p(beta), _p(y), current_segments(), _p(mean), _p(rstd), rows, dim,
+                                       eps, _s()), "layernorm_fwd_split", rows=rows, dim=dim)
+    return y, mean, rstd
+
+
 def layernorm_bwd(dy, x, ldx, gamma, mean, rstd, dx_add, dx, lddx, rows, dim, dx16=None, dx_colsum=None, beta=None):
     """Writes dx (fp32 rows ``lddx`` apart; ``dx_add`` added if given, same layout) -> (dgamma, dbeta).
     Optional fused by-products: ``dx16`` (bf16 [rows, dim] copy of dx) and ``dx_colsum`` (fp32 [dim] column sums).
@@ -764,19 +776,21 @@ def attention_fwd_f16(qkv16, B, N, H, scale):
     return out, lse
 
 
-def attention_bwd_f16(qkv16, out, dout, lse, B, N, H, scale):
-    """-> dqkv fp32 [B, N, 3*H*64].  ``out`` / ``dout`` fp32 [B, N, H*64]: dout is scaled into half's range by a power of two
-    taken from its own largest magnitude (one reduction + one conversion pass that also leaves delta), the kernel divides the
-    factor out of its fp32 outputs."""
+def attention_bwd_f16(qkv16, out, dout, lse, B, N, H, scale, split=False, colsum=None):
+    """-> dqkv [B, N, 3*H*64]: fp32, or (``split``) its bf16 pieces [B * N, nseg * 3*H*64] for the to_qkv dW / dX products.  ``out``
+    / ``dout`` fp32 [B, N, H*64]: dout is scaled into half's range per (image, head) by a power of two taken from its own largest
+    magnitude (one pass that also leaves delta); the kernel divides the factor out of its outputs.  ``colsum``: fp32 [B, 3*H*64]
+    receiving per-image column sums of dqkv (to_qkv's bias gradient after a sum over images)."""
     dev = qkv16.device
     dout16 = torch.empty(B, N, H * 64, dtype=torch.float16, device=dev)
     delta = torch.empty(B, H, N, dtype=torch.float32, device=dev)
     gscale = torch.empty(B * H, dtype=torch.float32, device=dev)
     check(lib().mv_attention_bwd_prep_f16(_p(dout), _p(out), _p(dout16), _p(delta), _p(gscale), B, N, H, _s()),
           "attention_bwd_prep_f16", B=B, N=N, H=H)
-    dqkv = torch.empty(B, N, 3 * H * 64, dtype=torch.float32, device=dev)
-    check(lib().mv_attention_bwd_f16(_p(qkv16), _p(dout16), _p(delta), _p(lse), _p(gscale), _p(dqkv), B, N, H, scale, _s()),
-          "attention_bwd_f16", B=B, N=N, H=H)
+    nseg = current_segments() if split else 0
+    dqkv = _split_buffer(B * N, 3 * H * 64, dev) if split else torch.empty(B, N, 3 * H * 64, dtype=torch.float32, device=dev)
+    check(lib().mv_attention_bwd_f16(_p(qkv16), _p(dout16), _p(delta), _p(lse), _p(gscale), _p(dqkv), nseg, _p(colsum), B, N, H,
+                                     scale, _s()), "attention_bwd_f16", B=B, N=N, H=H)
     return dqkv
 
 

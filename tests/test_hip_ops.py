@@ -499,6 +499,25 @@ def test_gemm_f32_bf16x6_is_fp32_accurate(ops, M, N, K):
     assert relerr(o, x.double() @ w.double().t() + b.double()) < 4e-6
 
 
+@pytest.mark.parametrize("rows,dim", [(394, 192), (1000, 768), (37, 1024), (513, 64)])
+def test_layernorm_fwd_split_equals_layernorm_then_split(ops, rows, dim):
+    """mv_layernorm_fwd_split (round 4): LayerNorm whose output leaves as the bf16 pieces of the split-operand products -- bit for
+    bit what mv_layernorm_fwd (fp32) followed by the split pass writes, statistics included, for three and six segments; the rows
+    behind the last one (the dW product walks whole 32-row stages) are zero."""
+    x = torch.randn(rows, dim, generator=g(1)).cuda() * 2 + 0.3
+    gm, bt = (1 + 0.1 * torch.randn(dim, generator=g(2))).cuda(), (0.1 * torch.randn(dim, generator=g(3))).cuda()
+    y, mean, rstd = ops.layernorm_fwd(x, dim, rows, dim, gm, bt, torch.float32)
+    for nseg in (6, 3):
+        with ops.segments(nseg):
+            want = ops.split_ex(y, rows, dim)
+            got, m2, r2 = ops.layernorm_fwd_split(x, dim, rows, dim, gm, bt)
+        assert got.shape == (rows, nseg * dim) and torch.equal(got, want)
+        assert torch.equal(m2, mean) and torch.equal(r2, rstd)
+        pad = got.storage_offset() + got.numel()
+        full = torch.empty(0, dtype=torch.bfloat16, device="cuda").set_(got.untyped_storage())
+        assert not full[pad:((rows + 31) // 32) * 32 * nseg * dim].any()
+
+
 @pytest.mark.parametrize("M,N,K", [(394, 192, 192), (1600, 768, 768), (1600, 3072, 768), (1024, 768, 3072), (4096, 2304, 768)])
 def test_gemm_f32_bf16x3_is_2e16_accurate(ops, M, N, K):
     """The bf16x3 products (``ops.segments(3)``: two bf16 pieces per operand, pairings a0 b0 + a0 b1 + a1 b0 in ONE bf16 MFMA
@@ -684,6 +703,13 @@ def test_attention_f16_fwd_bwd(ops, B, N, H, gscale):
     got, ref = dqkv.cpu().view(B, N, 3, H, 64), ref_in.grad.view(B, N, 3, H, 64)
     for i, name in enumerate("qkv"):
         assert relerr(got[:, :, i], ref[:, :, i]) < 2e-3, (name, relerr(got[:, :, i], ref[:, :, i]))
+    # the split-output form (what the bf16x3h block runs): the bf16 pieces of exactly those fp32 values, and per-image column sums
+    for nseg in (3, 6):
+        with ops.segments(nseg):
+            part = torch.empty(B, 3 * H * 64, device="cuda")
+            pieces = ops.attention_bwd_f16(q16, out, dout.cuda(), lse, B, N, H, scale, split=True, colsum=part)
+            assert torch.equal(pieces, ops.split_ex(dqkv.view(B * N, 3 * H * 64), B * N, 3 * H * 64))
+        assert relerr(part, dqkv.double().sum(1)) < 1e-5
     # deterministic, and an all-zero gradient gives exact zeros (scale 1, no 0 * inf)
     assert torch.equal(dqkv, ops.attention_bwd_f16(q16, out, dout.cuda(), lse, B, N, H, scale))
     assert not ops.attention_bwd_f16(q16, out, torch.zeros_like(dout).cuda(), lse, B, N, H, scale).any()
