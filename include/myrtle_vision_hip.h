@@ -57,6 +57,12 @@ enum {
   MV_EPI_GELU_GRAD8 = 8, /* as MV_EPI_GELU_GRAD with out2 as ONE BYTE per element (uint8 [M, ld_out2]): gelu' lies in
                             [-0.129, 1.129]; code = round(gelu' * 200) + 26: 0 and 1 are codes 26 and 226 exactly, |error| <= 0.0025 */
   MV_EPI_MUL8 = 9,       /* as MV_EPI_MUL with aux = those codes (uint8 [M, ld_aux]): C = acc * ((code - 26) * 0.005) */
+  MV_EPI_SPLIT_DGELU = 10, /* mv_gemm_nt_bf16 with C bf16 [M, aux_i * N] (aux_i = 3 | 6): the bf16 PIECES (mv_split2_bf16 / mv_split3_bf16,
+                              role 0, segments N apart) of acc * gelu_erf'(aux), aux fp32 [M, ld_aux]; out2 as MV_EPI_DGELU.  The
+                              fc2 input gradient of the split-operand modes leaves as the operand of fc1's dW / dX products: no fp32
+                              tensor, no split pass.  Whole 256 x 256 tiles only (M % 256 == N % 256 == 0) */
+  MV_EPI_SPLIT_GELU = 11,  /* likewise: out2 = acc + bias (fp32 pre-activation [M, ld_out2], required), C = the pieces of
+                              gelu_erf(acc + bias): fc1 of the split-operand modes */
   MV_EPI_EMBED = 4     /* patch-embedding: row m of the GEMM is patch (m % aux_i) of image (m / aux_i);
                           C row = img*(aux_i+1) + 1 + patch;  C = acc + bias + aux[1 + patch]  (aux: fp32 [aux_i+1, N]) */
 };

@@ -135,6 +135,28 @@ __device__ __forceinline__ void gelu_both_fast(float x, float& gl, float& dg) {
 constexpr bool epi_is_gelu(int e) { return e == MV_EPI_GELU || e == MV_EPI_GELU_GRAD || e == MV_EPI_GELU_GRAD8; }
 constexpr bool epi_is_dgelu(int e) { return e == MV_EPI_DGELU || e == MV_EPI_MUL || e == MV_EPI_MUL8; }
 constexpr bool epi_is_gelugrad(int e) { return e == MV_EPI_GELU_GRAD || e == MV_EPI_GELU_GRAD8; }
+constexpr bool epi_is_split(int e) { return e == MV_EPI_SPLIT_DGELU || e == MV_EPI_SPLIT_GELU; }
+// four consecutive columns of a split-output epilogue: the bf16 pieces of v (split3_kernel's arithmetic), nseg segments `seg` apart
+__device__ __forceinline__ void store_pieces4(bf16_t* o, const float (&v)[4], int nseg, long seg) {
+  bf16x4 p[3];
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    const bf16_t p0 = (bf16_t)v[e];
+    const float r1 = v[e] - (float)p0;
+    const bf16_t p1 = (bf16_t)r1;
+    p[0][e] = p0;
+    p[1][e] = p1;
+    p[2][e] = (bf16_t)(r1 - (float)p1);
+  }
+  *reinterpret_cast<bf16x4*>(o) = p[0];
+  *reinterpret_cast<bf16x4*>(o + seg) = p[0];
+  *reinterpret_cast<bf16x4*>(o + 2 * seg) = p[1];
+  if (nseg == 6) {
+    *reinterpret_cast<bf16x4*>(o + 3 * seg) = p[0];
+    *reinterpret_cast<bf16x4*>(o + 4 * seg) = p[1];
+    *reinterpret_cast<bf16x4*>(o + 5 * seg) = p[2];
+  }
+}
 // gelu'(x) lies in [-0.1290, 1.1290]: MV_EPI_GELU_GRAD8 leaves it as an 8-bit code on a fixed grid, MV_EPI_MUL8 reads it
 // back: one byte per hidden element instead of two in fc1's epilogue and in fc2-dX's.  The grid is step 0.005 from -0.13:
 // code 26 IS 0 and code 226 IS 1 (a saturated unit's gradient passes unchanged and a dead unit leaks nothing -- a grid
@@ -279,7 +301,7 @@ __device__ __forceinline__ void nt_epilogue(f32x4 (&acc)[4][4], CT* __restrict__
       return;
     }
     float4 ax[4][4];
-    if constexpr (EPI == MV_EPI_RESIDUAL || EPI == MV_EPI_EMBED) {
+    if constexpr (EPI == MV_EPI_RESIDUAL || EPI == MV_EPI_EMBED || EPI == MV_EPI_SPLIT_DGELU) {
 #pragma unroll
       for (int i = 0; i < 4; ++i)
 #pragma unroll
@@ -424,6 +446,13 @@ __device__ __forceinline__ void nt_epilogue(f32x4 (&acc)[4][4], CT* __restrict__
           }
         } else if constexpr (EPI == MV_EPI_RESIDUAL || EPI == MV_EPI_EMBED) {
           v[0] += ax[i][j].x; v[1] += ax[i][j].y; v[2] += ax[i][j].z; v[3] += ax[i][j].w;
+        } else if constexpr (EPI == MV_EPI_SPLIT_DGELU) {         // the exact gelu' of the split pass it replaces (split3_ex_kernel<2>)
+          v[0] *= dgelu_f(ax[i][j].x); v[1] *= dgelu_f(ax[i][j].y); v[2] *= dgelu_f(ax[i][j].z); v[3] *= dgelu_f(ax[i][j].w);
+          cs[j][0] += v[0]; cs[j][1] += v[1]; cs[j][2] += v[2]; cs[j][3] += v[3];
+        } else if constexpr (EPI == MV_EPI_SPLIT_GELU) {          // pre-activation out (fp32), then the exact GELU (split3_ex_kernel<1>)
+          st16(reinterpret_cast<float*>(ep.out2) + (long)(mb + i * 16) * ep.ld_out2 + n,
+               __builtin_bit_cast(u32x4, (f32x4){v[0], v[1], v[2], v[3]}));
+          v[0] = gelu_f(v[0]); v[1] = gelu_f(v[1]); v[2] = gelu_f(v[2]); v[3] = gelu_f(v[3]);
         } else if constexpr (epi_is_dgelu(EPI)) {
 #pragma unroll
           for (int r = 0; r < 4; ++r)
@@ -431,12 +460,14 @@ __device__ __forceinline__ void nt_epilogue(f32x4 (&acc)[4][4], CT* __restrict__
                     : (EPI == MV_EPI_MUL) ? (float)hx[i][j][r] : dgelu_fast((float)hx[i][j][r]);
           cs[j][0] += v[0]; cs[j][1] += v[1]; cs[j][2] += v[2]; cs[j][3] += v[3];
         }
-        if constexpr (sizeof(CT) == 4)
+        if constexpr (epi_is_split(EPI))
+          store_pieces4(reinterpret_cast<bf16_t*>(C) + crow[i] * ldc + n, v, ep.aux_i, N);
+        else if constexpr (sizeof(CT) == 4)
           st16(C + crow[i] * ldc + n, __builtin_bit_cast(u32x4, (f32x4){v[0], v[1], v[2], v[3]}));
         else
           store4(C + crow[i] * ldc + n, v, true, 4);
       }
-    if constexpr (epi_is_dgelu(EPI)) {
+    if constexpr (epi_is_dgelu(EPI) || EPI == MV_EPI_SPLIT_DGELU) {
       if (ep.out2) nt_colsum_flush(cs, reinterpret_cast<float*>(ep.out2), ep.ld_out2, (m0 + wm * 64) >> 6, nb, N, lane);
     }
     return;
@@ -1150,7 +1181,7 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_8phase_kernel(const bf16_t* __
       }
     }
   }
-  constexpr bool park = epi_is_dgelu(EPI) || EPI == MV_EPI_RESIDUAL;
+  constexpr bool park = epi_is_dgelu(EPI) || EPI == MV_EPI_RESIDUAL || EPI == MV_EPI_SPLIT_DGELU;
   f32x4* const parked = reinterpret_cast<f32x4*>(smem) + wave * 16 * 64 + lane;
   if (park && !is_half) {
 #pragma unroll
@@ -1855,6 +1886,19 @@ extern "C" int mv_gemm_nt_bf16_scaled(const void* A, int lda, const void* B, int
     case MV_EPI_EMBED:
       MV_REQUIRE(c_dtype == MV_F32 && aux && aux_i > 0, MV_ERR_UNSUPPORTED);
       return launch_nt<MV_EPI_EMBED, float>(A, lda, B, ldb, C, ldc, M, N, K, ep, s);
+    case MV_EPI_SPLIT_DGELU:
+    case MV_EPI_SPLIT_GELU: {
+      // pieces out: interior tiles only (the edge path of nt_epilogue does not know these forms), fp32 aux / out2, 16-byte rows
+      MV_REQUIRE(c_dtype == MV_BF16 && (aux_i == 3 || aux_i == 6) && M % 256 == 0 && N % 256 == 0 && K % 128 == 0 && K >= 128,
+                 MV_ERR_UNSUPPORTED);
+      MV_REQUIRE(ldc >= aux_i * N && ldc % 4 == 0, MV_ERR_ALIGN);
+      if (epilogue == MV_EPI_SPLIT_DGELU) {
+        MV_REQUIRE(aux && ld_aux % 4 == 0 && mv_aligned16(aux) && !bias, MV_ERR_ALIGN);
+        return launch_nt<MV_EPI_SPLIT_DGELU, bf16_t>(A, lda, B, ldb, C, ldc, M, N, K, ep, s);
+      }
+      MV_REQUIRE(out2 && ld_out2 % 4 == 0 && mv_aligned16(out2), MV_ERR_ALIGN);
+      return launch_nt<MV_EPI_SPLIT_GELU, bf16_t>(A, lda, B, ldb, C, ldc, M, N, K, ep, s);
+    }
     default:
       return MV_ERR_UNSUPPORTED;
   }

@@ -678,8 +678,11 @@ class _MlpBlock(Function):
             # activation gelu(h) is never stored (the split kernel applies the GELU on its way); LayerNorm writes its pieces itself
             y6, mean, rstd = ops.layernorm_fwd_split(x, D, M, D, g, b) if D <= 1024 else (ops.split_ex(y, M, D), mean, rstd)
             h = torch.empty(M, Hd, dtype=adt, device=x.device)
-            ops.nt_x6(y6, w1, "fwd", M, h, bias=b1)
-            a6 = ops.split_ex(h, M, Hd, op=1)
+            if ops.nt_split_ok(M, Hd, D):
+                a6 = ops.nt_x6_gelu_split(y6, w1, M, h, bias=b1)     # one launch: h (fp32) and the pieces of gelu(h)
+            else:
+                ops.nt_x6(y6, w1, "fwd", M, h, bias=b1)
+                a6 = ops.split_ex(h, M, Hd, op=1)
             out = torch.empty_like(x)
             ops.nt_x6(a6, w2, "fwd", M, out.view(M, D), bias=b2, residual=x.view(M, D))
             ctx.save_for_backward(x, g, mean, rstd, y6, h, a6, w1, w2)
@@ -716,10 +719,13 @@ class _MlpBlock(Function):
             db2 = ops.grad_out(b2, (D,), x.device)
             d6 = ops.split_ex(dout.view(M, D), M, D, colsum_out=db2)
             dw2 = ops.tn_x6(d6, a6, M, w2)
-            dh = torch.empty(M, Hd, dtype=torch.float32, device=x.device)
-            ops.nt_x6(d6, w2, "dx", M, dh)
             db1 = ops.grad_out(b1, (Hd,), x.device)
-            dh6 = ops.split_ex(dh, M, Hd, op=2, h=h, colsum_out=db1)         # (dY W2) * gelu'(h), its split and its column sums
+            if ops.nt_split_ok(M, Hd, D):
+                dh6 = ops.nt_x6_dgelu_split(d6, w2, M, h, db1)   # one launch: the pieces of (dY W2) * gelu'(h) and its column sums
+            else:
+                dh = torch.empty(M, Hd, dtype=torch.float32, device=x.device)
+                ops.nt_x6(d6, w2, "dx", M, dh)
+                dh6 = ops.split_ex(dh, M, Hd, op=2, h=h, colsum_out=db1)     # (dY W2) * gelu'(h), its split and its column sums
             dw1 = ops.tn_x6(dh6, y6, M, w1)
             dy = torch.empty(M, D, dtype=torch.float32, device=x.device)
             ops.nt_x6(dh6, w1, "dx", M, dy)

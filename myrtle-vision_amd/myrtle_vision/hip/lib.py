@@ -14,7 +14,7 @@ from .build import LIB_PATH
 
 MV_F32, MV_BF16, MV_I8, MV_F16 = 0, 1, 2, 3
 EPI_NONE, EPI_GELU, EPI_RESIDUAL, EPI_DGELU, EPI_EMBED, EPI_GELU_GRAD, EPI_MUL, EPI_GELU_Q8 = 0, 1, 2, 3, 4, 5, 6, 7
-EPI_GELU_GRAD8, EPI_MUL8 = 8, 9
+EPI_GELU_GRAD8, EPI_MUL8, EPI_SPLIT_DGELU, EPI_SPLIT_GELU = 8, 9, 10, 11
 
 _P, _I, _L, _F, _Z = ctypes.c_void_p, ctypes.c_int, ctypes.c_long, ctypes.c_float, ctypes.c_size_t
 _KIND = {"p": _P, "i": _I, "l": _L, "f": _F, "z": _Z, "Q": ctypes.c_uint64}

@@ -21,11 +21,12 @@ import weakref
 import torch
 
 from . import lib as _l
-from .lib import (EPI_DGELU, EPI_EMBED, EPI_GELU, EPI_GELU_GRAD, EPI_GELU_GRAD8, EPI_MUL, EPI_MUL8, EPI_NONE, EPI_RESIDUAL, MV_BF16,
-                  MV_F32, check,
+from .lib import (EPI_DGELU, EPI_EMBED, EPI_GELU, EPI_GELU_GRAD, EPI_GELU_GRAD8, EPI_MUL, EPI_MUL8, EPI_NONE, EPI_RESIDUAL,
+                  EPI_SPLIT_DGELU, EPI_SPLIT_GELU, MV_BF16, MV_F32, check,
                   lib)
 
-__all__ = ["EPI_NONE", "EPI_GELU", "EPI_RESIDUAL", "EPI_DGELU", "EPI_EMBED", "EPI_GELU_GRAD", "EPI_MUL", "EPI_GELU_GRAD8", "EPI_MUL8"]
+__all__ = ["EPI_NONE", "EPI_GELU", "EPI_RESIDUAL", "EPI_DGELU", "EPI_EMBED", "EPI_GELU_GRAD", "EPI_MUL", "EPI_GELU_GRAD8", "EPI_MUL8",
+           "EPI_SPLIT_DGELU", "EPI_SPLIT_GELU"]
 
 _DT = {torch.float32: MV_F32, torch.bfloat16: MV_BF16}
 
@@ -558,6 +559,43 @@ def nt_x6(a6, weight, which, M, out, *, bias=None, residual=None):
     _nt_x6(a6, split_weight(weight, which), out, N, M, N, Kc, bias, EPI_RESIDUAL if residual is not None else EPI_NONE,
            residual, N, tag=which)
     return out
+
+
+def nt_split_ok(M, N, Kc):
+    """Whether the split-output epilogues of the NT kernels take [M, N] = A[M, Kc] B[N, Kc]^T (whole 256 x 256 tiles only)."""
+    return M % 256 == 0 and N % 256 == 0 and (current_segments() * Kc) % 128 == 0
+
+
+def nt_x6_gelu_split(y6, weight, M, h, *, bias):
+    """fc1 of the split-operand modes in ONE launch: h[M, N] (fp32 pre-activation, kept for the backward) = y W^T + b and the
+    bf16 pieces of gelu(h) -> [M, nseg * N] (what fc2's forward and dW products read); no split pass over h."""
+    N, Kc = weight.shape
+    nseg = current_segments()
+    a6 = _split_buffer(M, N, h.device)
+    t0 = _timer.begin() if _timer is not None else None
+    check(lib().mv_gemm_nt_bf16(_p(y6), nseg * Kc, _p(split_weight(weight, "fwd")), nseg * Kc, _p(a6), nseg * N, MV_BF16, M, N,
+                                nseg * Kc, _p(bias), EPI_SPLIT_GELU, None, 0, nseg, _p(h), N, _s()),
+          "gemm_nt_bf16(split gelu)", M=M, N=N, K=nseg * Kc)
+    if t0 is not None:
+        _timer.end(f"gemm_nt_bf16x{nseg}", t0, 2.0 * M * N * Kc, shape=f"fwd N{N} K{Kc} split-gelu")
+    return a6
+
+
+def nt_x6_dgelu_split(d6, weight, M, h, colsum_out):
+    """fc2's input gradient of the split-operand modes in ONE launch: the bf16 pieces of (dY W2) * gelu'(h) -> [M, nseg * K] and its
+    column sums (fc1's bias gradient) -> ``colsum_out``; no fp32 dh, no split pass."""
+    N, K = weight.shape                                  # nn.Linear [out = N, in = K]: dX[M, K] = dY[M, N] W
+    nseg = current_segments()
+    dh6 = _split_buffer(M, K, h.device)
+    part = torch.empty((M + 63) // 64, K, dtype=torch.float32, device=h.device)
+    t0 = _timer.begin() if _timer is not None else None
+    check(lib().mv_gemm_nt_bf16(_p(d6), nseg * N, _p(split_weight(weight, "dx")), nseg * N, _p(dh6), nseg * K, MV_BF16, M, K,
+                                nseg * N, None, EPI_SPLIT_DGELU, _p(h), K, nseg, _p(part), K, _s()),
+          "gemm_nt_bf16(split dgelu)", M=M, N=K, K=nseg * N)
+    if t0 is not None:
+        _timer.end(f"gemm_nt_bf16x{nseg}", t0, 2.0 * M * N * K, shape=f"dx N{K} K{N} split-dgelu")
+    colsum(part, part.shape[0], K, K, colsum_out)
+    return dh6
 
 
 def tn_x6(dy6, x6, M, weight):
