@@ -98,6 +98,12 @@ int mv_layernorm_bwd(const void* dy, int dy_dtype, const float* x, long ldx, con
                      const float* mean, const float* rstd, const float* dx_add, float* dx, long lddx,
                      float* dgamma, float* dbeta, int accumulate, float* workspace, size_t workspace_bytes,
                      int rows, int dim, void* dx_bf16, float* dx_colsum, mv_stream_t stream);
+/* The same backward with dx ALSO leaving as the bf16 pieces of the split-operand products (dx_split [rows, nseg * dim], nseg = 3 | 6,
+ * mv_split2_bf16 / mv_split3_bf16 role 0): what the consumer of dx in backward order feeds its dW / dX products, without a split pass. */
+int mv_layernorm_bwd_split(const void* dy, int dy_dtype, const float* x, long ldx, const float* gamma, const float* mean,
+                           const float* rstd, const float* dx_add, float* dx, long lddx, float* dgamma, float* dbeta, int accumulate,
+                           float* workspace, size_t workspace_bytes, int rows, int dim, void* dx_split, int nseg, float* dx_colsum,
+                           mv_stream_t stream);
 
 /* ---- dense contractions on MFMA (bf16 in, fp32 accumulate) ----
  * nn.Linear forward  y = x W^T + b : patch_to_embedding :278, to_qkv :86, to_out :98, net.0/net.3 :48-51,

@@ -100,7 +100,9 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const DT* __restrict__ dy, 
                                                      const float* __restrict__ gamma, const float* __restrict__ mean,
                                                      const float* __restrict__ rstd, const float* dx_add, float* dx,
                                                      long lddx, float* __restrict__ partial, int rows, int dim,
-                                                     bf16_t* __restrict__ dx16, int want_colsum) {
+                                                     bf16_t* __restrict__ dx16, int want_colsum, int dx16_nseg = 0) {
+  // dx16_nseg = 3 / 6 (round 4): dx16 receives the bf16 PIECES of dx (mv_split2_bf16 / mv_split3_bf16 role 0, rows of nseg * dim)
+  // instead of one bf16 copy -- the dY operand of the consumer's split-operand products, without its split pass over dx
   __shared__ float red[4][VPL * 64 * 4 * 2];
   const int lane = threadIdx.x & 63;
   const int wave = threadIdx.x >> 6;
@@ -156,9 +158,25 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const DT* __restrict__ dy, 
           o.x += a.x; o.y += a.y; o.z += a.z; o.w += a.w;
         }
         dxr[c] = o;
-        if (dx16) {
+        if (dx16 && dx16_nseg == 0) {
           bf16x4 o16 = {(bf16_t)o.x, (bf16_t)o.y, (bf16_t)o.z, (bf16_t)o.w};
           reinterpret_cast<bf16x4*>(dx16 + row * (long)dim)[c] = o16;
+        } else if (dx16) {
+          const float ov[4] = {o.x, o.y, o.z, o.w};
+          bf16x4 p[3];
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            const bf16_t p0 = (bf16_t)ov[e];
+            const float r1 = ov[e] - (float)p0;
+            const bf16_t p1 = (bf16_t)r1;
+            p[0][e] = p0;
+            p[1][e] = p1;
+            p[2][e] = (bf16_t)(r1 - (float)p1);
+          }
+          bf16x4* pr = reinterpret_cast<bf16x4*>(dx16 + row * (long)dim * dx16_nseg) + c;
+          const int nv = dim >> 2;                          // segments are dim elements = nv vectors apart
+          pr[0] = p[0]; pr[nv] = p[0]; pr[2 * nv] = p[1];
+          if (dx16_nseg == 6) { pr[3 * nv] = p[0]; pr[4 * nv] = p[1]; pr[5 * nv] = p[2]; }
         }
         dc[i].x += o.x; dc[i].y += o.y; dc[i].z += o.z; dc[i].w += o.w;
       }
@@ -297,15 +315,35 @@ extern "C" int mv_layernorm_fwd_q8(const float* x, long ldx, const float* gamma,
 #define LN_BWD_LAUNCH(V)                                                                                     \
   if (dy_dtype == MV_F32)                                                                                    \
     ln_bwd_kernel<V, float><<<grid, 256, 0, s>>>((const float*)dy, x, ldx, gamma, mean, rstd, dx_add, dx, lddx, \
-                                                 workspace, rows, dim, (bf16_t*)dx_bf16, dx_colsum != nullptr); \
+                                                 workspace, rows, dim, (bf16_t*)dx_bf16, dx_colsum != nullptr, nseg); \
   else                                                                                                       \
     ln_bwd_kernel<V, bf16_t><<<grid, 256, 0, s>>>((const bf16_t*)dy, x, ldx, gamma, mean, rstd, dx_add, dx, lddx, \
-                                                  workspace, rows, dim, (bf16_t*)dx_bf16, dx_colsum != nullptr);
+                                                  workspace, rows, dim, (bf16_t*)dx_bf16, dx_colsum != nullptr, nseg);
 
+namespace {
+int ln_bwd_impl(const void* dy, int dy_dtype, const float* x, long ldx, const float* gamma, const float* mean, const float* rstd,
+                const float* dx_add, float* dx, long lddx, float* dgamma, float* dbeta, int accumulate, float* workspace,
+                size_t workspace_bytes, int rows, int dim, void* dx_bf16, float* dx_colsum, int nseg, mv_stream_t stream);
+}
 extern "C" int mv_layernorm_bwd(const void* dy, int dy_dtype, const float* x, long ldx, const float* gamma,
                                 const float* mean, const float* rstd, const float* dx_add, float* dx, long lddx,
                                 float* dgamma, float* dbeta, int accumulate, float* workspace, size_t workspace_bytes,
                                 int rows, int dim, void* dx_bf16, float* dx_colsum, mv_stream_t stream) {
+  return ln_bwd_impl(dy, dy_dtype, x, ldx, gamma, mean, rstd, dx_add, dx, lddx, dgamma, dbeta, accumulate, workspace, workspace_bytes,
+                     rows, dim, dx_bf16, dx_colsum, 0, stream);
+}
+extern "C" int mv_layernorm_bwd_split(const void* dy, int dy_dtype, const float* x, long ldx, const float* gamma,
+                                      const float* mean, const float* rstd, const float* dx_add, float* dx, long lddx,
+                                      float* dgamma, float* dbeta, int accumulate, float* workspace, size_t workspace_bytes,
+                                      int rows, int dim, void* dx_split, int nseg, float* dx_colsum, mv_stream_t stream) {
+  MV_REQUIRE((nseg == 3 || nseg == 6) && dx_split && mv_aligned16(dx_split), MV_ERR_UNSUPPORTED);
+  return ln_bwd_impl(dy, dy_dtype, x, ldx, gamma, mean, rstd, dx_add, dx, lddx, dgamma, dbeta, accumulate, workspace, workspace_bytes,
+                     rows, dim, dx_split, dx_colsum, nseg, stream);
+}
+namespace {
+int ln_bwd_impl(const void* dy, int dy_dtype, const float* x, long ldx, const float* gamma, const float* mean, const float* rstd,
+                const float* dx_add, float* dx, long lddx, float* dgamma, float* dbeta, int accumulate, float* workspace,
+                size_t workspace_bytes, int rows, int dim, void* dx_bf16, float* dx_colsum, int nseg, mv_stream_t stream) {
   MV_REQUIRE(rows >= 0 && dim > 0 && dim % 4 == 0 && dim <= 2048 && ldx % 4 == 0 && lddx % 4 == 0, MV_ERR_SHAPE);
   MV_REQUIRE(dy_dtype == MV_F32 || dy_dtype == MV_BF16, MV_ERR_UNSUPPORTED);
   MV_REQUIRE(mv_aligned16(x) && mv_aligned16(gamma) && mv_aligned16(dy) && mv_aligned16(dx) &&
@@ -343,3 +381,4 @@ extern "C" int mv_layernorm_bwd(const void* dy, int dy_dtype, const float* x, lo
   MV_CHECK_LAUNCH();
   return MV_OK;
 }
+}  // namespace

@@ -471,7 +471,7 @@ def _publish_side(dx, dx16, colsum):
 def _take_side(dout, rows, dim):
     ent = _side.pop(dout.data_ptr(), None)
     _side.clear()
-    if ent is None or ent[0].shape != dout.shape or ent[1].shape != (rows, dim):
+    if ent is None or ent[0].shape != dout.shape or ent[1].shape[0] != rows or ent[1].shape[1] not in (dim, ops.current_segments() * dim):
         return None, None
     return ent[1], ent[2]
 
@@ -486,6 +486,13 @@ def _ln_bwd_with_side(dy, x, D, g, b, mean, rstd, dout, M, adt, up_bias=None):
         cs = ops.grad_out(up_bias, (D,), x.device)
         dg, db = ops.layernorm_bwd(dy, x, D, g, mean, rstd, dout, dx, D, M, D, dx16=dx16, dx_colsum=cs, beta=b)
         _publish_side(dx, dx16, cs)
+    elif D <= 1024 and ops.x6_block_ok(M, D):
+        # split-operand modes: dx also leaves as the pieces the consumer's dW / dX products read, with its column sums (that Linear's
+        # bias gradient): the consumer (the block before this one, _take_side) then needs no split pass over dx
+        dx6 = ops._split_buffer(M, D, x.device)
+        cs = ops.grad_out(up_bias, (D,), x.device)
+        dg, db = ops.layernorm_bwd(dy, x, D, g, mean, rstd, dout, dx, D, M, D, dx_split=dx6, dx_colsum=cs, beta=b)
+        _publish_side(dx, dx6, cs)
     else:
         dg, db = ops.layernorm_bwd(dy, x, D, g, mean, rstd, dout, dx, D, M, D, beta=b)
     return dx, dg, db
@@ -603,8 +610,10 @@ class _AttnBlock(Function):
             y6, o6, probs = y, o, lse_or_probs
             dout = _c(dout)
             b, bqkv, bo = ctx.small
-            dbo = ops.grad_out(bo, (D,), x.device)
-            d6 = ops.split_ex(dout.view(M, D), M, D, colsum_out=dbo)          # one pass: the split and the bias gradient
+            d6, dbo = _take_side(dout, M, D)                                  # the producing LayerNorm backward left both
+            if d6 is None or d6.dtype != torch.bfloat16 or d6.shape[1] != ops.current_segments() * D:
+                dbo = ops.grad_out(bo, (D,), x.device)
+                d6 = ops.split_ex(dout.view(M, D), M, D, colsum_out=dbo)      # one pass: the split and the bias gradient
             dwo = ops.tn_x6(d6, o6, M, wo)
             do = torch.empty(B, T, inner, dtype=torch.float32, device=x.device)
             ops.nt_x6(d6, wo, "dx", M, do.view(M, inner))
@@ -716,8 +725,10 @@ class _MlpBlock(Function):
             y6, a6 = y, a
             dout = _c(dout)
             b, b1, b2 = ctx.small
-            db2 = ops.grad_out(b2, (D,), x.device)
-            d6 = ops.split_ex(dout.view(M, D), M, D, colsum_out=db2)
+            d6, db2 = _take_side(dout, M, D)
+            if d6 is None or d6.dtype != torch.bfloat16 or d6.shape[1] != ops.current_segments() * D:
+                db2 = ops.grad_out(b2, (D,), x.device)
+                d6 = ops.split_ex(dout.view(M, D), M, D, colsum_out=db2)
             dw2 = ops.tn_x6(d6, a6, M, w2)
             db1 = ops.grad_out(b1, (Hd,), x.device)
             if ops.nt_split_ok(M, Hd, D):

@@ -28,6 +28,7 @@ SIGNATURES = {
     "mv_layernorm_fwd": ("plpppipp" "iifp", _I),
     "mv_layernorm_fwd_split": ("plpppipp" "iifp", _I),
     "mv_layernorm_bwd": ("pi" "plp" "pp" "ppl" "ppi" "pz" "ii" "pp" "p", _I),
+    "mv_layernorm_bwd_split": ("pi" "plp" "pp" "ppl" "ppi" "pz" "ii" "pip" "p", _I),
     "mv_gemm_nt_bf16": ("pipipii" "iii" "pi" "pii" "pi" "p", _I),
     "mv_gemm_nt_bf16_scaled": ("pipipii" "iii" "f" "pi" "pii" "pi" "p", _I),
     "mv_quant_affine_codes": ("pip" "lii" "f" "iiii" "p", _I),

@@ -351,15 +351,21 @@ def layernorm_fwd_split(x, ldx, rows, dim, gamma, beta, eps=1e-5):
     return y, mean, rstd
 
 
-def layernorm_bwd(dy, x, ldx, gamma, mean, rstd, dx_add, dx, lddx, rows, dim, dx16=None, dx_colsum=None, beta=None):
+def layernorm_bwd(dy, x, ldx, gamma, mean, rstd, dx_add, dx, lddx, rows, dim, dx16=None, dx_colsum=None, beta=None, dx_split=None):
     """Writes dx (fp32 rows ``lddx`` apart; ``dx_add`` added if given, same layout) -> (dgamma, dbeta).
-    Optional fused by-products: ``dx16`` (bf16 [rows, dim] copy of dx) and ``dx_colsum`` (fp32 [dim] column sums).
+    Optional fused by-products: ``dx16`` (bf16 [rows, dim] copy of dx) or ``dx_split`` (the bf16 pieces of dx, a ``_split_buffer`` of
+    the current segment count) and ``dx_colsum`` (fp32 [dim] column sums).
     ``gamma`` / ``beta`` (the parameters) select the gradient destinations (``grad_out``)."""
     require_cuda(dy, x, dx)
     dgamma = grad_out(gamma, (dim,), x.device)
     dbeta = grad_out(beta, (dim,), x.device)
     nbytes = lib().mv_layernorm_bwd_workspace_bytes(rows, dim)
     ws = workspace(nbytes, x.device)
+    if dx_split is not None:
+        check(lib().mv_layernorm_bwd_split(_p(dy), _DT[dy.dtype], _p(x), ldx, _p(gamma), _p(mean), _p(rstd), _p(dx_add), _p(dx),
+                                           lddx, _p(dgamma), _p(dbeta), 0, _p(ws), ws.numel(), rows, dim, _p(dx_split),
+                                           current_segments(), _p(dx_colsum), _s()), "layernorm_bwd_split", rows=rows, dim=dim)
+        return dgamma, dbeta
     check(lib().mv_layernorm_bwd(_p(dy), _DT[dy.dtype], _p(x), ldx, _p(gamma), _p(mean), _p(rstd), _p(dx_add), _p(dx),
                                  lddx, _p(dgamma), _p(dbeta), 0, _p(ws), ws.numel(), rows, dim, _p(dx16), _p(dx_colsum), _s()),
           "layernorm_bwd", rows=rows, dim=dim)
