@@ -504,31 +504,38 @@ def test_gemm_f32_bf16x6_is_fp32_accurate(ops, M, N, K):
 def test_split_output_epilogues_equal_gemm_then_split(ops, M, D, Hd, nseg):
     """MV_EPI_SPLIT_GELU / MV_EPI_SPLIT_DGELU (round 4): fc1 and fc2-dX of the split-operand modes with the pieces of gelu(h) /
     (dY W2) gelu'(h) leaving the GEMM epilogue -- against the two passes they replace (fp32 GEMM output, then mv_split*_bf16_ex with
-    op 1 / 2): the SAME fp32 accumulator, the same erf, the same piece arithmetic, so every output is bit-identical: h, the pieces,
-    and the bias-gradient column sums up to their summation order."""
+    op 1 / 2): the same erf and piece arithmetic on the epilogue's own fp32 accumulator (the pieces of gelu(h) are bit-identical to
+    a split pass over the h it wrote), values against the two-pass path to fp32 rounding and against fp64 to the mode's accuracy,
+    bias-gradient column sums included."""
     x, w1, b1 = torch.randn(M, D, generator=g(1)).cuda(), (torch.randn(Hd, D, generator=g(2)) * D ** -0.5).cuda(), (0.1 * torch.randn(Hd, generator=g(3))).cuda()
     w2, dy = (torch.randn(D, Hd, generator=g(4)) * Hd ** -0.5).cuda(), torch.randn(M, D, generator=g(5)).cuda()
     with ops.segments(nseg):
         assert ops.nt_split_ok(M, Hd, D)
         y6 = ops.split_ex(x, M, D)
         h_ref = torch.empty(M, Hd, device="cuda"); ops.nt_x6(y6, w1, "fwd", M, h_ref, bias=b1)
-        a6_ref = ops.split_ex(h_ref, M, Hd, op=1)
         h = torch.full((M, Hd), float("nan"), device="cuda")
         a6 = ops.nt_x6_gelu_split(y6, w1, M, h, bias=b1)
-        assert torch.equal(h, h_ref) and torch.equal(a6, a6_ref)
+        # (the plain product may run K-split for so few tiles: another summation order of the same fp32 product)
+        assert relerr(h, h_ref.double()) < 2e-6
+        assert torch.equal(a6, ops.split_ex(h, M, Hd, op=1))               # the pieces of gelu(h) of exactly the h it wrote
         d6 = ops.split_ex(dy, M, D)
         dh = torch.empty(M, Hd, device="cuda"); ops.nt_x6(d6, w2, "dx", M, dh)
         db_ref = torch.empty(Hd, device="cuda")
-        dh6_ref = ops.split_ex(dh, M, Hd, op=2, h=h_ref, colsum_out=db_ref)
+        dh6_ref = ops.split_ex(dh, M, Hd, op=2, h=h, colsum_out=db_ref)
         db = torch.empty(Hd, device="cuda")
         dh6 = ops.nt_x6_dgelu_split(d6, w2, M, h, db)
-        assert torch.equal(dh6, dh6_ref)
+        npc = 2 if nseg == 3 else 3
+        val = lambda t: sum(t[:, i * Hd:(i + 1) * Hd].double() for i in ((0, 2) if nseg == 3 else (0, 2, 5)))
+        assert relerr(val(dh6), val(dh6_ref)) < 2e-6 and torch.equal(dh6[:, :Hd], dh6[:, Hd:2 * Hd])
         assert relerr(db, db_ref.double()) < 2e-6
         # the values themselves, against fp64
         hd = x.double() @ w1.double().t() + b1.double()
         gel = torch.nn.functional.gelu(hd)
-        p0, p1 = a6[:, :Hd].float(), a6[:, 2 * Hd:3 * Hd].float()
-        assert relerr(p0 + p1, gel) < 2e-5
+        assert relerr(val(a6), gel) < (2e-5 if nseg == 3 else 2e-6)
+        hg = hd.clone().requires_grad_(True)
+        (dgel,) = torch.autograd.grad(torch.nn.functional.gelu(hg).sum(), hg)
+        assert relerr(val(dh6), (dy.double() @ w2.double()) * dgel) < (3e-5 if nseg == 3 else 3e-6)
+        # a large enough grid takes the plain one-launch product on both sides: then everything is bit-identical
 
 
 @pytest.mark.parametrize("rows,dim", [(394, 192), (1000, 768), (37, 1024), (513, 64)])
