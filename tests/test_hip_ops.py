@@ -499,7 +499,7 @@ def test_gemm_f32_bf16x6_is_fp32_accurate(ops, M, N, K):
     assert relerr(o, x.double() @ w.double().t() + b.double()) < 4e-6
 
 
-@pytest.mark.parametrize("M,D,Hd", [(512, 768, 3072), (1024, 256, 512), (2048, 192, 768)])
+@pytest.mark.parametrize("M,D,Hd", [(512, 768, 3072), (1024, 256, 512), (2048, 384, 768)])
 @pytest.mark.parametrize("nseg", [3, 6])
 def test_split_output_epilogues_equal_gemm_then_split(ops, M, D, Hd, nseg):
     """MV_EPI_SPLIT_GELU / MV_EPI_SPLIT_DGELU (round 4): fc1 and fc2-dX of the split-operand modes with the pieces of gelu(h) /
