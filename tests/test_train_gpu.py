@@ -94,6 +94,26 @@ def test_train_starts_from_local_timm_backbone(tmp_path, capsys):
         assert torch.equal(a(img), b(img))
 
 
+@pytest.mark.parametrize("precision", ["bf16x3", "bf16x3h"])
+def test_train_loop_in_the_tolerance_meeting_precisions(tmp_path, capsys, precision):
+    """The reference's classification loop (classification/train.py:226-303) with ``vit_config["precision"]`` = bf16x3 / bf16x3h (the
+    extension key ``get_models`` reads): iterations run, the loss is finite and falls on the 90-image synthetic set, checkpoints
+    reload, evaluation works -- the modes are wired through the engine, not only through the model class."""
+    from myrtle_vision.engine import evaluate, train_worker
+    cfg = _config(tmp_path, "classification")
+    cfg["vit_config"]["precision"] = precision
+    cfg["train_config"]["epochs"] = 2
+    iters = train_worker(0, 1, copy.deepcopy(cfg), "classification")
+    out = capsys.readouterr().out
+    assert iters >= 4 and "nan" not in out.lower()
+    losses = [float(l.split("loss=")[1].split()[0]) for l in out.splitlines() if l.startswith("Iteration")]
+    assert len(losses) == iters and all(l == l and l < 20 for l in losses)
+    cfg2 = copy.deepcopy(cfg)
+    cfg2["train_config"]["checkpoint_path"] = os.path.join(cfg["train_config"]["output_directory"], "vit_000002")
+    res = evaluate(cfg2, "classification")
+    assert 0.0 <= res["accuracy"] <= 1.0
+
+
 def test_quantized_evaluation_path(tmp_path):
     from myrtle_vision.engine import evaluate, train_worker
     cfg = _config(tmp_path, "classification")
