@@ -247,8 +247,16 @@ def test_split_operand_gradients_vs_oracle_full_tensors(name, precision):
     logits = vit(img)
     cross_entropy(logits, labels).backward()
     lg = logits.detach().float().cpu()
-    assert float((lg - ref_logits).abs().max() / ref_logits.abs().max()) < 1e-3
-    assert torch.equal(lg.argmax(1), ref_logits.argmax(1))
+    err = float((lg - ref_logits).abs().max() / ref_logits.abs().max())
+    assert err < 1e-3
+    if lg.dim() == 2:
+        assert torch.equal(lg.argmax(1), ref_logits.argmax(1))
+    else:
+        # 100 k upsampled pixels: bilinear interpolation puts many of them on a class boundary (top-2 margin ~ 0); every pixel whose
+        # reference margin exceeds twice the measured logit error must agree, and they are nearly all of them
+        top2 = ref_logits.topk(2, dim=1).values
+        safe = (top2[:, 0] - top2[:, 1]) > 2 * err * ref_logits.abs().max()
+        assert float(safe.float().mean()) > 0.99 and bool((lg.argmax(1) == ref_logits.argmax(1))[safe].all())
     worst = 0.0
     for k, p in vit.named_parameters():
         if ref_grads[k] is None:
