@@ -330,6 +330,36 @@ def test_shard_sampler_is_torch_distributed_sampler(n, world):
         assert set(seen) == set(range(n))
 
 
+def test_segment_scope_is_per_thread_and_follows_the_precision():
+    """Round 4 host logic: the segment count of the split-operand modes (6 = bf16x6 / fp32, 3 = bf16x3, 4 = bf16x3 + half attention)
+    is a per-THREAD scope -- forward runs on the caller's thread, backward on autograd's workers, DataLoader threads see the
+    default -- that nests and restores, and every autograd function records the value its forward ran under."""
+    import threading
+    from myrtle_vision.hip import ops
+    assert [ops.prec_segments(p) for p in ("fp32", "bf16", "bf16x3", "bf16x3h")] == [6, 6, 3, 4]
+    assert all(ops.act_dtype(p) == torch.float32 for p in ("fp32", "bf16x3", "bf16x3h")) and ops.act_dtype("bf16") == torch.bfloat16
+    with pytest.raises(ValueError):
+        ops.act_dtype("fp16")
+    assert ops.current_segments() == 6 and not ops.half_attention()
+    seen = {}
+    with ops.segments(4):
+        assert ops.current_segments() == 3 and ops.half_attention()
+        with ops.segments(6):
+            assert ops.current_segments() == 6 and not ops.half_attention()
+        t = threading.Thread(target=lambda: seen.update(other=(ops.current_segments(), ops.half_attention())))
+        t.start(); t.join()
+        assert ops.current_segments() == 3 and ops.half_attention()
+    assert seen["other"] == (6, False) and ops.current_segments() == 6
+    with pytest.raises(ValueError):
+        ops.segments(5)
+    # the pruning switch: classification only, off by default, env override
+    from myrtle_vision.models.vit import ViT
+    kw = dict(image_size=224, patch_size=16, num_classes=5, dim=64, depth=1, heads=1, mlp_dim=64)
+    assert not ViT(decoder="classification", **kw).transformer.cls_only_tail
+    assert ViT(decoder="classification", prune_dead_tokens=True, **kw).transformer.cls_only_tail
+    assert not ViT(decoder="segmentation", prune_dead_tokens=True, **kw).transformer.cls_only_tail
+
+
 def test_get_models_reads_reference_config_schema(tmp_path):
     from myrtle_vision.utils.models import get_models
     cfg = json.load(open(os.path.join(ROOT, "classification", "train_configs", "vit_tiny.json")))
