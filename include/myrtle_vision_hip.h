@@ -156,7 +156,7 @@ int mv_attention_fwd(const void* qkv, void* out, float* lse, int B, int N, int H
 int mv_attention_bwd(const void* qkv, const void* out, const void* dout, const float* lse, void* dqkv, float* colsum,
                      int B, int N, int H, float scale, mv_stream_t stream);
 /* The attention core of precision "bf16x3" (vit.py:87-96 between fp32 tensors): the fused kernels above on IEEE-half operands with
- * fp32 accumulation, softmax and OUTPUTS; N <= 208.  qkv16: half [B, N, 3, H, 64] (mv_cast to MV_F16 of the fp32 to_qkv output);
+ * fp32 accumulation, softmax and OUTPUTS; N <= 288 (N <= 208: the 13-key-tile kernels; above: the two-pass kernels of the 257-token case).  qkv16: half [B, N, 3, H, 64] (mv_cast to MV_F16 of the fp32 to_qkv output);
  * out / lse as mv_attention_fwd but out is fp32.  Backward: mv_attention_bwd_prep_f16 turns the fp32 dout [B, N, H*64] into half
  * scaled, per (image, head), by a power of two s (the slice's largest magnitude -> [2^7, 2^8): gradients lie below half's normal
  * range otherwise), leaves s in gscale[b * H + h] (device, fp32 [B * H]) and delta[b, h, n] = sum_d half(dout * s) * out.

@@ -148,7 +148,7 @@ __device__ __forceinline__ void stage_kv_dma(const bf16_t* base, long D, int N, 
 // ------------------------------------------------------------------------------------------------
 // forward: one 256-thread workgroup per (image, head); waves take 16-query tiles round-robin
 // ------------------------------------------------------------------------------------------------
-template <int NKT>
+template <int NKT, bool F16 = false>   // F16: half operands, fp32 output (precision "bf16x3h")
 __global__ __launch_bounds__(256, (NKT <= 18 ? 2 : 1)) void attn_fwd_kernel(const bf16_t* __restrict__ qkv, bf16_t* __restrict__ out,
                                                           float* __restrict__ lse, int N, int H, float scale_log2e) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -192,10 +192,10 @@ __global__ __launch_bounds__(256, (NKT <= 18 ? 2 : 1)) void attn_fwd_kernel(cons
       {
         const bf16x8 ka0 = row_frag128(sK, kp * 16, L.rf[0]), kb0 = row_frag128(sK, (kp + 1) * 16, L.rf[0]);
         const bf16x8 ka1 = row_frag128(sK, kp * 16, L.rf[1]), kb1 = row_frag128(sK, (kp + 1) * 16, L.rf[1]);
-        acc[0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ka0, qf[0], acc[0], 0, 0, 0);
-        acc[1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kb0, qf[0], acc[1], 0, 0, 0);
-        acc[0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ka1, qf[1], acc[0], 0, 0, 0);
-        acc[1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kb1, qf[1], acc[1], 0, 0, 0);
+        acc[0] = mma32<F16>(ka0, qf[0], acc[0], 0, 0, 0);
+        acc[1] = mma32<F16>(kb0, qf[0], acc[1], 0, 0, 0);
+        acc[0] = mma32<F16>(ka1, qf[1], acc[0], 0, 0, 0);
+        acc[1] = mma32<F16>(kb1, qf[1], acc[1], 0, 0, 0);
       }
 #pragma unroll
       for (int t = 0; t < 2; ++t) {
@@ -231,22 +231,31 @@ __global__ __launch_bounds__(256, (NKT <= 18 ? 2 : 1)) void attn_fwd_kernel(cons
     for (int dt = 0; dt < 4; ++dt) o[dt] = (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int u = 0; u < NKT / 2; ++u) {
-      const bf16x8 pf = pack8(st[2 * u], st[2 * u + 1]);
+      const bf16x8 pf = pack8t<F16>(st[2 * u], st[2 * u + 1]);
 #pragma unroll
       for (int dt = 0; dt < 4; ++dt) {
-        o[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(tr_frag128(sV, 32 * u, L.tr[dt]), pf, o[dt], 0, 0, 0);
+        o[dt] = mma32<F16>(tr_frag128(sV, 32 * u, L.tr[dt]), pf, o[dt], 0, 0, 0);
       }
     }
     {
       const float inv = 1.0f / sum;
 #pragma unroll
       for (int dt = 0; dt < 4; ++dt) o[dt] *= inv;
+      if constexpr (F16) {
+        if (qrow < N) {
+          float* orow = reinterpret_cast<float*>(out) + ((long)b * N + qrow) * D + h * 64;
+#pragma unroll
+          for (int dt = 0; dt < 4; ++dt) *reinterpret_cast<f32x4*>(orow + 16 * dt + 4 * g) = o[dt];
+          if (g == 0) lse[((long)b * H + h) * N + qrow] = (mx + __builtin_amdgcn_logf(sum)) * LN2;
+        }
+      } else {
       const u32x4 w0 = pair16(o[0], o[1]), w1 = pair16(o[2], o[3]);
       if (qrow < N) {
         bf16_t* orow = out + ((long)b * N + qrow) * D + h * 64;
         *reinterpret_cast<u32x4*>(orow + pair16_off(0, g)) = w0;
         *reinterpret_cast<u32x4*>(orow + pair16_off(2, g)) = w1;
         if (g == 0) lse[((long)b * H + h) * N + qrow] = (mx + __builtin_amdgcn_logf(sum)) * LN2;
+      }
       }
     }
   }
@@ -1237,11 +1246,14 @@ __device__ __forceinline__ void stage_rows_dma(const bf16_t* src, long ld, int N
   }
 }
 
-template <int NP32>
+// F16 / SPLIT: as attn_bwd4_kernel -- half operands, dout scaled per (image, head) by gscale, delta precomputed (no O loads),
+// outputs fp32 (SPLIT = 0) or the bf16 pieces of the split-operand products (SPLIT = 3 / 6) with the scale divided out
+template <int NP32, bool F16 = false, int SPLIT = 0>
 __global__ __launch_bounds__(256, 2) void attn_bwd2p_kernel(const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ out,
                                                             const bf16_t* __restrict__ dout, const float* __restrict__ lse,
                                                             bf16_t* __restrict__ dqkv, float* __restrict__ colsum, int N, int H,
-                                                            float scale) {
+                                                            float scale, const float* __restrict__ delta_in = nullptr,
+                                                            const float* __restrict__ gscale = nullptr) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr int NR = NP32 * 32;
   char* sA = smem;                           // pass A: K    pass B: Q      ([NR][64] bf16, sw128 image, rows >= N clamped)
@@ -1258,6 +1270,28 @@ __global__ __launch_bounds__(256, 2) void attn_bwd2p_kernel(const bf16_t* __rest
   const bf16_t* obase = out + (long)b * N * D + h * 64;
   bf16_t* dbase = dqkv + (long)b * N * 3 * D + h * 64;
   const float c2 = scale * LOG2E;
+  [[maybe_unused]] const float inv_s = F16 ? 1.0f / gscale[blockIdx.x] : 1.0f;
+  [[maybe_unused]] const float inv_ss = inv_s * scale;      // F16: dS leaves without the softmax scale
+  auto put4 = [&](long row, int col, f32x4 v) __attribute__((always_inline)) {     // F16 outputs: four consecutive features
+    if constexpr (SPLIT == 0) {
+      *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(dqkv) + ((long)b * N + row) * 3 * D + h * 64 + col) = v;
+    } else {
+      bf16_t* o = dqkv + ((long)b * N + row) * (SPLIT * 3 * D) + h * 64 + col;
+      bf16x4 p[3];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const bf16_t p0 = (bf16_t)v[e];
+        const float r1 = v[e] - (float)p0;
+        const bf16_t p1 = (bf16_t)r1;
+        p[0][e] = p0;
+        p[1][e] = p1;
+        p[2][e] = (bf16_t)(r1 - (float)p1);
+      }
+      constexpr int order[6] = {0, 0, 1, 0, 1, 2};
+#pragma unroll
+      for (int sg = 0; sg < SPLIT; ++sg) *reinterpret_cast<bf16x4*>(o + (long)sg * 3 * D) = p[order[sg]];
+    }
+  };
 
   stage_rows_dma(base + D, 3 * D, N, sA, NR, wave, 4, lane);
   stage_rows_dma(base + 2 * D, 3 * D, N, sB, NR, wave, 4, lane);
@@ -1290,12 +1324,18 @@ __global__ __launch_bounds__(256, 2) void attn_bwd2p_kernel(const bf16_t* __rest
       for (int ks = 0; ks < 2; ++ks) {
         qf[t][ks] = __builtin_bit_cast(bf16x8, frag(base, 3 * D, qrow, ks));
         dof[t][ks] = __builtin_bit_cast(bf16x8, frag(dobase, D, qrow, ks));
-        const bf16x8 of = __builtin_bit_cast(bf16x8, frag(obase, D, qrow, ks));
+        if constexpr (!F16) {
+          const bf16x8 of = __builtin_bit_cast(bf16x8, frag(obase, D, qrow, ks));
 #pragma unroll
-        for (int e = 0; e < 8; ++e) d += (float)dof[t][ks][e] * (float)of[e];
+          for (int e = 0; e < 8; ++e) d += (float)dof[t][ks][e] * (float)of[e];
+        }
       }
-      d += __shfl_xor(d, 16, 64);
-      d += __shfl_xor(d, 32, 64);
+      if constexpr (F16) {
+        d = delta_in[((long)b * H + h) * N + (qrow < N ? qrow : N - 1)];
+      } else {
+        d += __shfl_xor(d, 16, 64);
+        d += __shfl_xor(d, 32, 64);
+      }
       if (g == 0) sDelta[qrow] = d;                      // pass B reads it after the barrier between the passes
       dl[t] = d;
       l2[t] = sLse[qrow];
@@ -1330,20 +1370,20 @@ __global__ __launch_bounds__(256, 2) void attn_bwd2p_kernel(const bf16_t* __rest
           f32x4 st = {0.f, 0.f, 0.f, 0.f}, dp = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
           for (int ks = 0; ks < 2; ++ks) {
-            st = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kr[u & 1][kk][ks], qf[t][ks], st, 0, 0, 0);
-            dp = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vr[u & 1][kk][ks], dof[t][ks], dp, 0, 0, 0);
+            st = mma32<F16>(kr[u & 1][kk][ks], qf[t][ks], st, 0, 0, 0);
+            dp = mma32<F16>(vr[u & 1][kk][ks], dof[t][ks], dp, 0, 0, 0);
           }
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
             const int key = (2 * u + kk) * 16 + 4 * g + r;
             const float p = key < N ? __builtin_amdgcn_exp2f(st[r] * c2 - l2[t]) : 0.f;
-            ds[kk][r] = p * (dp[r] - dl[t]) * scale;
+            ds[kk][r] = F16 ? __builtin_amdgcn_fmed3f(p * (dp[r] - dl[t]), -65000.f, 65000.f) : p * (dp[r] - dl[t]) * scale;
           }
         }
-        const bf16x8 dsf = pack8(ds[0], ds[1]);
+        const bf16x8 dsf = pack8t<F16>(ds[0], ds[1]);
 #pragma unroll
         for (int dt = 0; dt < 4; ++dt)
-          dq[t][dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ktr[dt], dsf, dq[t][dt], 0, 0, 0);
+          dq[t][dt] = mma32<F16>(ktr[dt], dsf, dq[t][dt], 0, 0, 0);
       }
       __builtin_amdgcn_sched_barrier(0);
     }
@@ -1351,6 +1391,14 @@ __global__ __launch_bounds__(256, 2) void attn_bwd2p_kernel(const bf16_t* __rest
 #pragma unroll
     for (int t = 0; t < 2; ++t) {
       const int qrow = 32 * task + 16 * t + (lane & 15);
+      if constexpr (F16) {
+        if (qrow < N) {
+#pragma unroll
+          for (int dt = 0; dt < 4; ++dt) put4(qrow, 16 * dt + 4 * g, dq[t][dt] * inv_ss);
+        }
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt) dqs[dt] += dq[t][dt] * inv_ss;
+      } else {
       const u32x4 w0 = pair16(dq[t][0], dq[t][1]), w1 = pair16(dq[t][2], dq[t][3]);
       if (qrow < N) {
         bf16_t* drow = dbase + (long)qrow * 3 * D;
@@ -1359,6 +1407,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd2p_kernel(const bf16_t* __rest
       }
 #pragma unroll
       for (int dt = 0; dt < 4; ++dt) dqs[dt] += dq[t][dt];   // padded queries: lse = +inf -> p = 0 -> exact zeros
+      }
     }
   }
 
@@ -1443,23 +1492,23 @@ __global__ __launch_bounds__(256, 2) void attn_bwd2p_kernel(const bf16_t* __rest
           f32x4 sv = {0.f, 0.f, 0.f, 0.f}, dp = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
           for (int ks = 0; ks < 2; ++ks) {
-            sv = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qrf[t][ks], kf[i][ks], sv, 0, 0, 0);
-            dp = __builtin_amdgcn_mfma_f32_16x16x32_bf16(dorf[t][ks], vf[i][ks], dp, 0, 0, 0);
+            sv = mma32<F16>(qrf[t][ks], kf[i][ks], sv, 0, 0, 0);
+            dp = mma32<F16>(dorf[t][ks], vf[i][ks], dp, 0, 0, 0);
           }
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
             float p = __builtin_amdgcn_exp2f(sv[r] * c2 - l2v[t][r]);
             p = key < N ? p : 0.f;
             pp[t][r] = p;
-            ds[t][r] = p * (dp[r] - dlv[t][r]) * scale;
+            ds[t][r] = F16 ? __builtin_amdgcn_fmed3f(p * (dp[r] - dlv[t][r]), -65000.f, 65000.f) : p * (dp[r] - dlv[t][r]) * scale;
           }
         }
-        const bf16x8 pf = pack8(pp[0], pp[1]);
-        const bf16x8 dsf = pack8(ds[0], ds[1]);
+        const bf16x8 pf = pack8t<F16>(pp[0], pp[1]);
+        const bf16x8 dsf = pack8t<F16>(ds[0], ds[1]);
 #pragma unroll
         for (int dt = 0; dt < 4; ++dt) {
-          adv[i][dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(dotr[dt], pf, adv[i][dt], 0, 0, 0);
-          adk[i][dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qtr[dt], dsf, adk[i][dt], 0, 0, 0);
+          adv[i][dt] = mma32<F16>(dotr[dt], pf, adv[i][dt], 0, 0, 0);
+          adk[i][dt] = mma32<F16>(qtr[dt], dsf, adk[i][dt], 0, 0, 0);
         }
       }
     }
@@ -1467,6 +1516,20 @@ __global__ __launch_bounds__(256, 2) void attn_bwd2p_kernel(const bf16_t* __rest
     for (int i = 0; i < 2; ++i) {
       const int kt = 2 * task + i;
       const int key = kt * 16 + (lane & 15);
+      if constexpr (F16) {
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt) {
+          adk[i][dt] *= inv_ss;
+          adv[i][dt] *= inv_s;
+        }
+        if (kt < nkt_valid && key < N) {
+#pragma unroll
+          for (int dt = 0; dt < 4; ++dt) {
+            put4(key, (int)D + 16 * dt + 4 * g, adk[i][dt]);
+            put4(key, 2 * (int)D + 16 * dt + 4 * g, adv[i][dt]);
+          }
+        }
+      } else {
 #pragma unroll
       for (int dp = 0; dp < 4; dp += 2) {
         const u32x4 wk = pair16(adk[i][dp], adk[i][dp + 1]), wv = pair16(adv[i][dp], adv[i][dp + 1]);
@@ -1474,6 +1537,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd2p_kernel(const bf16_t* __rest
           *reinterpret_cast<u32x4*>(dbase + (long)key * 3 * D + D + pair16_off(dp, g)) = wk;
           *reinterpret_cast<u32x4*>(dbase + (long)key * 3 * D + 2 * D + pair16_off(dp, g)) = wv;
         }
+      }
       }
     }
     if (colsum) {                                        // padded keys: p = 0 -> exact zeros
@@ -1620,13 +1684,19 @@ __global__ __launch_bounds__(256) void attn_bwd_prep_f16_kernel(const float* __r
 extern "C" int mv_attention_fwd_f16(const void* qkv16, float* out, float* lse, int B, int N, int H, float scale,
                                     mv_stream_t stream) {
   MV_REQUIRE(B >= 0 && N > 0 && H > 0, MV_ERR_SHAPE);
-  MV_REQUIRE(N <= 208, MV_ERR_UNSUPPORTED);
+  MV_REQUIRE(N <= 288, MV_ERR_UNSUPPORTED);
   MV_REQUIRE(mv_aligned16(qkv16) && mv_aligned16(out), MV_ERR_ALIGN);
   if (B == 0) return MV_OK;
-  constexpr int smem13 = 2 * 13 * 16 * 128;
-  const int a = MV_ONCE_PER_DEVICE(set_smem(attn_fwd13_kernel<true>, smem13));
-  if (a) return MV_ERR_LAUNCH;
-  attn_fwd13_kernel<true><<<B * H, 256, smem13, (hipStream_t)stream>>>((const bf16_t*)qkv16, (bf16_t*)out, lse, N, H, scale * LOG2E);
+  if (N <= 208) {
+    constexpr int smem13 = 2 * 13 * 16 * 128;
+    const int a = MV_ONCE_PER_DEVICE(set_smem(attn_fwd13_kernel<true>, smem13));
+    if (a) return MV_ERR_LAUNCH;
+    attn_fwd13_kernel<true><<<B * H, 256, smem13, (hipStream_t)stream>>>((const bf16_t*)qkv16, (bf16_t*)out, lse, N, H, scale * LOG2E);
+  } else {                                   // the 257-token case (256^2 inputs): 18 key tiles, two workgroups per CU
+    const int a = MV_ONCE_PER_DEVICE(set_smem(attn_fwd_kernel<18, true>, fwd_smem(18)));
+    if (a) return MV_ERR_LAUNCH;
+    attn_fwd_kernel<18, true><<<B * H, 256, fwd_smem(18), (hipStream_t)stream>>>((const bf16_t*)qkv16, (bf16_t*)out, lse, N, H, scale * LOG2E);
+  }
   MV_CHECK_LAUNCH();
   return MV_OK;
 }
@@ -1645,7 +1715,7 @@ extern "C" int mv_attention_bwd_f16(const void* qkv16, const void* dout16, const
                                     const float* gscale, void* dqkv, int nseg, float* colsum, int B, int N, int H, float scale,
                                     mv_stream_t stream) {
   MV_REQUIRE(B >= 0 && N > 0 && H > 0, MV_ERR_SHAPE);
-  MV_REQUIRE(N <= 208 && (nseg == 0 || nseg == 3 || nseg == 6), MV_ERR_UNSUPPORTED);
+  MV_REQUIRE(N <= 288 && (nseg == 0 || nseg == 3 || nseg == 6), MV_ERR_UNSUPPORTED);
   MV_REQUIRE(mv_aligned16(qkv16) && mv_aligned16(dout16) && mv_aligned16(dqkv) && delta && lse && gscale, MV_ERR_ALIGN);
   if (B == 0) return MV_OK;
   constexpr int smem4 = 224 * 128 + 208 * 128 + 8192 + 224 * 64 + 2 * 224 * 4;
@@ -1657,7 +1727,20 @@ extern "C" int mv_attention_bwd_f16(const void* qkv16, const void* dout16, const
     attn_bwd4_kernel<4, true, SPLIT_><<<B * H, 256, smem4, s>>>((const bf16_t*)qkv16, nullptr, (const bf16_t*)dout16, lse,   \
                                                                 (bf16_t*)dqkv, colsum, N, H, scale, delta, gscale);           \
   }
-  if (nseg == 0) MV_BWD_F16(0) else if (nseg == 3) MV_BWD_F16(3) else MV_BWD_F16(6)
+#define MV_BWD2P_F16(SPLIT_)                                                                                                  \
+  {                                                                                                                          \
+    constexpr int smem2 = 2 * 288 * 128 + 2 * 288 * 4 + 4 * 192 * 4;                                                         \
+    const int a = MV_ONCE_PER_DEVICE(set_smem(attn_bwd2p_kernel<9, true, SPLIT_>, smem2));                                   \
+    if (a) return MV_ERR_LAUNCH;                                                                                             \
+    attn_bwd2p_kernel<9, true, SPLIT_><<<B * H, 256, smem2, s>>>((const bf16_t*)qkv16, nullptr, (const bf16_t*)dout16, lse,  \
+                                                                 (bf16_t*)dqkv, colsum, N, H, scale, delta, gscale);          \
+  }
+  if (N <= 208) {
+    if (nseg == 0) MV_BWD_F16(0) else if (nseg == 3) MV_BWD_F16(3) else MV_BWD_F16(6)
+  } else {                                   // 209 .. 288 tokens: the two-pass kernel (the 257-token case)
+    if (nseg == 0) MV_BWD2P_F16(0) else if (nseg == 3) MV_BWD2P_F16(3) else MV_BWD2P_F16(6)
+  }
+#undef MV_BWD2P_F16
 #undef MV_BWD_F16
   MV_CHECK_LAUNCH();
   return MV_OK;

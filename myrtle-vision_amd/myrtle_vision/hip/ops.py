@@ -800,8 +800,8 @@ def attention_f32_fused_supported(qkv_dtype, N, dim_head):
 
 
 def attention_f16_supported(qkv_dtype, N, dim_head):
-    """The half-operand attention core of precision "bf16x3h" (the bf16 kernels instantiated on IEEE half): fp32 q/k/v, N <= 208."""
-    return qkv_dtype == torch.float32 and dim_head == 64 and N <= 208 and half_attention()
+    """The half-operand attention core of precision "bf16x3h" (the bf16 kernels instantiated on IEEE half): fp32 q/k/v, N <= 288."""
+    return qkv_dtype == torch.float32 and dim_head == 64 and N <= 288 and half_attention()
 
 
 def cast_f16(src):

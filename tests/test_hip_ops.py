@@ -717,7 +717,7 @@ def test_attention_fused_fp32_forward(ops, B, N, H):
     assert relerr(out2, want2) < 5e-5 and torch.equal(out2, ops.attention_fwd_f32(qkv2.cuda(), B, N, H, scale))
 
 
-@pytest.mark.parametrize("B,N,H", [(2, 197, 3), (3, 50, 1), (1, 17, 12), (2, 208, 2), (1, 193, 2)])
+@pytest.mark.parametrize("B,N,H", [(2, 197, 3), (3, 50, 1), (1, 17, 12), (2, 208, 2), (1, 193, 2), (2, 257, 2), (1, 209, 1), (1, 288, 1)])
 @pytest.mark.parametrize("gscale", [1.0, 3.0e-7, 4.0e4])
 def test_attention_f16_fwd_bwd(ops, B, N, H, gscale):
     """The attention core of precision "bf16x3": the fused bf16 kernels instantiated on IEEE-half operands (fp32 sums, softmax,

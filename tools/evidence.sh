@@ -10,7 +10,7 @@
 #   _mfma_util.json     SQ_VALU_MFMA_BUSY_CYCLES / GRBM_GUI_ACTIVE pass -> MFMA-busy per family and for the attention+MLP block
 #   _kernel_stats.csv   rocprofv3 --kernel-trace of the SAME bench command (per-kernel durations)
 #   _bench.json         the headline line, run LAST so that it reads the PMC files written above (same tree, same commit)
-#   _workload_lines.jsonl  the other bench.py workloads (seg, seg256, int8, batch 32, batch 64, fp32 at batch 64, bf16x3, fp32)
+#   _workload_lines.jsonl  the other bench.py workloads (seg, seg256, int8, batch 32, batch 64, fp32 at batch 64, bf16x3h, bf16x3, fp32, seg256 in both split modes)
 #   _dist_rehearsal.jsonl  MV_FORCE_DIST=1 (one-rank RCCL group) with the fp32 and the bf16 gradient exchange
 #   _stamp.json         commit, source digest of the loaded .so, date, rocm-smi clocks
 # Counter passes use --kernel-trace + --pmc only (no sys-trace: refused on this pool).
@@ -45,7 +45,7 @@ for w in "--workload seg" "--workload seg256" "--workload infer-int8" "--batch 3
   python3 bench.py $w --steps 8 --warmup 3 --no-cpu-baseline 2>> $O/bench.err | tail -1 >> $O/${TAG}_workload_lines.jsonl
 done
 # the reference-tolerance modes next to the headline
-for w in "--precision bf16x3h" "--precision bf16x3" "--precision fp32"; do
+for w in "--precision bf16x3h" "--precision bf16x3" "--precision fp32" "--workload seg256 --precision bf16x3h" "--workload seg256 --precision bf16x3"; do
   python3 bench.py $w --steps 6 --warmup 2 --no-cpu-baseline 2>> $O/bench.err | tail -1 >> $O/${TAG}_workload_lines.jsonl
 done
 # launch-path record of the RCCL exchange with ONE rank (no multi-GPU hardware in this pool): both exchange dtypes
