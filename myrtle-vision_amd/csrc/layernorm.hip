@@ -230,12 +230,19 @@ extern "C" size_t mv_layernorm_bwd_workspace_bytes(int rows, int dim) {
   return (size_t)ln_grid(rows) * 3 * (size_t)dim * sizeof(float);
 }
 
+// launch with the grid capped at the workgroups resident at once (MV_RESIDENT_BLOCKS: the wide and the split-output forms keep
+// fewer than the eight groups per CU that the 2 048 cap assumes)
+#define LN_GO(args_, ...)                                                        \
+  do {                                                                           \
+    const int g_ = min(grid, MV_RESIDENT_BLOCKS((__VA_ARGS__), 256, 0));         \
+    __VA_ARGS__<<<g_, 256, 0, s>>> args_;                                        \
+  } while (0)
 #define LN_FWD_CASE(V)                                                                                      \
   case V:                                                                                                   \
     if (y_dtype == MV_F32)                                                                                  \
-      ln_fwd_kernel<V, float><<<grid, 256, 0, s>>>(x, ldx, gamma, beta, (float*)y, mean, rstd, rows, dim, eps); \
+      LN_GO((x, ldx, gamma, beta, (float*)y, mean, rstd, rows, dim, eps), ln_fwd_kernel<V, float>); \
     else                                                                                                    \
-      ln_fwd_kernel<V, bf16_t><<<grid, 256, 0, s>>>(x, ldx, gamma, beta, (bf16_t*)y, mean, rstd, rows, dim, eps); \
+      LN_GO((x, ldx, gamma, beta, (bf16_t*)y, mean, rstd, rows, dim, eps), ln_fwd_kernel<V, bf16_t>); \
     break;
 
 extern "C" int mv_layernorm_fwd(const float* x, long ldx, const float* gamma, const float* beta, void* y, int y_dtype,
@@ -252,15 +259,15 @@ extern "C" int mv_layernorm_fwd(const float* x, long ldx, const float* gamma, co
     LN_FWD_CASE(1) LN_FWD_CASE(2) LN_FWD_CASE(3) LN_FWD_CASE(4)
     case 5: case 6: case 7: case 8:
       if (y_dtype == MV_F32)
-        ln_fwd_kernel<8, float><<<grid, 256, 0, s>>>(x, ldx, gamma, beta, (float*)y, mean, rstd, rows, dim, eps);
+        LN_GO((x, ldx, gamma, beta, (float*)y, mean, rstd, rows, dim, eps), ln_fwd_kernel<8, float>);
       else
-        ln_fwd_kernel<8, bf16_t><<<grid, 256, 0, s>>>(x, ldx, gamma, beta, (bf16_t*)y, mean, rstd, rows, dim, eps);
+        LN_GO((x, ldx, gamma, beta, (bf16_t*)y, mean, rstd, rows, dim, eps), ln_fwd_kernel<8, bf16_t>);
       break;
     default:
       if (y_dtype == MV_F32)
-        ln_fwd_kernel<16, float><<<grid, 256, 0, s>>>(x, ldx, gamma, beta, (float*)y, mean, rstd, rows, dim, eps);
+        LN_GO((x, ldx, gamma, beta, (float*)y, mean, rstd, rows, dim, eps), ln_fwd_kernel<16, float>);
       else
-        ln_fwd_kernel<16, bf16_t><<<grid, 256, 0, s>>>(x, ldx, gamma, beta, (bf16_t*)y, mean, rstd, rows, dim, eps);
+        LN_GO((x, ldx, gamma, beta, (bf16_t*)y, mean, rstd, rows, dim, eps), ln_fwd_kernel<16, bf16_t>);
   }
   MV_CHECK_LAUNCH();
   return MV_OK;
@@ -278,14 +285,14 @@ extern "C" int mv_layernorm_fwd_split(const float* x, long ldx, const float* gam
   bf16_t* y = (bf16_t*)y_split;
 #define LN_SPLIT_CASE(V)                                                                                               \
   case V:                                                                                                              \
-    if (nseg == 3) ln_fwd_kernel<V, bf16_t, 3><<<grid, 256, 0, s>>>(x, ldx, gamma, beta, y, mean, rstd, rows, dim, eps); \
-    else ln_fwd_kernel<V, bf16_t, 6><<<grid, 256, 0, s>>>(x, ldx, gamma, beta, y, mean, rstd, rows, dim, eps);           \
+    if (nseg == 3) LN_GO((x, ldx, gamma, beta, y, mean, rstd, rows, dim, eps), ln_fwd_kernel<V, bf16_t, 3>); \
+    else LN_GO((x, ldx, gamma, beta, y, mean, rstd, rows, dim, eps), ln_fwd_kernel<V, bf16_t, 6>);           \
     break;
   switch (mv_cdiv(dim / 4, 64)) {
     LN_SPLIT_CASE(1) LN_SPLIT_CASE(2) LN_SPLIT_CASE(3)
     default:
-      if (nseg == 3) ln_fwd_kernel<4, bf16_t, 3><<<grid, 256, 0, s>>>(x, ldx, gamma, beta, y, mean, rstd, rows, dim, eps);
-      else ln_fwd_kernel<4, bf16_t, 6><<<grid, 256, 0, s>>>(x, ldx, gamma, beta, y, mean, rstd, rows, dim, eps);
+      if (nseg == 3) LN_GO((x, ldx, gamma, beta, y, mean, rstd, rows, dim, eps), ln_fwd_kernel<4, bf16_t, 3>);
+      else LN_GO((x, ldx, gamma, beta, y, mean, rstd, rows, dim, eps), ln_fwd_kernel<4, bf16_t, 6>);
   }
 #undef LN_SPLIT_CASE
   MV_CHECK_LAUNCH();
@@ -312,13 +319,18 @@ extern "C" int mv_layernorm_fwd_q8(const float* x, long ldx, const float* gamma,
   return MV_OK;
 }
 
+// grid: every workgroup resident at once (the kernel keeps 142 registers at dim 768: three groups per CU, not the four that
+// ln_grid's 1 024 assumes)
 #define LN_BWD_LAUNCH(V)                                                                                     \
-  if (dy_dtype == MV_F32)                                                                                    \
+  if (dy_dtype == MV_F32) {                                                                                  \
+    grid = min(grid, MV_RESIDENT_BLOCKS((ln_bwd_kernel<V, float>), 256, 0));                                 \
     ln_bwd_kernel<V, float><<<grid, 256, 0, s>>>((const float*)dy, x, ldx, gamma, mean, rstd, dx_add, dx, lddx, \
                                                  workspace, rows, dim, (bf16_t*)dx_bf16, dx_colsum != nullptr, nseg); \
-  else                                                                                                       \
+  } else {                                                                                                   \
+    grid = min(grid, MV_RESIDENT_BLOCKS((ln_bwd_kernel<V, bf16_t>), 256, 0));                                \
     ln_bwd_kernel<V, bf16_t><<<grid, 256, 0, s>>>((const bf16_t*)dy, x, ldx, gamma, mean, rstd, dx_add, dx, lddx, \
-                                                  workspace, rows, dim, (bf16_t*)dx_bf16, dx_colsum != nullptr, nseg);
+                                                  workspace, rows, dim, (bf16_t*)dx_bf16, dx_colsum != nullptr, nseg); \
+  }
 
 namespace {
 int ln_bwd_impl(const void* dy, int dy_dtype, const float* x, long ldx, const float* gamma, const float* mean, const float* rstd,
@@ -351,7 +363,7 @@ int ln_bwd_impl(const void* dy, int dy_dtype, const float* x, long ldx, const fl
              MV_ERR_ALIGN);
   MV_REQUIRE(workspace_bytes >= mv_layernorm_bwd_workspace_bytes(rows, dim), MV_ERR_WORKSPACE);
   hipStream_t s = (hipStream_t)stream;
-  const int grid = ln_grid(rows);
+  int grid = ln_grid(rows);
   if (rows > 0) {
     const int vpl = mv_cdiv(dim / 4, 64);
     switch (vpl) {

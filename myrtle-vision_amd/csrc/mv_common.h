@@ -40,6 +40,26 @@ inline int mv_cu_count() {
   return n;
 }
 
+// Workgroups of `kernel_` (threads_ per group, dyn_lds_ bytes of dynamic LDS) that are RESIDENT on the current device at once:
+// the grid of a grid-stride kernel whose register count limits occupancy.  A larger grid runs in rounds, and the last round
+// leaves most of the chip idle (LayerNorm backward: 1 024 groups against 768 resident ran 1.33 rounds, -22 %).
+#define MV_RESIDENT_BLOCKS(kernel_, threads_, dyn_lds_)                                                        \
+  ([&]() -> int {                                                                                              \
+    static std::atomic<int> n_[32] = {};                                                                       \
+    int d_ = 0;                                                                                                \
+    const bool have_ = hipGetDevice(&d_) == hipSuccess && d_ >= 0 && d_ < 32;                                  \
+    if (have_) {                                                                                               \
+      const int c_ = n_[d_].load(std::memory_order_acquire);                                                   \
+      if (c_ > 0) return c_;                                                                                   \
+    }                                                                                                          \
+    int per_cu_ = 0;                                                                                           \
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu_, kernel_, threads_, dyn_lds_) != hipSuccess || per_cu_ <= 0) \
+      per_cu_ = 1;                                                                                             \
+    const int r_ = per_cu_ * mv_cu_count();                                                                    \
+    if (have_) n_[d_].store(r_, std::memory_order_release);                                                    \
+    return r_;                                                                                                 \
+  }())
+
 typedef __bf16 bf16_t;
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
 typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;

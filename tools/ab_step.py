@@ -5,6 +5,8 @@ blocks of STEPS steps for ROUNDS rounds (cdna guide rule 24); prints mean, std a
     NT_VARIANTS=3000,3002 ROUNDS=10 STEPS=10 python tools/ab_step.py      # column bands off / on (compare PAIRS only: with more
                                                                            # than two arms each one always follows the same predecessor)
     GELU_BITS=8,16 ROUNDS=8 python tools/ab_step.py        # instead: width of the gelu' the MLP block keeps (functional.GELU_GRAD_BITS)
+    LIBS=a.so,b.so python tools/ab_step.py                 # instead: two BUILDS of the library take turns in the one process (variants
+                                                           # 0 and 1; both are loaded, every op goes through the selected handle)
 """
 import os
 import statistics
@@ -23,14 +25,29 @@ from myrtle_vision.utils.utils import seed_everything  # noqa: E402
 import myrtle_vision.hip.functional as _F  # noqa: E402
 
 GELU_AB = "GELU_BITS" in os.environ
+LIB_AB = "LIBS" in os.environ
 TN_AB = "TN_VARIANTS" in os.environ              # TN_VARIANTS=128,256: dW kernels forced
 ATTN_AB = "ATTN_BWD_VARIANTS" in os.environ      # ATTN_BWD_VARIANTS=4,5: attention backward with four / two waves per workgroup
+HANDLES = []
+if LIB_AB:
+    import ctypes
+    import myrtle_vision.hip.lib as _L
+    for path in os.environ["LIBS"].split(","):
+        h = ctypes.CDLL(os.path.abspath(path))
+        for name, (kinds, ret) in _L.SIGNATURES.items():
+            fn = getattr(h, name)
+            fn.argtypes = [_L._KIND[k] for k in kinds]
+            fn.restype = ret
+        HANDLES.append(h)
+    os.environ["NT_VARIANTS"] = ",".join(str(i) for i in range(len(HANDLES)))
 VARIANTS = [int(v) for v in os.environ.get("GELU_BITS" if GELU_AB else "TN_VARIANTS" if TN_AB else "ATTN_BWD_VARIANTS" if ATTN_AB
                                            else "NT_VARIANTS", "3000,3002").split(",")]
 
 
 def select(v):
-    if GELU_AB:
+    if LIB_AB:
+        _L._lib = HANDLES[v]
+    elif GELU_AB:
         _F.GELU_GRAD_BITS = v
     elif TN_AB:
         lib().mv_gemm_force_variant(0, v)
@@ -75,7 +92,7 @@ for r in range(ROUNDS):
         e.record()
         torch.cuda.synchronize()
         times[v].append(s.elapsed_time(e) / STEPS)
-if not GELU_AB:
+if not GELU_AB and not LIB_AB:
     lib().mv_gemm_force_variant(0, 0)
 for v in VARIANTS:
     t = times[v]
