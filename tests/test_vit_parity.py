@@ -196,8 +196,8 @@ def test_bf16x3_matches_reference(name):
 
 @pytest.mark.parametrize("name", CASES)
 def test_bf16x3h_matches_reference(name):
-    """``precision="bf16x3h"``: bf16x3 with the attention core on IEEE-half operands (fp32 sums, softmax and outputs; 197-token
-    models -- the 257-token fixtures run the fp32 core as in bf16x3).  Against the REFERENCE: logits and loss at north_star's 1e-3
+    """``precision="bf16x3h"``: bf16x3 with the attention core on IEEE-half operands (fp32 sums, softmax and outputs; up to
+    288 tokens: the 197- and the 257-token fixtures alike).  Against the REFERENCE: logits and loss at north_star's 1e-3
     (measured <= 1.6e-4), bit-exact class indices, gradient norms and sampled values at 1e-3; every gradient element is held to
     1e-3 (relative L2 per tensor) through the fp32 mode in test_bf16x3h_vs_fp32_full_tensors."""
     check_case(name, "bf16x3h", 1e-3, 1e-3)
@@ -227,6 +227,69 @@ def test_bf16x3h_vs_fp32_full_tensors(name):
         worst = max(worst, e)
         assert e < 1e-3, (k, e)
     report(f"{name}/bf16x3h-vs-fp32 grad-rel-l2", worst)
+
+
+@pytest.mark.parametrize("precision", ["fp32", "bf16x3h", "bf16"])
+def test_config4_at_its_own_shape_batch_64(precision):
+    """Config 4 (ViT-B/16 segmentation on 256^2 inputs, 257 tokens) at a production batch, against the REFERENCE through the batch-1
+    fixture ``base_seg_256`` and two size-independent properties:
+      (A) a batch of 64 copies of the fixture's image and mask: every copy's logits, the loss and every gradient summary are the
+          fixture's (the mean over identical items), at the precision's own bar -- the whole training step at batch 64;
+      (B) the fixture's image at positions 0, 17 and 63 of a batch of 64 otherwise different images: its logits are still the
+          fixture's, and every OTHER image's logits equal what that image gives in a batch of 4 (no leakage between images in the
+          257-token attention, the position-embedding resize, the decoder or the upsampling at this batch)."""
+    from myrtle_vision.hip.functional import cross_entropy
+    exact = precision in EXACT
+    tol = 1e-3 if exact else BF16_LOGITS
+    tol_g = 1e-3 if exact else 3e-2
+    vit, img1, lab1, arrays, meta = build("base_seg_256", precision)
+    vit.train()
+    want = arrays["logits_sub"]
+    scale = float(np.abs(want).max())
+    # (A)
+    img, lab = img1.expand(64, -1, -1, -1).contiguous(), lab1.expand(64, -1, -1).contiguous()
+    logits = vit(img)
+    loss = cross_entropy(logits, lab)
+    loss.backward()
+    sub = logits.detach().float()[:, :, ::7, ::7].cpu().numpy()
+    e = float(np.abs(sub - want).max() / scale)
+    report(f"config4-b64/{precision} logits", e)
+    assert e < tol
+    if exact:
+        assert (sub.argmax(1) == arrays["argmax_sub"]).all()
+    assert abs(float(loss) - float(arrays["loss"])) < tol * max(1.0, abs(float(arrays["loss"])))
+    worst = 0.0
+    for pname, p in vit.named_parameters():
+        if p.grad is None:
+            continue
+        w = arrays[f"gsum:{canonical(pname)}"]
+        got = summarize(p.grad.float().cpu()).numpy()
+        if precision == "fp32":
+            e = max(np.abs(got[:4] - w[:4]).max() / max(w[1], 1e-30), np.abs(got[4:] - w[4:]).max() / max(w[2], 1e-30))
+        else:                       # norms and sampled values (see check_case)
+            e = max(abs(got[1] - w[1]) / max(w[1], 1e-30), abs(got[2] - w[2]) / max(w[2], 1e-30),
+                    np.abs(got[4:] - w[4:]).max() / max(w[2], 1e-30))
+        worst = max(worst, e)
+        assert e < tol_g, (pname, e)
+    report(f"config4-b64/{precision} grad-summaries", worst)
+    # (B)
+    vit.zero_grad(set_to_none=True)
+    others = det_images("config4_batch", 64, 256).cuda()
+    mixed = others.clone()
+    for pos in (0, 17, 63):
+        mixed[pos] = img1[0]
+    with torch.no_grad():
+        lm = vit(mixed).float()
+        for pos in (0, 17, 63):
+            got = lm[pos:pos + 1, :, ::7, ::7].cpu().numpy()
+            assert float(np.abs(got - want).max() / scale) < tol
+        # fp32-accumulating paths are batch-independent to rounding; the bound is the precision's own rounding unit
+        small = {"fp32": 2e-5, "bf16x3h": 2e-4, "bf16": 2e-5}[precision]
+        for lo in (4, 28, 56):
+            alone = vit(mixed[lo:lo + 4].contiguous()).float()
+            e = float((alone - lm[lo:lo + 4]).abs().max() / lm.abs().max())
+            report(f"config4-b64/{precision} batch-independence", e)
+            assert e < small, (lo, e)
 
 
 @pytest.mark.parametrize("name", ["micro_cls", "micro_seg", "tiny_cls"])
