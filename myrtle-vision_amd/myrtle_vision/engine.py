@@ -7,11 +7,14 @@ seeding, batch-size solver, one process per GPU, rank-0 checkpoints every ``iter
 
 * compute runs on the HIP kernels (model, loss, optimizer); no CPU fallback;
 * gradients are exchanged by ``utils.ddp.GradAllReducer`` over RCCL, and only on the LAST micro-batch of an
-  accumulation window (the reference's DDP all-reduces every micro-batch; the result is identical);
+  accumulation window (the reference's DDP all-reduces every micro-batch; the result is identical) -- except when
+  ``clip_grad`` is set with ``n_batch_accum > 1``: then every micro-batch is exchanged, because the reference clips the
+  running accumulated (and already averaged) gradient after every backward, and that needs the averaged gradient each time;
 * the two detection-only parameters are left out of the optimizer/all-reduce (the reference's DDP dies on them);
 * ``GradScaler`` is dropped (a numerical no-op without autocast, SURVEY 9.5);
-* ``clip_grad`` clips the gradient of the whole optimizer step (after accumulation and all-reduce) rather than after every
-  micro-batch backward: identical when ``n_batch_accum == 1``, the well-defined variant otherwise;
+* ``clip_grad`` is the reference's ``clip_grad_norm_`` after EVERY micro-batch backward on the running accumulated gradient
+  (classification/train.py:265-270): the intermediate clips rescale the gradient arena in place
+  (``AdamW.clip_accumulated``), the last one rides into the AdamW kernel as a device scalar;
 * ``pretrained_backbone`` must be a local timm-format state dict (no network); a bare timm model NAME that is not a
   file means "random init" with a warning.
 """
@@ -266,13 +269,12 @@ def train_worker(rank, num_gpus, config, task="classification"):
     reducer = GradAllReducer(optimizer.arena, exchange_dtype=exchange_dtype_from_env())   # MV_DDP_EXCHANGE=bf16: half-width, opt-in
     broadcast_parameters(optimizer.arena)
     optimizer.grad_scale = reducer.grad_scale
-    # classification/train.py:265-270 (clip_grad_norm_ after backward): here the norm is taken once per optimizer step over
-    # the flat (all-reduced, accumulated) gradient arena and the coefficient is applied inside the AdamW kernel
+    # classification/train.py:265-270 (clip_grad_norm_ after EVERY backward, on the running accumulated gradient): the norm is
+    # taken over the flat (all-reduced) gradient arena; on the last micro-batch of a window the coefficient is applied inside the
+    # AdamW kernel, on the earlier ones the arena is rescaled in place (which needs the averaged gradient: those micro-batches are
+    # exchanged too, as the reference's DDP does on every backward)
     optimizer.max_grad_norm = optimizer_args.clip_grad
-    if optimizer_args.clip_grad is not None and n_batch_accum > 1 and rank == 0:
-        print(f"WARNING: clip_grad={optimizer_args.clip_grad} with n_batch_accum={n_batch_accum}: the reference clips the "
-              "running accumulated gradient after EVERY micro-batch backward (classification/train.py:265-270); this loop "
-              "clips once per optimizer step, after accumulation and all-reduce.  The two differ whenever a clip engages.")
+    clip_every = optimizer_args.clip_grad is not None and n_batch_accum > 1
     scalars = _Scalars(train_config.get("tensorboard_dir", "runs/")) if (task == "segmentation" and rank == 0) else None
 
     vit.train()
@@ -297,7 +299,7 @@ def train_worker(rank, num_gpus, config, task="classification"):
                     scalars.add_scalar("miou", last_val[2], iteration)
             if n_accum == 0:
                 optimizer.zero_grad()
-            reducer.enabled = reducer.world > 1 and (n_accum == n_batch_accum - 1)
+            reducer.enabled = reducer.world > 1 and (clip_every or n_accum == n_batch_accum - 1)
             if _fused_seg_tail(task, criterion):
                 loss, acc_t, _ = vit.segmentation_loss(imgs, labels)
             else:
@@ -306,6 +308,9 @@ def train_worker(rank, num_gpus, config, task="classification"):
                 acc_t = None
             loss.backward()
             n_accum += 1
+            if clip_every and n_accum < n_batch_accum:
+                reducer.finish()
+                optimizer.clip_accumulated()
             if n_accum == n_batch_accum:
                 n_accum = 0
                 reducer.finish()

@@ -149,6 +149,19 @@ class AdamW:
         self.arena.zero_grad()
 
     @torch.no_grad()
+    def clip_accumulated(self):
+        """``clip_grad_norm_`` on the running accumulated gradient BETWEEN the micro-batches of an accumulation window
+        (classification/train.py:265-270 runs it after every backward): the arena becomes grad_scale * coefficient * itself, in
+        place -- the pending 1/world of a SUM all-reduce is applied here, so the next micro-batch adds to the averaged, clipped
+        gradient exactly as the reference's does.  No host synchronisation (norm and coefficient stay on the device)."""
+        if self.max_grad_norm is None:
+            return
+        self.arena.sync_grads()
+        a = self.arena
+        self.last_grad_norm = ops.grad_norm_clip(a.flat_grad, self.max_grad_norm, self.grad_scale)
+        a.flat_grad.mul_(self.last_grad_norm[1] * self.grad_scale)
+
+    @torch.no_grad()
     def step(self):
         self.arena.sync_grads()
         if self._hyper is None:

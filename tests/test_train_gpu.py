@@ -55,6 +55,25 @@ def test_train_loop_writes_reloadable_checkpoints(tmp_path, task, capsys):
     assert 0.0 <= res["accuracy"] <= 1.0
 
 
+def test_train_loop_clips_after_every_micro_batch(tmp_path, capsys):
+    """clip_grad with gradient accumulation through the real loop (classification/train.py:265-270: clip_grad_norm_ after EVERY
+    backward): local 4 / global 8 = two micro-batches per iteration, a threshold that engages.  The loop must run without the old
+    "clips once per step" warning and take finite steps; the arithmetic of the sequence (backward, clip, backward, clip, step) is
+    held to torch's in test_clip_grad_after_every_micro_batch_matches_the_reference_loop."""
+    from myrtle_vision.engine import train_worker
+    cfg = _config(tmp_path, "classification")
+    cfg["train_config"].update(local_batch_size=4, global_batch_size=8, iters_per_checkpoint=1, iters_per_val=1000)
+    cfg["train_config"]["clip_grad"] = 0.05
+    iters = train_worker(0, 1, copy.deepcopy(cfg), "classification")
+    out = capsys.readouterr().out
+    assert iters >= 2 and "WARNING: clip_grad" not in out and "nan" not in out.lower()
+    d = cfg["train_config"]["output_directory"]
+    ck0 = torch.load(os.path.join(d, "vit_000000"), map_location="cpu", weights_only=False)
+    ck1 = torch.load(os.path.join(d, "vit_000001"), map_location="cpu", weights_only=False)
+    moved = max(float((ck1["model"][k].float() - ck0["model"][k].float()).abs().max()) for k in ck0["model"])
+    assert 0 < moved < 1e-2                      # one AdamW step at the configured learning rate, finite
+
+
 def test_train_starts_from_local_timm_backbone(tmp_path, capsys):
     """Row f4 end to end (segmentation/train.py:98,163-175; classification configs carry the same key): ``pretrained_backbone``
     = a LOCAL timm-format state dict.  The loop must start from exactly the renamed weights -- the iteration-0 checkpoint it
@@ -463,6 +482,60 @@ def test_clip_grad_matches_torch_clip_grad_norm(tmp_path):
         assert (coef < 1.0) == (max_norm < float(total))
         for (n, rp), (_, p) in zip(ref_params, used):
             assert torch.allclose(p.detach(), rp.detach(), rtol=2e-6, atol=2e-7), n
+
+
+@pytest.mark.parametrize("grad_scale", [1.0, 0.5])
+def test_clip_grad_after_every_micro_batch_matches_the_reference_loop(grad_scale):
+    """clip_grad with n_batch_accum = 2 (classification/train.py:257-275): backward, clip_grad_norm_ on the RUNNING accumulated
+    gradient, backward again (accumulating onto the clipped gradient), clip again, step.  Here: AdamW.clip_accumulated between the
+    micro-batches (arena rescaled in place) and the last clip inside the AdamW kernel, against torch doing exactly the reference's
+    sequence on copies.  grad_scale = 0.5 plays a two-rank SUM all-reduce whose 1/world is still pending (both "ranks" hold the
+    same data, so the exchange doubles the arena): the first clip must apply the 1/world, and so must the step."""
+    from myrtle_vision.hip.functional import cross_entropy
+    from myrtle_vision.models.vit import ViT
+    from myrtle_vision.utils.optim import AdamW, ParamArena
+    from myrtle_vision.utils.utils import seed_everything
+    from oracle.optim_oracle import reference_adamw
+    kw = dict(decoder="classification", image_size=224, patch_size=16, num_classes=7, dim=128, depth=2, heads=2, mlp_dim=256)
+    g = torch.Generator().manual_seed(3)
+    imgs = [torch.randn(4, 3, 224, 224, generator=g).cuda() for _ in range(2)]
+    labs = [torch.randint(0, 7, (4,), generator=g).cuda() for _ in range(2)]
+    world = round(1.0 / grad_scale)
+    for max_norm in (0.05, 1e6):
+        seed_everything(5)
+        vit = ViT(precision="fp32", q_format="FP32", **kw).cuda()
+        opt = AdamW(ParamArena(vit.named_parameters(), skip=vit.unused_parameter_names()), lr=1e-3, weight_decay=0.05)
+        opt.max_grad_norm, opt.grad_scale = max_norm, grad_scale
+        start = {n: p.detach().clone() for n, p in vit.named_parameters()}
+        opt.zero_grad()
+        micro = []                                                   # the per-micro-batch gradients, for the torch side
+        for k in range(2):
+            before = opt.arena.flat_grad.clone()
+            cross_entropy(vit(imgs[k]), labs[k]).backward()
+            opt.arena.sync_grads()
+            micro.append(opt.arena.flat_grad - before)
+            opt.arena.flat_grad.mul_(world)                          # the SUM all-reduce over `world` ranks holding the same data
+            if k == 0:
+                opt.clip_accumulated()
+                first = [float(v) for v in opt.last_grad_norm.tolist()]
+        used = [(n, p) for n, p in vit.named_parameters() if p.grad is not None]
+        ref_params = [(n, torch.nn.Parameter(start[n].clone())) for n, _ in used]
+        ref_opt = reference_adamw(ref_params, lr=1e-3, weight_decay=0.05)
+        totals = []
+        for k in range(2):
+            for (n, rp), (_, p) in zip(ref_params, used):
+                lo = p.grad.data_ptr() - opt.arena.flat_grad.data_ptr()
+                gk = micro[k][lo // 4: lo // 4 + p.numel()].view_as(p)
+                rp.grad = gk.clone() if rp.grad is None else rp.grad + gk
+            totals.append(float(torch.nn.utils.clip_grad_norm_([rp for _, rp in ref_params], max_norm)))
+        ref_opt.step()
+        opt.step()
+        assert abs(first[0] - totals[0]) < 1e-5 * totals[0]
+        got_norm, coef = (float(v) for v in opt.last_grad_norm.tolist())
+        assert abs(got_norm - totals[1]) < 2e-5 * totals[1]
+        assert (coef < 1.0) == (max_norm < totals[1])
+        for (n, rp), (_, p) in zip(ref_params, used):
+            assert torch.allclose(p.detach(), rp.detach(), rtol=5e-6, atol=5e-7), n
 
 
 def test_dropout_statistics_determinism_and_backward():
