@@ -45,12 +45,17 @@ def timeit_variants(fn, rounds=3, iters=8):
 rows = []
 for name, N, K, epi in [("qkv fwd", 2304, 768, "none"), ("proj fwd +res", 768, 768, "res"), ("fc1 fwd +gelu", 3072, 768, "gelu"),
                         ("fc1 fwd +gelu+grad", 3072, 768, "gelugrad"),
-                        ("fc2 fwd +res", 768, 3072, "res"), ("plain bf16 out N=3072", 3072, 768, "none"), ("plain K=3072", 768, 3072, "none")]:
+                        ("fc2 fwd +res", 768, 3072, "res"), ("plain bf16 out N=3072", 3072, 768, "none"), ("plain K=3072", 768, 3072, "none"),
+                        ("plain K=3072 fp32 out", 768, 3072, "none32"), ("plain N=K=768", 768, 768, "none"),
+                        ("plain N=K=768 fp32 out", 768, 768, "none32")]:
     w, b = torch.randn(N, K, device=dev) * K ** -0.5, torch.randn(N, device=dev)
     def make(N=N, K=K, epi=epi, w=w, b=b):
         x = rnd(M, K)
         if epi == "none":
             out = torch.empty(M, N, device=dev, dtype=torch.bfloat16)
+            return lambda: ops.linear_fwd(x, M, K, w, b, out, N)
+        if epi == "none32":                 # fp32 output without the residual read: separates the epilogue's store from its load
+            out = torch.empty(M, N, device=dev)
             return lambda: ops.linear_fwd(x, M, K, w, b, out, N)
         if epi == "res":
             out, res = torch.empty(M, N, device=dev), torch.randn(M, N, device=dev)
