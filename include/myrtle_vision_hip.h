@@ -243,6 +243,11 @@ int mv_split2_bf16(const float* x, long ldx, void* out, long ldo, long seg, long
                    mv_stream_t stream);
 int mv_split2_bf16_ex(const float* x, long ldx, const float* h, long ldh, int op, void* out, long rows, int cols,
                       float* colsum, float* workspace, size_t workspace_bytes, mv_stream_t stream);
+/* The right-operand pieces of an nn.Linear weight w [R = out, C = in] (fp32, dense) for BOTH of its split-operand products from
+ * one read: fwd [R, nseg * C] = mv_split2/3_bf16(w, role 1) (y = x W^T, vit.py:48-51,86,98) and dx [C, nseg * R] = the same of w^T
+ * (dx = dy W); either may be NULL.  nseg = 3 | 6; R and C even.  Replaces a transposed fp32 copy + two split passes per weight and
+ * optimizer step. */
+int mv_weight_split(const float* w, void* fwd, void* dx, int R, int C, int nseg, mv_stream_t stream);
 int mv_gemm_tn_bf16_x3(const void* A3, const void* B3, float* C, int ldc, int M, int N, int rows, float* workspace,
                        size_t workspace_bytes, mv_stream_t stream);
 /* weight prep for the MFMA path: w fp32 [R, C] -> w_bf16 [R, ldw] and wt_bf16 [C, ldt] (transposed), pads zeroed;

@@ -218,6 +218,61 @@ __global__ __launch_bounds__(256) void weight_prep_batch_kernel(const mv_weight_
   weight_prep_tile64(it.w, (bf16_t*)it.w_bf16, it.ldw, (bf16_t*)it.wt_bf16, it.ldt, it.R, it.C, ty * 64, tx * 64, tile);
 }
 
+// The right-operand (role 1) bf16 pieces of an nn.Linear weight for the split-operand products, BOTH layouts from one read of w:
+//   fwd [R, NSEG * C]: the pieces of w      (y  = x W^T),   segments C apart:  b0 b1 b0 (b2 b1 b0)
+//   dx  [C, NSEG * R]: the pieces of w^T    (dx = dy W),    segments R apart
+// (mv_split2_bf16 / mv_split3_bf16 role 1 of w and of a transposed copy of w: the same values, without the copy and the second pass).
+template <int NSEG>
+__global__ __launch_bounds__(256) void weight_split_kernel(const float* __restrict__ w, bf16_t* __restrict__ fwd,
+                                                           bf16_t* __restrict__ dx, int R, int C) {
+  typedef __attribute__((ext_vector_type(2))) bf16_t bf16x2;
+  __shared__ float tile[64][65];
+  constexpr int order[6] = {0, 1, 0, 2, 1, 0};
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;  // 32 x 8
+  const int r0 = blockIdx.y * 64, c0 = blockIdx.x * 64;
+  auto pieces = [](float v, bf16_t (&p)[3]) {
+    p[0] = (bf16_t)v;
+    const float r1 = v - (float)p[0];
+    p[1] = (bf16_t)r1;
+    p[2] = (bf16_t)(r1 - (float)p[1]);
+  };
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    const int r = r0 + ty + 8 * i, c = c0 + 2 * tx;       // C, R even (host): a pair is inside or outside together
+    float a = 0.f, b = 0.f;
+    if (r < R && c < C) {
+      const float2 v = *reinterpret_cast<const float2*>(w + (long)r * C + c);
+      a = v.x;
+      b = v.y;
+    }
+    tile[ty + 8 * i][2 * tx] = a;
+    tile[ty + 8 * i][2 * tx + 1] = b;
+    if (fwd && r < R && c < C) {
+      bf16_t pa[3], pb[3];
+      pieces(a, pa);
+      pieces(b, pb);
+#pragma unroll
+      for (int sg = 0; sg < NSEG; ++sg)
+        *reinterpret_cast<bf16x2*>(fwd + (long)r * NSEG * C + (long)sg * C + c) = bf16x2{pa[order[sg]], pb[order[sg]]};
+    }
+  }
+  __syncthreads();
+  if (dx) {
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const int c = c0 + ty + 8 * i, r = r0 + 2 * tx;      // dx[c][sg * R + r], dx[c][sg * R + r + 1]
+      if (c < C && r < R) {
+        bf16_t pa[3], pb[3];
+        pieces(tile[2 * tx][ty + 8 * i], pa);
+        pieces(tile[2 * tx + 1][ty + 8 * i], pb);
+#pragma unroll
+        for (int sg = 0; sg < NSEG; ++sg)
+          *reinterpret_cast<bf16x2*>(dx + (long)c * NSEG * R + (long)sg * R + r) = bf16x2{pa[order[sg]], pb[order[sg]]};
+      }
+    }
+  }
+}
+
 template <typename T>
 __global__ void gelu_fwd_kernel(const T* __restrict__ x, T* __restrict__ y, long n) {
   for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x)
@@ -1096,6 +1151,18 @@ extern "C" int mv_weight_prep_batch(const mv_weight_prep_item* items_device, int
   if (count == 0) return MV_OK;
   MV_REQUIRE(items_device != nullptr, MV_ERR_SHAPE);
   weight_prep_batch_kernel<<<total_blocks, 256, 0, S_>>>(items_device, count);
+  MV_CHECK_LAUNCH();
+  return MV_OK;
+}
+
+extern "C" int mv_weight_split(const float* w, void* fwd, void* dx, int R, int C, int nseg, mv_stream_t stream) {
+  MV_REQUIRE(R > 0 && C > 0 && R % 2 == 0 && C % 2 == 0 && (nseg == 3 || nseg == 6) && (fwd || dx), MV_ERR_SHAPE);
+  MV_REQUIRE(mv_aligned16(w) && (!fwd || mv_aligned16(fwd)) && (!dx || mv_aligned16(dx)), MV_ERR_ALIGN);
+  const dim3 grid(mv_cdiv(C, 64), mv_cdiv(R, 64));
+  if (nseg == 3)
+    weight_split_kernel<3><<<grid, 256, 0, S_>>>(w, (bf16_t*)fwd, (bf16_t*)dx, R, C);
+  else
+    weight_split_kernel<6><<<grid, 256, 0, S_>>>(w, (bf16_t*)fwd, (bf16_t*)dx, R, C);
   MV_CHECK_LAUNCH();
   return MV_OK;
 }

@@ -519,13 +519,27 @@ def split_weight(weight: torch.Tensor, which: str) -> torch.Tensor:
         sw.version, sw.ptr, sw.fwd, sw.dx, sw.epoch = weight._version, weight.data_ptr(), {}, {}, epoch
     n_out, k_in = weight.shape
     nseg = current_segments()
+    have = sw.fwd if which == "fwd" else sw.dx
+    if nseg in have:
+        return have[nseg]
+    if weight.is_contiguous() and n_out % 2 == 0 and k_in % 2 == 0:
+        # one read of w gives both layouts (mv_weight_split); a weight that takes gradients will be asked for the other one in
+        # this step's backward, so both are made now -- one launch per weight and optimizer step, no transposed fp32 copy
+        both = weight.requires_grad and torch.is_grad_enabled()
+        want_fwd, want_dx = which == "fwd" or both, which == "dx" or both
+        fwd = _split_buffer(n_out, k_in, weight.device) if want_fwd and nseg not in sw.fwd else None
+        dx = _split_buffer(k_in, n_out, weight.device) if want_dx and nseg not in sw.dx else None
+        check(lib().mv_weight_split(_p(weight.detach()), _p(fwd), _p(dx), n_out, k_in, nseg, _s()), "weight_split", R=n_out, C=k_in)
+        if fwd is not None:
+            sw.fwd[nseg] = fwd
+        if dx is not None:
+            sw.dx[nseg] = dx
+        return have[nseg]
     if which == "fwd":
-        if nseg not in sw.fwd:
-            sw.fwd[nseg] = split3(weight.detach().contiguous(), n_out, k_in, k_in, 1)
-        return sw.fwd[nseg]
-    if nseg not in sw.dx:
+        sw.fwd[nseg] = split3(weight.detach().contiguous(), n_out, k_in, k_in, 1)
+    else:
         sw.dx[nseg] = split3(weight.detach().t().contiguous(), k_in, n_out, n_out, 1)
-    return sw.dx[nseg]
+    return have[nseg]
 
 
 def _x6_nt_ok(M, N, Kc):

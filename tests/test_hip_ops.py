@@ -717,6 +717,33 @@ def test_attention_fused_fp32_forward(ops, B, N, H):
     assert relerr(out2, want2) < 5e-5 and torch.equal(out2, ops.attention_fwd_f32(qkv2.cuda(), B, N, H, scale))
 
 
+@pytest.mark.parametrize("R,C", [(768, 3072), (1000, 768), (8, 12), (2304, 768)])
+@pytest.mark.parametrize("nseg", [3, 6])
+def test_weight_split_equals_the_two_split_passes(ops, R, C, nseg):
+    """mv_weight_split: the role-1 pieces of an nn.Linear weight for its forward product and of its transpose for the dX product,
+    both from one read -- bit-identical to mv_split2/3_bf16(role 1) of w and of a transposed copy; and ops.split_weight hands out
+    exactly those (a parameter that takes gradients gets both layouts in one launch)."""
+    from myrtle_vision.hip.lib import lib, check
+    w = (torch.randn(R, C, generator=g(1)) * 0.3).cuda()
+    with ops.segments(nseg):
+        want_f = ops.split3(w, R, C, C, 1)
+        want_t = ops.split3(w.t().contiguous(), C, R, R, 1)
+        fwd = torch.full((R, nseg * C), float("nan"), dtype=torch.bfloat16, device="cuda")
+        dx = torch.full((C, nseg * R), float("nan"), dtype=torch.bfloat16, device="cuda")
+        check(lib().mv_weight_split(w.data_ptr(), fwd.data_ptr(), dx.data_ptr(), R, C, nseg, torch.cuda.current_stream().cuda_stream),
+              "weight_split")
+        assert torch.equal(fwd, want_f) and torch.equal(dx, want_t)
+        only = torch.full_like(dx, float("nan"))
+        check(lib().mv_weight_split(w.data_ptr(), None, only.data_ptr(), R, C, nseg, torch.cuda.current_stream().cuda_stream),
+              "weight_split")
+        assert torch.equal(only, want_t)
+        p = torch.nn.Parameter(w.clone())
+        assert torch.equal(ops.split_weight(p, "fwd"), want_f) and torch.equal(ops.split_weight(p, "dx"), want_t)
+        with torch.no_grad():
+            p.mul_(2.0)                                                   # version bump: both layouts refresh
+        assert torch.equal(ops.split_weight(p, "dx").float(), want_t.float() * 2) and torch.equal(ops.split_weight(p, "fwd").float(), want_f.float() * 2)
+
+
 @pytest.mark.parametrize("B,N,H", [(2, 197, 3), (3, 50, 1), (1, 17, 12), (2, 208, 2), (1, 193, 2), (2, 257, 2), (1, 209, 1), (1, 288, 1)])
 @pytest.mark.parametrize("gscale", [1.0, 3.0e-7, 4.0e4])
 def test_attention_f16_fwd_bwd(ops, B, N, H, gscale):
