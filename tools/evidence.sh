@@ -35,7 +35,7 @@ cd $R
 db() { ls $O/$1/*.db $O/$1/*/*.db 2>/dev/null | head -1; }
 python3 tools/pmc_traffic.py $(db pf) $(db pw) $O/${TAG}_pmc_traffic.json
 python3 tools/pmc_mfma_util.py $(db pu) $O/${TAG}_mfma_util.json
-python3 tools/rocpd_kernel_stats.py $(db pk) $O/${TAG}_kernel_stats.csv 10 | head -20 | cut -c1-150
+python3 tools/rocpd_kernel_stats.py $(db pk) $O/${TAG}_kernel_stats.csv 10 > $O/kernel_stats.txt 2>&1; sed -n 1,20p $O/kernel_stats.txt | cut -c1-150
 rm -rf $O/pf $O/pw $O/pu $O/pk
 # bench.py reads the NEWEST profiles/rNN_*; put this run's files there (on the box) so that the line below quotes this commit
 cp $O/${TAG}_pmc_traffic.json $O/${TAG}_mfma_util.json $R/profiles/
