@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """LayerNorm backward as the training step calls it (bf16 dy, fp32 x / dx_add / dx, bf16 copy + column sums of dx), rows = 50 432,
 dim = 768: microseconds per launch and HBM rate over 16 B / element, rotating over buffer sets larger than the Infinity Cache.
-MV_LIB_PATH selects the library (tools/diag/ln_bwd_variants.sh)."""
+MV_LIB_PATH selects the library (a second build to compare against: see the LIBS mode of tools/ab_step.py)."""
 import os, sys, json
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "..", "myrtle-vision_amd"))
 import torch
