@@ -98,7 +98,7 @@ Quant = Optional[Callable[[str, torch.Tensor], torch.Tensor]]
 
 def vit_forward(params: Dict[str, torch.Tensor], img: torch.Tensor, cfg: ViTConfig,
                 quant: Quant = None, taps: Optional[dict] = None, quant_outputs: bool = False,
-                probs_site: bool = False) -> torch.Tensor:
+                probs_site: bool = False, linear_fn=None) -> torch.Tensor:
     """``ViT.forward`` (``vit.py:267-320``) for the classification and segmentation
     decoders.  ``quant(site, tensor)`` is the fake-quant hook (identity when None);
     sites follow ``ModelQuantizer._prepare_qat_fp16_32/_tf32``
@@ -111,7 +111,8 @@ def vit_forward(params: Dict[str, torch.Tensor], img: torch.Tensor, cfg: ViTConf
     ("ff:<name>": cls_token_cat, pos_embedding_cat, pos_embedding_add, res_add).
     ``taps`` (optional dict) receives intermediate activations.  ``probs_site`` adds one site the reference does not
     have, "attn:probs" on the softmax output: the rounding-error budget of the bf16 kernels (tests/test_error_budget.py)
-    needs it, no fixture uses it.
+    needs it, no fixture uses it.  ``linear_fn(name, x, weight, bias)`` (optional) replaces the arithmetic of every nn.Linear
+    product -- emulation studies of GEMM number formats (tests/test_error_budget.py); no fixture uses it.
     """
     q = quant if quant is not None else (lambda site, t: t)
     qo = q if quant_outputs else (lambda site, t: t)
@@ -120,6 +121,8 @@ def vit_forward(params: Dict[str, torch.Tensor], img: torch.Tensor, cfg: ViTConf
     b, _, h, w = img.shape
 
     def linear(name, x):
+        if linear_fn is not None:
+            return linear_fn(name, x, P[f"{name}.weight"], P[f"{name}.bias"])
         y = F.linear(q(f"act:{name}", x), q(f"w:{name}", P[f"{name}.weight"]), P[f"{name}.bias"])
         return qo(f"out:{name}", y)
 

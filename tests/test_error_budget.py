@@ -73,6 +73,64 @@ def budget(name, n_images):
     return rows
 
 
+# ---------------------------------------------------------------------------------------------------------------------------
+# Study for a faster tolerance-meeting mode (DESIGN section 8, 00 iii): bf16x3 computes a b = a0 b0 + a0 b1 + a1 b0 as three bf16
+# products.  The two correction products are 2^-8 of the result, so they need only ~8 bits of relative accuracy themselves -- would
+# FP8 operands (e4m3, the format of gfx950's double-rate matrix path) do?  Emulated here on the oracle's nn.Linear products:
+#     y = a0 b0  (bf16 pieces, exact products, fp32 sums)  +  Q(a0) Q(b1)  +  Q(a1) Q(b0),     Q = e4m3 with one power-of-two scale
+# per operand ROW (token / output feature; the hardware's block scales are finer: 32 elements).  Attention, LayerNorm, GELU and the
+# residual stream stay fp32, as in precision="bf16x3".
+# ---------------------------------------------------------------------------------------------------------------------------
+def _pieces(t):
+    p0 = t.to(torch.bfloat16).float()
+    return p0, (t - p0).to(torch.bfloat16).float()
+
+
+def _e4m3_rows(t):
+    """Round to e4m3 (3 significand bits, finite max 448) after scaling every row by a power of two so that its largest magnitude
+    lands in [128, 256); returns the dequantised values."""
+    amax = t.abs().amax(dim=-1, keepdim=True).clamp_min(1e-30)
+    scale = torch.exp2(7.0 - torch.floor(torch.log2(amax)))
+    return (t * scale).to(torch.float8_e4m3fn).float() / scale
+
+
+def _linear_x3(correction):
+    def fn(name, x, w, bias):
+        a0, a1 = _pieces(x)
+        b0, b1 = _pieces(w)
+        if correction == "bf16":
+            y = a0 @ b0.t() + a0 @ b1.t() + a1 @ b0.t()
+        else:
+            y = a0 @ b0.t() + _e4m3_rows(a0) @ _e4m3_rows(b1).t() + _e4m3_rows(a1) @ _e4m3_rows(b0).t()
+        return y + bias
+    return fn
+
+
+def fp8_correction_study(name, n_images):
+    arrays, meta = load_golden(name)
+    cfg = ViTConfig(patch_size=16, **meta["kwargs"])
+    params = det_state_dict(cfg.param_shapes())
+    img = det_images(name, meta["batch"], cfg.image_size)[:n_images]
+    want = arrays["logits"][:n_images]
+    scale = np.abs(want).max()
+    rows = {}
+    with torch.no_grad():
+        for label, corr in [("bf16x3 (three bf16 products)", "bf16"), ("bf16 main product + two e4m3 correction products", "e4m3")]:
+            lg = vit_forward(params, img, cfg, linear_fn=_linear_x3(corr)).numpy()
+            rows[label] = (float(np.abs(lg - want).max() / scale), bool((lg.argmax(1) == want.argmax(1)).all()))
+    return rows
+
+
+def test_fp8_correction_products_would_stay_inside_the_tolerance():
+    """ViT-Tiny, 8 images (forward): the emulated scheme's logits stay inside north_star's 1e-3 with every arg-max equal, within 30x
+    of bf16x3 itself -- the feasibility bound quoted in DESIGN section 8 for a next round's kernel, not a claim about a shipped path."""
+    torch.set_num_threads(8)
+    rows = fp8_correction_study("tiny_cls_b64", 8)
+    x3, f8 = rows["bf16x3 (three bf16 products)"], rows["bf16 main product + two e4m3 correction products"]
+    assert x3[0] < 1e-4 and x3[1]
+    assert f8[0] < 1e-3 and f8[1]
+
+
 def test_budget_sources_add_up_in_quadrature():
     """ViT-Tiny, 8 images: the per-source errors are independent roundings, so the all-sources error is of the size of
     their root-sum-square (within 2x either way: max-norm statistics), bf16 as a whole lands in the envelope the GPU tests
@@ -96,3 +154,6 @@ if __name__ == "__main__":
     print(f"# rounding-error budget, {name}, {n} images: max |logit error| / max |reference logit| (CPU emulation on the oracle)")
     for k, v in budget(name, n).items():
         print(f"{v:.3e}  {k}")
+    print("# split-operand products with FP8 correction terms (emulated): logits error, every arg-max equal")
+    for k, (v, same) in fp8_correction_study(name, n).items():
+        print(f"{v:.3e}  {same}  {k}")
