@@ -121,6 +121,57 @@ def fp8_correction_study(name, n_images):
     return rows
 
 
+def _prod(a, b, correction):
+    """a [M, K] . b [N, K]^T with both operands split along K's rows: the bf16x3 pairings, corrections in bf16 or e4m3."""
+    a0, a1 = _pieces(a)
+    b0, b1 = _pieces(b)
+    if correction == "bf16":
+        return a0 @ b0.t() + a0 @ b1.t() + a1 @ b0.t()
+    return a0 @ b0.t() + _e4m3_rows(a0) @ _e4m3_rows(b1).t() + _e4m3_rows(a1) @ _e4m3_rows(b0).t()
+
+
+class _EmuLinear(torch.autograd.Function):
+    """nn.Linear whose three products (forward, dX = dY W, dW = dY^T X) all run the emulated scheme."""
+
+    @staticmethod
+    def forward(ctx, x, w, bias, correction):
+        ctx.save_for_backward(x, w)
+        ctx.correction = correction
+        return _prod(x.reshape(-1, x.shape[-1]), w, correction).view(*x.shape[:-1], w.shape[0]) + bias
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, w = ctx.saved_tensors
+        dy2, x2 = dy.reshape(-1, dy.shape[-1]), x.reshape(-1, x.shape[-1])
+        dx = _prod(dy2, w.t().contiguous(), ctx.correction).view_as(x)
+        dw = _prod(dy2.t().contiguous(), x2.t().contiguous(), ctx.correction)
+        return dx, dw, dy2.sum(0), None
+
+
+def fp8_correction_gradient_study(name, n_images):
+    """-> {scheme: (worst relative L2 error over the gradient tensors against exact fp32 autograd, name of that tensor)}."""
+    from oracle.detinit import det_labels
+    arrays, meta = load_golden(name)
+    cfg = ViTConfig(patch_size=16, **meta["kwargs"])
+    img = det_images(name, meta["batch"], cfg.image_size)[:n_images]
+    labels = det_labels(name, (meta["batch"],), cfg.num_classes)[:n_images]
+
+    def grads(linear_fn):
+        params = {k: v.clone().requires_grad_(True) for k, v in det_state_dict(cfg.param_shapes()).items()}
+        loss = torch.nn.functional.cross_entropy(vit_forward(params, img, cfg, linear_fn=linear_fn), labels)
+        loss.backward()
+        return {k: v.grad for k, v in params.items() if v.grad is not None}
+
+    exact = grads(None)
+    out = {}
+    for label, corr in [("bf16x3 (three bf16 products)", "bf16"), ("bf16 main product + two e4m3 correction products", "e4m3")]:
+        got = grads(lambda n, x, w, b, c=corr: _EmuLinear.apply(x, w, b, c))
+        errs = {k: float((got[k] - exact[k]).norm() / exact[k].norm().clamp_min(1e-30)) for k in exact if float(exact[k].norm()) > 0}
+        worst = max(errs, key=errs.get)
+        out[label] = (errs[worst], worst)
+    return out
+
+
 def test_fp8_correction_products_would_stay_inside_the_tolerance():
     """ViT-Tiny, 8 images (forward): the emulated scheme's logits stay inside north_star's 1e-3 with every arg-max equal, within 30x
     of bf16x3 itself -- the feasibility bound quoted in DESIGN section 8 for a next round's kernel, not a claim about a shipped path."""
@@ -129,6 +180,8 @@ def test_fp8_correction_products_would_stay_inside_the_tolerance():
     x3, f8 = rows["bf16x3 (three bf16 products)"], rows["bf16 main product + two e4m3 correction products"]
     assert x3[0] < 1e-4 and x3[1]
     assert f8[0] < 1e-3 and f8[1]
+    g = fp8_correction_gradient_study("tiny_cls_b64", 4)
+    assert g["bf16x3 (three bf16 products)"][0] < 1e-4 and g["bf16 main product + two e4m3 correction products"][0] < 1e-3
 
 
 def test_budget_sources_add_up_in_quadrature():
@@ -157,3 +210,6 @@ if __name__ == "__main__":
     print("# split-operand products with FP8 correction terms (emulated): logits error, every arg-max equal")
     for k, (v, same) in fp8_correction_study(name, n).items():
         print(f"{v:.3e}  {same}  {k}")
+    print("# the same schemes in all three products of every nn.Linear: worst relative L2 error of a gradient tensor vs exact autograd")
+    for k, (v, which) in fp8_correction_gradient_study(name, min(n, 8)).items():
+        print(f"{v:.3e}  ({which})  {k}")
