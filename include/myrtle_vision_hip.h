@@ -248,6 +248,15 @@ int mv_split2_bf16_ex(const float* x, long ldx, const float* h, long ldh, int op
  * (dx = dy W); either may be NULL.  nseg = 3 | 6; R and C even.  Replaces a transposed fp32 copy + two split passes per weight and
  * optimizer step. */
 int mv_weight_split(const float* w, void* fwd, void* dx, int R, int C, int nseg, mv_stream_t stream);
+/* Round 4, NOT yet used by the model (a measured building block for a faster tolerance-meeting mode,
+ * profiles/r04_fp8_correction_study.txt): the bf16x3 product a0 b0 + a0 b1 + a1 b0 of an nn.Linear (vit.py:48-51,86,98) with its two
+ * CORRECTION terms on e4m3 operands and the 8-bit matrix instruction.  mv_split_f8c writes an operand's rows of 4 * cols bytes
+ * [p0 as bf16 | 8-bit segment 1 | 8-bit segment 2] (role 0: Q(p0 2^e) | Q(p1 2^(e+8)); role 1: Q(p1 2^(e+8)) | Q(p0 2^e)); exp_hi = e:
+ * max |x| 2^e < 448.  mv_gemm_nt_f8c: C[M, N] = A0 B0^T + 2^scale_exp (segments 1 and 2 contracted), scale_exp = -(e_a + e_b + 8);
+ * K % 128 == 0; epilogues MV_EPI_NONE (fp32 / bf16 C) and MV_EPI_RESIDUAL (fp32 C). */
+int mv_split_f8c(const float* x, long ldx, void* out, long ldo_bytes, long rows, int cols, int role, int exp_hi, mv_stream_t stream);
+int mv_gemm_nt_f8c(const void* A, long lda_bytes, const void* B, long ldb_bytes, void* C, int ldc, int c_dtype, int M, int N, int K,
+                   int scale_exp, const float* bias, int epilogue, const void* aux, int ld_aux, mv_stream_t stream);
 int mv_gemm_tn_bf16_x3(const void* A3, const void* B3, float* C, int ldc, int M, int N, int rows, float* workspace,
                        size_t workspace_bytes, mv_stream_t stream);
 /* weight prep for the MFMA path: w fp32 [R, C] -> w_bf16 [R, ldw] and wt_bf16 [C, ldt] (transposed), pads zeroed;

@@ -1054,6 +1054,41 @@ __global__ __launch_bounds__(256) void split3_ex_kernel(const float* __restrict_
   if (partial) *reinterpret_cast<float4*>(partial + (long)blockIdx.y * (cols4 * 4) + c) = make_float4(cs[0], cs[1], cs[2], cs[3]);
 }
 
+// Operand rows for mv_gemm_nt_f8c (round 4; profiles/r04_fp8_correction_study.txt): x = p0 + p1 + ... with p0 = bf16(x), p1 = bf16(x - p0);
+// a row of 4 * cols bytes = [p0 as bf16 | segment 1 | segment 2] with the two 8-bit segments e4m3 (OCP, v_cvt_pk_fp8_f32) of
+//   role 0 (left operand):  Q(p0 * 2^e)       | Q(p1 * 2^(e + 8))          role 1 (right operand):  Q(p1 * 2^(e + 8)) | Q(p0 * 2^e)
+// so that segment s of one operand meets segment s of the other and both products carry 2^(e_a + e_b + 8).  e is the caller's: the
+// largest |x| times 2^e must stay below 448 (the low piece is at most 2^-9 of the high one: the same bound with 2^8 more).
+template <int ROLE>
+__global__ __launch_bounds__(256) void split_f8c_kernel(const float* __restrict__ x, long ldx, unsigned char* __restrict__ out,
+                                                        long ldo_bytes, long rows, int cols4, float s_hi, float s_lo) {
+  const long total = rows * cols4;
+  for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long)gridDim.x * 256) {
+    const long r = idx / cols4;
+    const int c = (int)(idx - r * cols4) * 4;
+    const float4 v = *reinterpret_cast<const float4*>(x + r * ldx + c);
+    const float in[4] = {v.x, v.y, v.z, v.w};
+    bf16x4 p0;
+    float hi[4], lo[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const bf16_t b = (bf16_t)in[e];
+      p0[e] = b;
+      hi[e] = (float)b * s_hi;
+      lo[e] = (float)(bf16_t)(in[e] - (float)b) * s_lo;
+    }
+    int qh = __builtin_amdgcn_cvt_pk_fp8_f32(hi[0], hi[1], 0, false);
+    qh = __builtin_amdgcn_cvt_pk_fp8_f32(hi[2], hi[3], qh, true);
+    int ql = __builtin_amdgcn_cvt_pk_fp8_f32(lo[0], lo[1], 0, false);
+    ql = __builtin_amdgcn_cvt_pk_fp8_f32(lo[2], lo[3], ql, true);
+    unsigned char* o = out + r * ldo_bytes;
+    const long cols = (long)cols4 * 4;
+    *reinterpret_cast<bf16x4*>(o + 2L * c) = p0;
+    *reinterpret_cast<int*>(o + 2 * cols + c) = ROLE == 0 ? qh : ql;
+    *reinterpret_cast<int*>(o + 3 * cols + c) = ROLE == 0 ? ql : qh;
+  }
+}
+
 inline int split3_parts(long rows) {
   long p = rows / 16;
   return (int)(p < 1 ? 1 : (p > 1024 ? 1024 : p));
@@ -1163,6 +1198,22 @@ extern "C" int mv_weight_split(const float* w, void* fwd, void* dx, int R, int C
     weight_split_kernel<3><<<grid, 256, 0, S_>>>(w, (bf16_t*)fwd, (bf16_t*)dx, R, C);
   else
     weight_split_kernel<6><<<grid, 256, 0, S_>>>(w, (bf16_t*)fwd, (bf16_t*)dx, R, C);
+  MV_CHECK_LAUNCH();
+  return MV_OK;
+}
+
+extern "C" int mv_split_f8c(const float* x, long ldx, void* out, long ldo_bytes, long rows, int cols, int role, int exp_hi,
+                            mv_stream_t stream) {
+  MV_REQUIRE(rows >= 0 && cols >= 0 && (role == 0 || role == 1) && exp_hi > -100 && exp_hi < 100, MV_ERR_SHAPE);
+  if (rows == 0 || cols == 0) return MV_OK;
+  MV_REQUIRE(cols % 4 == 0 && ldx % 4 == 0 && ldx >= cols && ldo_bytes >= 4L * cols && ldo_bytes % 16 == 0, MV_ERR_ALIGN);
+  MV_REQUIRE(mv_aligned16(x) && mv_aligned16(out), MV_ERR_ALIGN);
+  const int grid = ew_grid(rows * (cols / 4));
+  const float s_hi = ldexpf(1.0f, exp_hi), s_lo = ldexpf(1.0f, exp_hi + 8);
+  if (role == 0)
+    split_f8c_kernel<0><<<grid, 256, 0, S_>>>(x, ldx, (unsigned char*)out, ldo_bytes, rows, cols / 4, s_hi, s_lo);
+  else
+    split_f8c_kernel<1><<<grid, 256, 0, S_>>>(x, ldx, (unsigned char*)out, ldo_bytes, rows, cols / 4, s_hi, s_lo);
   MV_CHECK_LAUNCH();
   return MV_OK;
 }

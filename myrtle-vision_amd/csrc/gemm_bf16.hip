@@ -65,6 +65,8 @@ struct EpiArgs {
   int ks_tiles, ks_len;
   long ks_slab;
   int band;             // 8-phase kernel: > 0 = an XCD walks column BANDS of this many tile columns (its B slice stays in its L2)
+  // OPK = NT_F8C (mv_gemm_nt_f8c): the first f8_tiles16 K-tiles of a row are bf16, the rest e4m3 whose products carry 2^(f8_scale - 127)
+  int f8_tiles16, f8_scale;
 };
 
 // 16-byte output store of the NT epilogues
@@ -923,7 +925,13 @@ typedef __attribute__((ext_vector_type(4))) int i32x4;
 // epilogues, after the zero-point correction icorr[n] has been added in integer arithmetic.
 // OPK = NT_F16: the operands are IEEE half (v_mfma_f32_16x16x32_f16): same 2-byte geometry as bf16, only the MFMA differs.
 // Used for the forward products of the fake-quantised FP16 formats, whose operands are exactly representable in fp16.
-constexpr int NT_BF16 = 0, NT_I8 = 1, NT_F16 = 2;
+// OPK = NT_F8C (round 4, not yet used by the model: profiles/r04_fp8_correction_study.txt): a split-operand product with its two
+// CORRECTION segments on the 8-bit matrix path.  A row is [p0 as bf16 (K x 2 bytes) | Q(.) (K bytes) | Q(.) (K bytes)]: K / 64 bf16
+// K-tiles, then K / 64 e4m3 K-tiles of 128 elements -- every tile the same 128-byte rows, LDS image and fragment reads; an 8-bit
+// tile issues ONE v_mfma_f32_16x16x128_f8f6f4 on the two 16-byte chunks a bf16 tile gives to two 16x16x32 instructions (any k
+// order serves: both operands use the same one), with the segments' common power of two in the instruction's e8m0 scale operand.
+constexpr int NT_BF16 = 0, NT_I8 = 1, NT_F16 = 2, NT_F8C = 3;
+typedef __attribute__((ext_vector_type(8))) int i32x8;
 typedef __attribute__((ext_vector_type(8))) _Float16 f16x8;
 
 template <int EPI, typename CT, int OPK = NT_BF16, bool KSPLIT = false>
@@ -1030,25 +1038,53 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_8phase_kernel(const bf16_t* __
   const char* const a_rd = smem + 64 * wm * 128;
   const char* const b_rd = smem + 32 * wn * 128;
   bf16x8 af[4][2], bf0[2][2], bf1[2][2];
+  // NT_F8C keeps each fragment PAIR as one 8-dword value (the 8-bit instruction's operand: eight consecutive registers); its bf16
+  // tiles take the halves as sub-registers.  (Built at the MFMA from two 4-dword values instead, the pairs cost 50-100 spilled dwords.)
+  [[maybe_unused]] i32x8 af_8[4], bf0_8[2], bf1_8[2];
+#define P8_PAIR(p0_, p1_)                                                                                    \
+  __builtin_shufflevector(*reinterpret_cast<const i32x4*>(p0_), *reinterpret_cast<const i32x4*>(p1_), 0, 1, 2, 3, 4, 5, 6, 7)
 #define P8_READ_A(buf_, slot_)                                                                               \
   {                                                                                                          \
     const char* s_ = a_rd + ((buf_) * 4 + (slot_)) * P8_SLOT;                                                \
     _Pragma("unroll") for (int i = 0; i < 4; ++i) {                                                          \
-      af[i][0] = *reinterpret_cast<const bf16x8*>(s_ + i * 2048 + rf0);                                      \
-      af[i][1] = *reinterpret_cast<const bf16x8*>(s_ + i * 2048 + rf1);                                      \
+      if constexpr (OPK == NT_F8C) {                                                                         \
+        af_8[i] = P8_PAIR(s_ + i * 2048 + rf0, s_ + i * 2048 + rf1);                                         \
+      } else {                                                                                               \
+        af[i][0] = *reinterpret_cast<const bf16x8*>(s_ + i * 2048 + rf0);                                    \
+        af[i][1] = *reinterpret_cast<const bf16x8*>(s_ + i * 2048 + rf1);                                    \
+      }                                                                                                      \
     }                                                                                                        \
   }
 #define P8_READ_B(dst_, buf_, slot_)                                                                         \
   {                                                                                                          \
     const char* s_ = b_rd + ((buf_) * 4 + (slot_)) * P8_SLOT;                                                \
     _Pragma("unroll") for (int j = 0; j < 2; ++j) {                                                          \
-      dst_[j][0] = *reinterpret_cast<const bf16x8*>(s_ + j * 2048 + rf0);                                    \
-      dst_[j][1] = *reinterpret_cast<const bf16x8*>(s_ + j * 2048 + rf1);                                    \
+      if constexpr (OPK == NT_F8C) {                                                                         \
+        dst_##_8[j] = P8_PAIR(s_ + j * 2048 + rf0, s_ + j * 2048 + rf1);                                     \
+      } else {                                                                                               \
+        dst_[j][0] = *reinterpret_cast<const bf16x8*>(s_ + j * 2048 + rf0);                                  \
+        dst_[j][1] = *reinterpret_cast<const bf16x8*>(s_ + j * 2048 + rf1);                                  \
+      }                                                                                                      \
     }                                                                                                        \
   }
-#define P8_MFMA(mb_, nb_, bfx_)                                                                              \
+#define P8_MFMA(mb_, nb_, bfx_, M8_)                                                                         \
   {                                                                                                          \
     __builtin_amdgcn_s_setprio(1);                                                                           \
+    if constexpr (OPK == NT_F8C && (M8_)) {                                                                  \
+      _Pragma("unroll") for (int i = 0; i < 4; ++i)                                                          \
+        _Pragma("unroll") for (int j = 0; j < 2; ++j)                                                        \
+          acc[(mb_) + i][(nb_) + j] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(                      \
+              bfx_##_8[j], af_8[i], acc[(mb_) + i][(nb_) + j], 0, 0, 0, 0x7F7F7F7F, 0, f8_sc);               \
+    } else if constexpr (OPK == NT_F8C) {                                                                    \
+      _Pragma("unroll") for (int ks = 0; ks < 2; ++ks)                                                       \
+        _Pragma("unroll") for (int i = 0; i < 4; ++i)                                                        \
+          _Pragma("unroll") for (int j = 0; j < 2; ++j) {                                                    \
+            const i32x4 a4 = ks ? __builtin_shufflevector(af_8[i], af_8[i], 4, 5, 6, 7) : __builtin_shufflevector(af_8[i], af_8[i], 0, 1, 2, 3);                 \
+            const i32x4 b4 = ks ? __builtin_shufflevector(bfx_##_8[j], bfx_##_8[j], 4, 5, 6, 7) : __builtin_shufflevector(bfx_##_8[j], bfx_##_8[j], 0, 1, 2, 3); \
+            acc[(mb_) + i][(nb_) + j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(                             \
+                __builtin_bit_cast(bf16x8, b4), __builtin_bit_cast(bf16x8, a4), acc[(mb_) + i][(nb_) + j], 0, 0, 0);   \
+          }                                                                                                  \
+    } else                                                                                                   \
     _Pragma("unroll") for (int ks = 0; ks < 2; ++ks)                                                         \
       _Pragma("unroll") for (int i = 0; i < 4; ++i)                                                          \
         _Pragma("unroll") for (int j = 0; j < 2; ++j) {                                                      \
@@ -1094,7 +1130,7 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_8phase_kernel(const bf16_t* __
 // (no A_q1 slot, three slots per K-tile) keep the round-1 waits (H4_).  (Measured against the round-1 placement with a run-time
 // switch, since removed: +0...3.8 % per shape, 37.16 vs 37.27 ms in the step.)
 #define P8_WAIT(N_) asm volatile("s_waitcnt vmcnt(" #N_ ")" ::: "memory");
-#define P8_KTILE(d_, ST_, first_slot_buf_, first_slot_kt_, next_buf_, next_kt_, W1_, W2_, W4_, H4_, STAGE_FIRST_)        \
+#define P8_KTILE(d_, ST_, first_slot_buf_, first_slot_kt_, next_buf_, next_kt_, W1_, W2_, W4_, H4_, STAGE_FIRST_, M8_)   \
   {                                                                                                          \
     /* phase 1/5 */                                                                                          \
     P8_READ_B(bf0, d_, P8_BQ0)                                                                               \
@@ -1106,7 +1142,7 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_8phase_kernel(const bf16_t* __
     if (lazy) { W1_ }                                                                                        \
     P8_BAR()                                                                                                 \
     P8_LGKM0()                                                                                               \
-    P8_MFMA(0, 0, bf0)                                                                                       \
+    P8_MFMA(0, 0, bf0, M8_)                                                                                       \
     P8_BAR()                                                                                                 \
     /* phase 2/6 */                                                                                          \
     P8_READ_B(bf1, d_, P8_BQ1)                                                                               \
@@ -1115,7 +1151,7 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_8phase_kernel(const bf16_t* __
     if (lazy) { W2_ }                                                                                        \
     P8_BAR()                                                                                                 \
     P8_LGKM0()                                                                                               \
-    P8_MFMA(0, 2, bf1)                                                                                       \
+    P8_MFMA(0, 2, bf1, M8_)                                                                                       \
     P8_BAR()                                                                                                 \
     /* phase 3/7 */                                                                                          \
     if (!is_half) P8_READ_A(d_, P8_AQ1)                                                                      \
@@ -1123,13 +1159,13 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_8phase_kernel(const bf16_t* __
     if (ST_) P8_STAGE(next_buf_, P8_AQ0, next_kt_)                                                           \
     P8_BAR()                                                                                                 \
     P8_LGKM0()                                                                                               \
-    if (!is_half) P8_MFMA(4, 2, bf1)                                                                         \
+    if (!is_half) P8_MFMA(4, 2, bf1, M8_)                                                                         \
     P8_BAR()                                                                                                 \
     /* phase 4/8 */                                                                                          \
     if (ST_) P8_STAGE(next_buf_, P8_BQ1, next_kt_)                                                           \
     if (lazy) { W4_ } else { H4_ }                                                                           \
     P8_BAR()                                                                                                 \
-    if (!is_half) P8_MFMA(4, 0, bf0)                                                                         \
+    if (!is_half) P8_MFMA(4, 0, bf0, M8_)                                                                         \
     P8_BAR()                                                                                                 \
   }
 
@@ -1140,15 +1176,31 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_8phase_kernel(const bf16_t* __
   P8_BAR()
   if (__builtin_amdgcn_readfirstlane(wave) >= 4) P8_BAR()      // waves 4-7 run one barrier behind
   int kt = 0;
+  [[maybe_unused]] const int f8_sc = (ep.f8_scale & 255) * 0x01010101;          // NT_F8C: the e8m0 scale byte, in every position
+  if constexpr (OPK == NT_F8C) {
+    // the same loop twice, once per MFMA type (compile-time, no branch inside): the bf16 tiles [0, f8_tiles16), then the 8-bit tiles;
+    // staging is type-blind (whole 128-byte rows), so the pipeline runs across the boundary.  f8_tiles16 even, 2 <= f8_tiles16 <= nk - 2.
+    for (; kt < ep.f8_tiles16; kt += 2) {
+      P8_KTILE(0, 1, 1, kt + 1, 0, kt + 2, P8_WAIT(10), P8_WAIT(10), P8_WAIT(10), P8_WAIT(6), 1, 0)
+      P8_KTILE(1, 1, 0, kt + 2, 1, kt + 3, P8_WAIT(10), P8_WAIT(10), P8_WAIT(10), P8_WAIT(6), 1, 0)
+    }
+    for (; kt < nk - 2; kt += 2) {
+      P8_KTILE(0, 1, 1, kt + 1, 0, kt + 2, P8_WAIT(10), P8_WAIT(10), P8_WAIT(10), P8_WAIT(6), 1, 1)
+      P8_KTILE(1, 1, 0, kt + 2, 1, kt + 3, P8_WAIT(10), P8_WAIT(10), P8_WAIT(10), P8_WAIT(6), 1, 1)
+    }
+    P8_KTILE(0, 0, 1, kt + 1, 0, 0, P8_WAIT(10), P8_WAIT(8), P8_WAIT(4), P8_WAIT(0), 1, 1)
+    P8_KTILE(1, 0, 0, 0, 0, 0, P8_WAIT(2), P8_WAIT(0), , , 0, 1)
+  } else {
   for (; kt < nk - 2; kt += 2) {
     // phases 1-4: compute buffer 0 (K-tile kt); stage A_q1[kt+1] -> buffer 1, then B_q0/A_q0/B_q1[kt+2] -> buffer 0
-    P8_KTILE(0, 1, 1, kt + 1, 0, kt + 2, P8_WAIT(10), P8_WAIT(10), P8_WAIT(10), P8_WAIT(6), 1)
+    P8_KTILE(0, 1, 1, kt + 1, 0, kt + 2, P8_WAIT(10), P8_WAIT(10), P8_WAIT(10), P8_WAIT(6), 1, 0)
     // phases 5-8: compute buffer 1 (K-tile kt+1); stage A_q1[kt+2] -> buffer 0, then B_q0/A_q0/B_q1[kt+3] -> buffer 1
-    P8_KTILE(1, 1, 0, kt + 2, 1, kt + 3, P8_WAIT(10), P8_WAIT(10), P8_WAIT(10), P8_WAIT(6), 1)
+    P8_KTILE(1, 1, 0, kt + 2, 1, kt + 3, P8_WAIT(10), P8_WAIT(10), P8_WAIT(10), P8_WAIT(6), 1, 0)
   }
   // peeled last iteration: only K-tile nk-1's A_q1 is still to be staged; the queue drains 10 -> 8 -> 4 -> 2 -> 0
-  P8_KTILE(0, 0, 1, kt + 1, 0, 0, P8_WAIT(10), P8_WAIT(8), P8_WAIT(4), P8_WAIT(0), 1)
-  P8_KTILE(1, 0, 0, 0, 0, 0, P8_WAIT(2), P8_WAIT(0), , , 0)
+  P8_KTILE(0, 0, 1, kt + 1, 0, 0, P8_WAIT(10), P8_WAIT(8), P8_WAIT(4), P8_WAIT(0), 1, 0)
+  P8_KTILE(1, 0, 0, 0, 0, 0, P8_WAIT(2), P8_WAIT(0), , , 0, 0)
+  }
   if (__builtin_amdgcn_readfirstlane(wave) < 4) P8_BAR()
 #undef P8_WAIT
 #undef P8_KTILE
@@ -1156,6 +1208,7 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_8phase_kernel(const bf16_t* __
 #undef P8_BAR
 #undef P8_MFMA
 #undef P8_READ_A
+#undef P8_PAIR
 #undef P8_READ_B
 #undef P8_STAGE
   // full tile: wave (wm, wn) finishes rows 128 wm + 64 h (h = 0, 1); half item: its only quadrant-row, rows 64 wm.
@@ -2035,6 +2088,47 @@ extern "C" int mv_gemm_nt_f16(const void* A, int lda, const void* B, int ldb, vo
       MV_REQUIRE(aux, MV_ERR_UNSUPPORTED);
       return launch_nt_f16<MV_EPI_RESIDUAL, float>(A, lda, B, ldb, C, ldc, M, N, K, ep, s);
     default: return MV_ERR_UNSUPPORTED;
+  }
+}
+
+namespace {
+template <int EPI, typename CT>
+int launch_nt_f8c(const void* A, int lda, const void* B, int ldb, void* C, int ldc, int M, int N, int K, EpiArgs ep, hipStream_t s) {
+  const int a8 = MV_ONCE_PER_DEVICE(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_nt_8phase_kernel<EPI, CT, NT_F8C>),
+                                            hipFuncAttributeMaxDynamicSharedMemorySize, P8_SMEM) == hipSuccess ? 0 : -1);
+  if (a8) return MV_ERR_LAUNCH;
+  const int t2m = mv_cdiv(M, BM2), t2n = mv_cdiv(N, BN2);
+  const int tiles = t2m * t2n, full = nt_full_tiles(tiles);
+  ep.f8_tiles16 = K / 64;
+  // a row of 4 K bytes in the 2-byte geometry the kernel is written in: 2 K "elements", K / 32 K-tiles
+  gemm_nt_8phase_kernel<EPI, CT, NT_F8C><<<full + 2 * (tiles - full), 512, P8_SMEM, s>>>(
+      (const bf16_t*)A, lda / 2, (const bf16_t*)B, ldb / 2, (CT*)C, ldc, M, N, 2 * K, t2n, ep, full, 0);
+  MV_CHECK_LAUNCH();
+  return MV_OK;
+}
+}  // namespace
+
+extern "C" int mv_gemm_nt_f8c(const void* A, long lda_bytes, const void* B, long ldb_bytes, void* C, int ldc, int c_dtype, int M, int N,
+                              int K, int scale_exp, const float* bias, int epilogue, const void* aux, int ld_aux, mv_stream_t stream) {
+  MV_REQUIRE(M >= 0 && N >= 0 && K > 0, MV_ERR_SHAPE);
+  if (M == 0 || N == 0) return MV_OK;
+  MV_REQUIRE(K % 128 == 0 && scale_exp > -127 && scale_exp <= 127, MV_ERR_UNSUPPORTED);        // whole K-tile pairs per segment
+  MV_REQUIRE(lda_bytes % 16 == 0 && ldb_bytes % 16 == 0 && lda_bytes >= 4L * K && ldb_bytes >= 4L * K, MV_ERR_ALIGN);
+  MV_REQUIRE(mv_aligned16(A) && mv_aligned16(B) && mv_aligned16(C), MV_ERR_ALIGN);
+  MV_REQUIRE((long)M * lda_bytes < (1L << 32) && (long)N * ldb_bytes < (1L << 32), MV_ERR_SHAPE);  // 32-bit byte offsets of the DMA
+  hipStream_t s = (hipStream_t)stream;
+  EpiArgs ep{1.0f, bias, aux, ld_aux, 0, nullptr, 0, nullptr, 0.f, 0.f};
+  ep.f8_scale = scale_exp + 127;
+  switch (epilogue) {
+    case MV_EPI_NONE:
+      MV_REQUIRE(c_dtype == MV_F32 || c_dtype == MV_BF16, MV_ERR_UNSUPPORTED);
+      return c_dtype == MV_F32 ? launch_nt_f8c<MV_EPI_NONE, float>(A, (int)lda_bytes, B, (int)ldb_bytes, C, ldc, M, N, K, ep, s)
+                               : launch_nt_f8c<MV_EPI_NONE, bf16_t>(A, (int)lda_bytes, B, (int)ldb_bytes, C, ldc, M, N, K, ep, s);
+    case MV_EPI_RESIDUAL:
+      MV_REQUIRE(c_dtype == MV_F32 && aux, MV_ERR_UNSUPPORTED);
+      return launch_nt_f8c<MV_EPI_RESIDUAL, float>(A, (int)lda_bytes, B, (int)ldb_bytes, C, ldc, M, N, K, ep, s);
+    default:
+      return MV_ERR_UNSUPPORTED;
   }
 }
 

@@ -68,6 +68,8 @@ SIGNATURES = {
     "mv_gemm_tn_bf16_x6": ("ppp" "iiii" "pz" "p", _I),
     "mv_split2_bf16": ("plpll" "lii" "p", _I),
     "mv_weight_split": ("ppp" "iii" "p", _I),
+    "mv_split_f8c": ("plpl" "liii" "p", _I),
+    "mv_gemm_nt_f8c": ("plplpi" "iiiii" "pipi" "p", _I),
     "mv_split2_bf16_ex": ("plpl" "ip" "li" "ppz" "p", _I),
     "mv_gemm_tn_bf16_x3": ("ppp" "iiii" "pz" "p", _I),
     "mv_weight_prep": ("ppipi" "ii" "p", _I),

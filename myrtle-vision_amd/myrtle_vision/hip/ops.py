@@ -544,6 +544,34 @@ def split_weight(weight: torch.Tensor, which: str) -> torch.Tensor:
     return have[nseg]
 
 
+# ------------------------------------------------------------------------------------------------------------
+# Building block of a faster tolerance-meeting mode (round 4; NOT used by the model yet, profiles/r04_fp8_correction_study.txt):
+# the bf16x3 product with its two correction terms on e4m3 operands and the 8-bit matrix instruction.
+# ------------------------------------------------------------------------------------------------------------
+def f8c_exponent(t: torch.Tensor) -> int:
+    """The power of two that puts max |t| into [128, 256) (e4m3's largest finite value is 448).  Synchronises: tests / tools."""
+    import math
+    amax = float(t.detach().abs().max())
+    return 7 - math.floor(math.log2(amax)) if amax > 0 else 0
+
+
+def split_f8c(x, rows, cols, role, exp_hi, ldx=None):
+    """fp32 [rows, cols] -> uint8 [rows, 4 * cols]: bf16 p0 | e4m3 segment 1 | e4m3 segment 2 (include/myrtle_vision_hip.h)."""
+    require_cuda(x)
+    out = torch.empty(rows, 4 * cols, dtype=torch.uint8, device=x.device)
+    check(lib().mv_split_f8c(_p(x), cols if ldx is None else ldx, _p(out), 4 * cols, rows, cols, role, int(exp_hi), _s()),
+          "split_f8c", rows=rows, cols=cols)
+    return out
+
+
+def gemm_nt_f8c(a8, b8, M, N, K, exp_a, exp_b, out, ldc, bias=None, epi=0, aux=None, ld_aux=0):
+    """out[M, N] = A B^T from two ``split_f8c`` operands (roles 0 and 1, exponents exp_a / exp_b) (+ bias, + aux for EPI_RESIDUAL)."""
+    require_cuda(a8, b8, out)
+    check(lib().mv_gemm_nt_f8c(_p(a8), 4 * K, _p(b8), 4 * K, _p(out), ldc, _DT[out.dtype], M, N, K, -(int(exp_a) + int(exp_b) + 8),
+                               _p(bias), epi, _p(aux), ld_aux, _s()), "gemm_nt_f8c", M=M, N=N, K=K)
+    return out
+
+
 def _x6_nt_ok(M, N, Kc):
     """[M, N] = A[M, Kc] B[N, Kc]^T through the 8-phase kernel with a 6 * Kc contraction."""
     return _f32_gemm_mode == "bf16x6" and M >= 128 and N % 16 == 0 and N >= 64 and Kc % 64 == 0

@@ -717,6 +717,51 @@ def test_attention_fused_fp32_forward(ops, B, N, H):
     assert relerr(out2, want2) < 5e-5 and torch.equal(out2, ops.attention_fwd_f32(qkv2.cuda(), B, N, H, scale))
 
 
+@pytest.mark.parametrize("M,N,K", [(512, 768, 768), (1000, 520, 256), (4096, 2304, 768), (2048, 768, 3072)])
+def test_gemm_nt_f8c_matches_the_emulation_of_its_roundings(ops, M, N, K):
+    """mv_split_f8c + mv_gemm_nt_f8c (a0 b0 on the bf16 matrix instruction, Q(a0) Q(b1) + Q(a1) Q(b0) on the e4m3 one, one
+    power-of-two scale per operand tensor): (i) the producer's bytes ARE bf16 / torch.float8_e4m3fn of the scaled pieces; (ii) the
+    product equals the fp64 sum of exactly those rounded operands to fp32-summation accuracy; (iii) against the exact fp64 product
+    it is a ~2^-12 arithmetic (bf16x3: 2^-16, bf16: 2^-8).  Ragged M / N, all K-tile counts of the ViT-B products."""
+    a = torch.randn(M, K, generator=g(1)) * 2.0
+    w = torch.randn(N, K, generator=g(2)) * K ** -0.5
+    bias = torch.randn(N, generator=g(3)) * 0.1
+    ea, eb = ops.f8c_exponent(a), ops.f8c_exponent(w)
+    a8, w8 = ops.split_f8c(a.cuda(), M, K, 0, ea), ops.split_f8c(w.cuda(), N, K, 1, eb)
+
+    def pieces(x, e):
+        p0 = x.to(torch.bfloat16)
+        p1 = (x - p0.float()).to(torch.bfloat16)
+        return p0, (p0.float() * 2.0 ** e).to(torch.float8_e4m3fn), (p1.float() * 2.0 ** (e + 8)).to(torch.float8_e4m3fn)
+
+    for got, x, e, role in [(a8.cpu(), a, ea, 0), (w8.cpu(), w, eb, 1)]:
+        p0, qh, ql = pieces(x, e)
+        R, C = x.shape
+        assert torch.equal(got[:, :2 * C].contiguous().view(torch.bfloat16), p0)
+        s1, s2 = (qh, ql) if role == 0 else (ql, qh)
+        assert torch.equal(got[:, 2 * C:3 * C], s1.view(torch.uint8)) and torch.equal(got[:, 3 * C:], s2.view(torch.uint8))
+    out = torch.full((M, N), float("nan"), device="cuda")
+    ops.gemm_nt_f8c(a8, w8, M, N, K, ea, eb, out, N, bias=bias.cuda())
+    a0, qa0, qa1 = pieces(a, ea)
+    b0, qb0, qb1 = pieces(w, eb)
+    emu = a0.double() @ b0.double().t() + (qa0.double() @ qb1.double().t() + qa1.double() @ qb0.double().t()) * 2.0 ** -(ea + eb + 8) \
+        + bias.double()
+    exact = a.double() @ w.double().t() + bias.double()
+    scale = float(exact.abs().max())
+    assert float((out.double().cpu() - emu).abs().max()) / scale < (2e-6 if K <= 1024 else 6e-6)       # fp32 summation order only
+    err = float((out.double().cpu() - exact).abs().max()) / scale
+    assert 6e-6 < err < 4e-4, err
+    # residual epilogue and bf16 output
+    res = torch.randn(M, N, generator=g(4)).cuda()
+    out2 = torch.full((M, N), float("nan"), device="cuda")
+    ops.gemm_nt_f8c(a8, w8, M, N, K, ea, eb, out2, N, bias=bias.cuda(), epi=ops.EPI_RESIDUAL, aux=res, ld_aux=N)
+    assert float((out2 - (out + res)).abs().max()) < 1e-5 * scale
+    ldn = (N + 15) & ~15
+    out16 = torch.full((M, ldn), float("nan"), device="cuda", dtype=torch.bfloat16)
+    ops.gemm_nt_f8c(a8, w8, M, N, K, ea, eb, out16, ldn, bias=bias.cuda())
+    assert float((out16[:, :N].float() - out).abs().max()) < 2.0 ** -8 * scale
+
+
 @pytest.mark.parametrize("R,C", [(768, 3072), (1000, 768), (8, 12), (2304, 768)])
 @pytest.mark.parametrize("nseg", [3, 6])
 def test_weight_split_equals_the_two_split_passes(ops, R, C, nseg):
