@@ -35,7 +35,9 @@ if LIB_AB:
     for path in os.environ["LIBS"].split(","):
         h = ctypes.CDLL(os.path.abspath(path))
         for name, (kinds, ret) in _L.SIGNATURES.items():
-            fn = getattr(h, name)
+            fn = getattr(h, name, None)
+            if fn is None:                          # an older build without a newer entry point: fine as long as the step does not call it
+                continue
             fn.argtypes = [_L._KIND[k] for k in kinds]
             fn.restype = ret
         HANDLES.append(h)
