@@ -507,7 +507,10 @@ def main():
             except Exception as e:                               # a secondary figure must never cost the headline line
                 out["within_tolerance"] = {"error": f"{type(e).__name__}: {e}"[:300]}
         if world == 1 and not args.no_cpu_baseline and args.workload == "cls":
-            out["cpu_baseline"] = cpu_baseline()
+            try:
+                out["cpu_baseline"] = cpu_baseline()
+            except Exception as e:                               # likewise: report the failure, keep the line
+                out["cpu_baseline"] = {"value": None, "error": f"{type(e).__name__}: {e}"[:300]}
         print(json.dumps(out))
     if world > 1 or force_dist:
         dist.destroy_process_group()
