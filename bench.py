@@ -269,7 +269,7 @@ def main():
     ap.add_argument("--no-kernel-timer", action="store_true")
     ap.add_argument("--timer-every", type=int, default=0,
                     help="bracket the GEMM launches with events on every k-th timed step only; 0 (default) = on the first and the "
-                         "middle step of the timed region (the first only below 8 steps): a step whose ~150 GEMM launches are "
+                         "middle step of the timed region (the first only below 16 steps): a step whose ~150 GEMM launches are "
                          "bracketed runs 1.4 ms (4 %%) longer, idle time around ~300 event packets (rocprofv3 trace, round 4)")
     ap.add_argument("--graph", action="store_true",
                     help="capture the training step in ONE HIP graph and replay it (utils/graph.py): single GPU, static shapes; "
@@ -388,7 +388,7 @@ def main():
     for _ in range(args.warmup):
         loss = step()
     reducer.exposed_ms(reset=True)                            # drop the warm-up steps' spans (lazy RCCL / communicator setup)
-    timed_steps = (sorted({0, args.steps // 2}) if args.steps >= 8 else [0]) if args.timer_every <= 0 else \
+    timed_steps = (sorted({0, args.steps // 2}) if args.steps >= 16 else [0]) if args.timer_every <= 0 else \
         list(range(0, args.steps, args.timer_every))
     timer = None if args.no_kernel_timer else ops.KernelTimer(sample_steps=timed_steps)
     if world > 1 or force_dist:

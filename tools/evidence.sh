@@ -41,8 +41,8 @@ rm -rf $O/pf $O/pw $O/pu $O/pk
 cp $O/${TAG}_pmc_traffic.json $O/${TAG}_mfma_util.json $R/profiles/
 python3 bench.py --steps 20 --warmup 5 2> $O/bench.err | tail -1 > $O/${TAG}_bench.json; cut -c1-300 $O/${TAG}_bench.json
 : > $O/${TAG}_workload_lines.jsonl
-for w in "--workload seg" "--workload seg256" "--workload infer-int8" "--batch 32" "--batch 64" "--precision fp32 --batch 64"; do
-  python3 bench.py $w --steps 8 --warmup 3 --no-cpu-baseline 2>> $O/bench.err | tail -1 >> $O/${TAG}_workload_lines.jsonl
+for w in "--workload seg" "--workload seg256" "--workload infer-int8" "--batch 32 --steps 24" "--batch 64 --steps 16" "--precision fp32 --batch 64"; do
+  python3 bench.py --steps 8 --warmup 3 --no-cpu-baseline $w 2>> $O/bench.err | tail -1 >> $O/${TAG}_workload_lines.jsonl
 done
 # the reference-tolerance modes next to the headline
 for w in "--precision bf16x3h" "--precision bf16x3" "--precision fp32" "--workload seg256 --precision bf16x3h" "--workload seg256 --precision bf16x3"; do
